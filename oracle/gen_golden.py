@@ -1,0 +1,147 @@
+"""Generate tests/golden/*.npz by running the REAL reference models (imported from /root/reference
+through oracle/ref_shims.py) on the deterministic synthetic weights/inputs of robo-vln_amd/synth.py.
+
+Run in the build container only:   python oracle/gen_golden.py [case ...]
+The goldens hold OUTPUTS (+ subsampled intermediates); inputs and weights are regenerated from
+the seed by whoever replays a case.  Also prints the max-abs difference between the reference and
+the oracle restatement (oracle/hcm_oracle.py) for each stored tensor.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hcm_pkg  # noqa: E402
+
+hcm_pkg.load()
+from robo_vln_amd import synth  # noqa: E402
+from oracle import cases, ref_shims, hcm_oracle  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _hook(store, name, pick=None):
+    def fn(mod, inp, out):
+        t = out if pick is None else pick(out)
+        store.setdefault(name, []).append(t.detach().clone())
+    return fn
+
+
+def run_case(name):
+    cfg, B, T, which = cases.case_config(name)
+    torch.manual_seed(0)
+    hi_sd = lo_sd = None
+    if which in ("both", "hi"):
+        hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
+    if which in ("both", "lo"):
+        lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
+    hi, lo = ref_shims.build_models(cfg, hi_sd, lo_sd, want_hi=hi_sd is not None, want_lo=lo_sd is not None)
+    taps = {}
+    if hi is not None:
+        hi.depth_encoder.register_forward_hook(_hook(taps, "hi.depth_spatial"))
+        hi.rgb_encoder.register_forward_hook(_hook(taps, "hi.rgb_spatial"))
+        hi.embedding_layer.register_forward_hook(_hook(taps, "hi.bert", lambda o: o[0]))
+        hi.image_cm_encoder.register_forward_hook(_hook(taps, "hi.vla"))
+        hi.state_encoder.register_forward_hook(_hook(taps, "hi.rnn_out", lambda o: o[0]))
+        hi.state_encoder.register_forward_pre_hook(lambda m, i: taps.setdefault("hi.rnn_in", []).append(i[0].detach().clone()))
+    if lo is not None:
+        lo.depth_encoder.register_forward_hook(_hook(taps, "lo.depth_flat"))
+        lo.rgb_encoder.register_forward_hook(_hook(taps, "lo.rgb_flat"))
+        lo.state_encoder.register_forward_pre_hook(lambda m, i: taps.setdefault("lo.rnn_in", []).append(i[0].detach().clone()))
+
+    R = cfg.num_recurrent_layers
+    hi_h = torch.zeros(R, B, cfg.hidden)
+    lo_h = torch.zeros(R, B, cfg.hidden)
+    prev = torch.zeros(B, 2, dtype=torch.long)
+    records = []
+    t0 = time.time()
+    with torch.no_grad():
+        for t in range(T):
+            obs_np = synth.make_observations(cfg, B, step=t, seed=cases.SEED)
+            # batch_obs contract: every sensor float32 (common/utils.py:78-83)
+            obs = {k: torch.from_numpy(v.astype(np.float32)) for k, v in obs_np.items()}
+            masks = ref_shims.ref_masks(cases.step_masks(B, t))
+            rec = []
+            if hi is not None:
+                logits, hi_h = hi((dict(obs), hi_h, prev, masks))     # copy: forward deletes 'instruction'
+                rec.append(logits)
+                pred = torch.argmax(logits, dim=1)
+            else:
+                rec.append(torch.zeros(B, 4))
+                pred = torch.from_numpy(cases.fixed_subtask(B, t))
+            if lo is not None:
+                vel, stop, lo_h = lo((dict(obs), lo_h, prev, masks, pred))
+                rec += [vel, stop]
+            else:
+                rec += [torch.zeros(B, 2), torch.zeros(B, 1)]
+            records.append(torch.cat(rec, dim=1))
+    dt = time.time() - t0
+    out = {"records": torch.stack(records).numpy(), "hi_hidden": hi_h.numpy(), "lo_hidden": lo_h.numpy()}
+    for k, v in taps.items():
+        if k == "hi.vla":
+            out["tap.hi.vla_rgb"] = cases.subsample(v[0].numpy())
+            out["tap.hi.vla_depth"] = cases.subsample(v[1].numpy())
+        else:
+            out["tap." + k] = cases.subsample(v[0].numpy())
+    meta = dict(case=name, config=repr(cfg.to_dict()), batch=B, steps=T, which=which, seed=cases.SEED,
+                torch=torch.__version__,
+                note="reference modules imported from /root/reference via oracle/ref_shims.py; torchvision resnet50 "
+                     "shim uses AdaptiveAvgPool2d(1) (SURVEY 8a-a3); BERT = transformers.BertModel(BertConfig) random init; "
+                     "taps are step-0 tensors flattened and subsampled by cases.subsample")
+    out["meta"] = np.array(repr(meta))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+    # cross-check the oracle restatement right here
+    worst = compare_oracle(name, out, hi_sd, lo_sd)
+    print(f"[{name}] reference ran {T} steps B={B} in {dt:.1f}s; oracle-vs-reference worst max-abs {worst:.3e}")
+    return worst
+
+
+def compare_oracle(name, gold, hi_sd, lo_sd):
+    cfg, B, T, which = cases.case_config(name)
+    R = cfg.num_recurrent_layers
+    hi_o = hcm_oracle.HighLevelOracle(cfg, hi_sd) if hi_sd is not None else None
+    lo_o = hcm_oracle.LowLevelOracle(cfg, lo_sd) if lo_sd is not None else None
+    hi_h = torch.zeros(R, B, cfg.hidden)
+    lo_h = torch.zeros(R, B, cfg.hidden)
+    worst = 0.0
+    for t in range(T):
+        obs = synth.make_observations(cfg, B, step=t, seed=cases.SEED)
+        m = cases.step_masks(B, t)
+        taps_hi, taps_lo = {}, {}
+        if hi_o is not None:
+            logits, hi_h = hi_o.forward(obs, hi_h, m, taps_hi if t == 0 else None)
+            pred = torch.argmax(logits, 1)
+        else:
+            logits = torch.zeros(B, 4)
+            pred = torch.from_numpy(cases.fixed_subtask(B, t))
+        if lo_o is not None:
+            vel, stop, lo_h = lo_o.forward(obs, lo_h, m, pred, taps_lo if t == 0 else None)
+        else:
+            vel, stop = torch.zeros(B, 2), torch.zeros(B, 1)
+        rec = torch.cat([logits, vel, stop], 1).numpy()
+        d = np.abs(rec - gold["records"][t]).max()
+        worst = max(worst, d)
+        if t == 0:
+            for pre, k, v in [("tap.hi.", k, v) for k, v in taps_hi.items()] + [("tap.lo.", k, v) for k, v in taps_lo.items()]:
+                if True:
+                    if pre + k in gold:
+                        g = gold[pre + k]
+                        dd = np.abs(cases.subsample(v.numpy()) - g).max()
+                        print(f"    {pre + k:24s} max-abs {dd:.3e}  (|gold| max {np.abs(g).max():.3f} std {g.std():.3f})")
+                        worst = max(worst, dd)
+        print(f"    step {t} record max-abs {d:.3e}   record={np.array2string(rec[0], precision=4)}")
+    return worst
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(cases.CASES)
+    bad = 0
+    for n in names:
+        w = run_case(n)
+        bad |= (w > 1e-4)
+    sys.exit(1 if bad else 0)

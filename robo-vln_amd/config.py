@@ -1,0 +1,94 @@
+"""Hyper-parameters of the HCM hot path.
+
+Values restate the reference's `MODEL.*` defaults
+(/root/reference/robo_vln_baselines/config/default.py:131,:156-164,:180-199 and
+paper_configs/hierarchical_cma.yaml) as a plain dataclass; yacs is not used.
+"""
+from dataclasses import dataclass, asdict
+
+
+@dataclass
+class HCMConfig:
+    # observation sizes (frames are NHWC)
+    rgb_hw: int = 256
+    depth_hw: int = 256
+    instr_len: int = 80            # L: tokens per instruction
+    # encoders: cnn_type strings are the reference's
+    rgb_encoder: str = "TorchVisionResNet50"      # or "SimpleRGBCNN" (low-level only)
+    depth_encoder: str = "VlnResnetDepthEncoder"  # or "SimpleDepthCNN" (low-level only)
+    rgb_out: int = 256             # RGB_ENCODER.output_size
+    depth_out: int = 128           # DEPTH_ENCODER.output_size
+    depth_baseplanes: int = 32     # resnet_encoders.py:19
+    # Visual_Ling_Attn (default.py:156-164)
+    vla_layers: int = 1
+    d_model: int = 256
+    vla_heads: int = 4
+    d_ff: int = 1024
+    vis_in: int = 256
+    ins_in: int = 768
+    cm_d_model: int = 256          # IMAGE_CROSS_MODAL_ENCODER.d_model (rnn input size sum only)
+    # state encoder
+    hidden: int = 512
+    rnn_type: str = "LSTM"         # default.py:199; "GRU" selectable
+    num_actions: int = 4           # high-level sub-task logits
+    num_sub_tasks: int = 4
+    lo_actions: int = 2            # (lin_vel, ang_vel)
+    # BERT (bert-base-uncased architecture); bert_layers may be reduced in CPU tests
+    bert_layers: int = 12
+    bert_hidden: int = 768
+    bert_heads: int = 12
+    bert_inter: int = 3072
+    bert_vocab: int = 30522
+    bert_max_pos: int = 512
+    # flags the reference has but whose branches are broken
+    use_prev_action: bool = False
+    ablate_instruction: bool = False
+    ablate_depth: bool = False
+    ablate_rgb: bool = False
+    progress_monitor: bool = False
+
+    def validate(self):
+        if self.use_prev_action:
+            raise ValueError("SEQ2SEQ.use_prev_action=True is a broken branch in the reference "
+                             "(seq2seq_highlevel_cma.py:203-207, undefined `x`); not supported")
+        if self.ablate_instruction:
+            raise ValueError("ablate_instruction=True is a broken branch in the reference "
+                             "(seq2seq_highlevel_cma.py:183-184); not supported")
+        if self.rnn_type not in ("LSTM", "GRU"):
+            raise ValueError("STATE_ENCODER.rnn_type must be LSTM or GRU")
+        if self.rgb_encoder not in ("TorchVisionResNet50", "SimpleRGBCNN"):
+            raise ValueError("RGB_ENCODER.cnn_type must be either 'SimpleRGBCNN' or 'TorchVisionResNet50'.")
+        if self.depth_encoder not in ("VlnResnetDepthEncoder", "SimpleDepthCNN"):
+            raise ValueError("DEPTH_ENCODER.cnn_type must be SimpleDepthCNN or VlnResnetDepthEncoder")
+        if self.d_model % self.vla_heads:
+            raise ValueError("d_model must be divisible by h")
+        return self
+
+    @property
+    def num_recurrent_layers(self):
+        # state_encoder.py:41-45
+        return 2 if self.rnn_type == "LSTM" else 1
+
+    def depth_final_spatial(self):
+        # habitat ResNetEncoder: spatial_size = H // 2; final = int(spatial * 1/32)
+        return int((self.depth_hw // 2) / 32)
+
+    def depth_compress_channels(self):
+        fs = self.depth_final_spatial()
+        return int(round(2048 / (fs * fs)))
+
+    def to_dict(self):
+        return asdict(self)
+
+
+# BASELINE.json configs[0..4]
+def baseline_config(idx: int) -> "HCMConfig":
+    if idx == 0:   # plumbing: 128x128, L=20, N=2
+        return HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, vla_layers=2)
+    if idx in (1, 2):  # full HCM 256x256, L=80, N=1
+        return HCMConfig()
+    if idx == 3:   # SimpleDepthCNN + 1-layer VLA microbench
+        return HCMConfig(depth_encoder="SimpleDepthCNN", vla_layers=1)
+    if idx == 4:   # ResNet50 + N=6, L=160
+        return HCMConfig(instr_len=160, vla_layers=6)
+    raise IndexError(idx)
