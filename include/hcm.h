@@ -1,0 +1,156 @@
+/*
+ * libhcm -- MI355X-native per-step policy forward of robo-vln's Hierarchical Cross-Modal agent.
+ *
+ * Plain C ABI (no torch types): pointers, sizes, an opaque handle.  Every entry point returns an
+ * int status (0 = ok, negative = hcm_status) and records a message readable by hcm_last_error().
+ * All I/O buffers of the forward calls are caller-owned DEVICE pointers; weights passed to
+ * hcm_load_tensor are HOST pointers.  All work of a forward call is enqueued on the passed
+ * hipStream_t (as void*); no host synchronisation happens inside a forward call.  A handle is not
+ * thread-safe: one handle per device per thread.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/robo_vln_baselines/).  The reference is pure Python with no FFI; the ctypes
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef HCM_H
+#define HCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hcm_ctx* hcm_handle;
+
+enum hcm_status {
+    HCM_OK = 0,
+    HCM_ERR_ARG = -1,          /* null / out-of-range argument                         (Python: ValueError)  */
+    HCM_ERR_STATE = -2,        /* call order violated (e.g. forward before finalize)   (RuntimeError)        */
+    HCM_ERR_KEY = -3,          /* unknown or missing state_dict key                    (KeyError)            */
+    HCM_ERR_SHAPE = -4,        /* tensor shape does not match the configured model     (ValueError)          */
+    HCM_ERR_HIP = -5,          /* HIP runtime error                                    (RuntimeError)        */
+    HCM_ERR_UNSUPPORTED = -6,  /* configuration the reference itself cannot run        (ValueError)          */
+    HCM_ERR_NOMEM = -7
+};
+
+enum hcm_dtype { HCM_F32 = 0, HCM_BF16 = 1, HCM_I32 = 2, HCM_I64 = 3, HCM_U8 = 4 };
+enum hcm_model { HCM_HIGH = 0, HCM_LOW = 1 };
+enum hcm_encoder { HCM_ENC_RESNET = 0, HCM_ENC_SIMPLECNN = 1 };
+enum hcm_rnn { HCM_LSTM = 0, HCM_GRU = 1 };
+
+/* hcm_query() selectors: properties the reference's callers read from the models
+ * (state_encoder.num_recurrent_layers hierarchical_trainer.py:1053,:1059; MODEL.STATE_ENCODER.hidden_size). */
+enum hcm_query_what {
+    HCM_NUM_RECURRENT_LAYERS = 0,  /* 2 for LSTM (cat[h,c]), 1 for GRU: models/decoder/state_encoder.py:41-45 */
+    HCM_HIDDEN_SIZE = 1,
+    HCM_NUM_ACTIONS = 2,           /* high-level sub-task logits (4) */
+    HCM_RECORD_WIDTH = 3,          /* 7 = 4 logits + (v, w) + stop logit */
+    HCM_WORKSPACE_BYTES = 4,
+    HCM_WEIGHT_BYTES = 5,
+    HCM_MAX_BATCH = 6
+};
+
+/* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,
+ * :180-199).  Zero-initialise, set struct_size = sizeof(hcm_config), fill. */
+typedef struct hcm_config {
+    int32_t struct_size;
+    int32_t precision;        /* HCM_BF16 (bf16 storage + MFMA, fp32 accumulate) or HCM_F32 (fp32 storage + fp32 MFMA) */
+    int32_t max_batch;        /* workspace is sized for this many environments per call */
+    int32_t rgb_h, rgb_w;     /* frames are NHWC */
+    int32_t depth_h, depth_w;
+    int32_t instr_len;        /* L */
+    int32_t rgb_encoder;      /* hcm_encoder; SIMPLECNN is valid for the low-level model only */
+    int32_t depth_encoder;
+    int32_t rgb_out, depth_out, depth_baseplanes;
+    int32_t vla_layers, d_model, vla_heads, d_ff, vis_in, ins_in;
+    int32_t hidden, rnn_type, num_actions, num_sub_tasks, lo_actions;
+    int32_t bert_layers, bert_hidden, bert_heads, bert_inter, bert_vocab, bert_max_pos;
+    int32_t build_high, build_low;      /* which of the two models this handle holds */
+    int32_t use_prev_action;            /* must be 0: broken branch in the reference (seq2seq_highlevel_cma.py:203-207) */
+    int32_t ablate_instruction;         /* must be 0: broken branch (:183-184) */
+    int32_t progress_monitor;           /* must be 0 in forward (:221-225 references an undefined name) */
+    int32_t reserved[8];
+} hcm_config;
+
+/* Replaces model construction, hierarchical_trainer.py:315-328 (Seq2Seq_HighLevel_CMA.__init__
+ * models/seq2seq_highlevel_cma.py:33-141, Seq2Seq_LowLevel.__init__ models/seq2seq_lowlevel.py:32-98).
+ * Rejects the flags whose branches crash in the reference. */
+int hcm_create(const hcm_config* cfg, hcm_handle* out);
+
+/* Replaces `load_state_dict(ckpt["high_level_state_dict"])` / `["low_level_state_dict"]`
+ * (hierarchical_trainer.py:343-345): call once per state_dict entry with the reference's own key.
+ * `data` is a HOST pointer to a contiguous tensor of `dtype` (HCM_F32 or HCM_I64); it is copied.
+ * Unknown keys fail with HCM_ERR_KEY, wrong shapes with HCM_ERR_SHAPE (strict=True semantics). */
+int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, int dtype,
+                    const int64_t* shape, int ndim);
+
+/* After the last hcm_load_tensor: checks that every required key arrived, folds eval-mode BatchNorm into
+ * the convolutions, re-lays weights out for NHWC implicit GEMM, converts to the compute precision,
+ * uploads, and allocates the per-handle workspace for max_batch.  (The reference does the equivalent
+ * implicitly in `.to(device)` + `.eval()`, hierarchical_trainer.py:339-340,:1080-1081.) */
+int hcm_finalize(hcm_handle h);
+
+/* Replaces `logits, hidden' = high_level((observations, hidden, prev_actions, masks))`
+ * (hierarchical_trainer.py:1096-1097 -> models/seq2seq_highlevel_cma.py:170-233).
+ *   rgb    (B,H,W,3)  rgb_dtype HCM_F32 (values 0..255, the batch_obs contract common/utils.py:78-83) or HCM_U8
+ *   depth  (B,H,W,1)  f32
+ *   ids    (B,L)      ids_dtype HCM_I32 / HCM_I64 / HCM_F32 (the reference carries ids as f32 and casts .long())
+ *   h_in   (R,B,hidden) f32, R = hcm_query(HCM_NUM_RECURRENT_LAYERS)
+ *   mask   (B,) f32   -- column 0 of the reference's masks (masks[:,0], :208); 0 at episode start
+ *   logits (B,num_actions) f32 out;  h_out (R,B,hidden) f32 out (may alias h_in)
+ * prev_actions is ignored on the working path of the reference and is not part of this ABI. */
+int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
+                     const void* ids, int ids_dtype, int B,
+                     const float* h_in, const float* mask,
+                     float* logits, float* h_out, void* stream);
+
+/* Replaces `vel, stop, hidden' = low_level((observations, hidden, prev_actions, masks, subtask))`
+ * (hierarchical_trainer.py:1099-1100 -> models/seq2seq_lowlevel.py:116-162).
+ *   subtask (B,) int64 in [0, num_sub_tasks];  vel (B,2) f32;  stop (B,1) f32 (logit). */
+int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, int B,
+                    const float* h_in, const float* mask, const int64_t* subtask,
+                    float* vel, float* stop, float* h_out, void* stream);
+
+/* The caller-side step of the eval loop, hierarchical_trainer.py:1095-1101: high -> argmax(dim=1) -> low.
+ *   record (B,7) f32 out: [4 sub-task logits, lin_vel, ang_vel, stop logit]. */
+int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
+            const void* ids, int ids_dtype, int B,
+            const float* hi_h_in, const float* lo_h_in, const float* mask,
+            float* record, float* hi_h_out, float* lo_h_out, void* stream);
+
+int hcm_query(hcm_handle h, int what, int64_t* out);
+
+/* Message of the last failing call on this handle (or on creation when h is NULL). */
+const char* hcm_last_error(hcm_handle h);
+
+void hcm_destroy(hcm_handle h);
+
+/* ---- test / profiling hooks (not part of the drop-in surface) ---- */
+
+/* Enable capture of named intermediate activations during the next forward calls. */
+int hcm_debug_enable_taps(hcm_handle h, int enable);
+/* Copy a captured intermediate (as f32) to host; synchronises the device.  *n_out = element count;
+ * shape_out receives up to 4 dims (0-padded). */
+int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t capacity,
+                      int64_t* n_out, int64_t* shape_out);
+
+/* Stand-alone operator entry points used by the kernel-level parity tests (device pointers, f32 or bf16
+ * per `dtype`; layouts NHWC / row-major).  See robo-vln_amd/csrc/ops_api.cpp. */
+int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y,
+                  int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                  int act, void* stream);
+int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                  int dtype, int M, int N, int K, int act, int out_f32, void* stream);
+int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype,
+                     int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, void* stream);
+int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
+                     void* y, int dtype, int rows, int D, float eps, void* stream);
+int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta,
+                     int dtype, int B, int HW, int C, int groups, float eps, int relu, void* stream);
+int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCM_H */

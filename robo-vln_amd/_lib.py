@@ -1,0 +1,78 @@
+"""ctypes binding of libhcm.so (include/hcm.h).  The HIP library is the product path: if it is missing
+this module raises -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhcm.so")
+
+HCM_F32, HCM_BF16, HCM_I32, HCM_I64, HCM_U8 = 0, 1, 2, 3, 4
+HCM_HIGH, HCM_LOW = 0, 1
+HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
+HCM_LSTM, HCM_GRU = 0, 1
+(HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
+ HCM_WEIGHT_BYTES, HCM_MAX_BATCH) = range(7)
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: KeyError, -4: ValueError, -5: RuntimeError, -6: ValueError,
+              -7: MemoryError}
+
+
+class HcmConfigStruct(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "precision", "max_batch", "rgb_h", "rgb_w", "depth_h", "depth_w", "instr_len",
+        "rgb_encoder", "depth_encoder", "rgb_out", "depth_out", "depth_baseplanes",
+        "vla_layers", "d_model", "vla_heads", "d_ff", "vis_in", "ins_in",
+        "hidden", "rnn_type", "num_actions", "num_sub_tasks", "lo_actions",
+        "bert_layers", "bert_hidden", "bert_heads", "bert_inter", "bert_vocab", "bert_max_pos",
+        "build_high", "build_low", "use_prev_action", "ablate_instruction", "progress_monitor")] + [("reserved", C.c_int32 * 8)]
+
+
+EXPORTS = {
+    "hcm_create": (C.c_int, [C.POINTER(HcmConfigStruct), C.POINTER(C.c_void_p)]),
+    "hcm_load_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "hcm_finalize": (C.c_int, [C.c_void_p]),
+    "hcm_high_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hcm_low_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hcm_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "hcm_last_error": (C.c_char_p, [C.c_void_p]),
+    "hcm_destroy": (None, [C.c_void_p]),
+    "hcm_debug_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),
+    "hcm_debug_get_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hcm_op_conv2d": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 11 + [C.c_void_p]),
+    "hcm_op_linear": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
+    "hcm_op_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]),
+    "hcm_op_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "hcm_op_groupnorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p]),
+    "hcm_op_maxpool3x3s2": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libhcm.so (built in-tree by `__graft_entry__.build()` / `make -C robo-vln_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP library is the only compute path; there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(l, name)      # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc == 0:
+        return
+    msg = lib().hcm_last_error(handle)
+    msg = msg.decode() if msg else f"libhcm error {rc}"
+    raise STATUS_EXC.get(rc, RuntimeError)(msg)

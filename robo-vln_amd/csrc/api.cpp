@@ -1,0 +1,304 @@
+// C ABI of libhcm (include/hcm.h).
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "model.h"
+
+namespace hcm {
+void build_spec_high(hcm_ctx* ctx);
+void build_spec_low(hcm_ctx* ctx);
+void prepare_high(hcm_ctx* ctx);
+void prepare_low(hcm_ctx* ctx);
+void run_high(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
+              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out);
+void run_low(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
+             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out);
+}  // namespace hcm
+
+using namespace hcm;
+
+static thread_local std::string g_create_err;
+
+static int fail(hcm_ctx* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define REQUIRE(cond, code, msg) do { if (!(cond)) return fail(h, code, msg); } while (0)
+
+extern "C" {
+
+int hcm_create(const hcm_config* cfg, hcm_handle* out) {
+    hcm_ctx* h = nullptr;
+    REQUIRE(cfg && out, HCM_ERR_ARG, "hcm_create: null argument");
+    REQUIRE(cfg->struct_size == (int32_t)sizeof(hcm_config), HCM_ERR_ARG, "hcm_create: struct_size mismatch");
+    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16, HCM_ERR_ARG, "precision must be HCM_F32 or HCM_BF16");
+    REQUIRE(cfg->max_batch >= 1, HCM_ERR_ARG, "max_batch must be >= 1");
+    // flags whose branches crash in the reference are rejected, not emulated
+    REQUIRE(!cfg->use_prev_action, HCM_ERR_UNSUPPORTED,
+            "SEQ2SEQ.use_prev_action=True is a broken branch in the reference (seq2seq_highlevel_cma.py:203-207)");
+    REQUIRE(!cfg->ablate_instruction, HCM_ERR_UNSUPPORTED,
+            "ablate_instruction=True is a broken branch in the reference (seq2seq_highlevel_cma.py:183-184)");
+    REQUIRE(!cfg->progress_monitor, HCM_ERR_UNSUPPORTED,
+            "PROGRESS_MONITOR.use in forward references an undefined name (seq2seq_highlevel_cma.py:221-225)");
+    REQUIRE(cfg->rnn_type == HCM_LSTM || cfg->rnn_type == HCM_GRU, HCM_ERR_ARG, "STATE_ENCODER.rnn_type must be LSTM or GRU");
+    REQUIRE(cfg->build_high || cfg->build_low, HCM_ERR_ARG, "nothing to build");
+    if (cfg->build_high) {
+        REQUIRE(cfg->rgb_encoder == HCM_ENC_RESNET && cfg->depth_encoder == HCM_ENC_RESNET, HCM_ERR_UNSUPPORTED,
+                "Seq2Seq_HighLevel_CMA needs TorchVisionResNet50 + VlnResnetDepthEncoder: SimpleCNN encoders have no "
+                "output_shape (seq2seq_highlevel_cma.py:87,:96)");
+        REQUIRE(cfg->d_model == 256 && cfg->vis_in % 32 == 0 && cfg->ins_in == cfg->bert_hidden, HCM_ERR_UNSUPPORTED,
+                "VISUAL_LING_ATTN: d_model must be 256 and ins_in_features must equal the BERT width");
+        REQUIRE(cfg->d_model / cfg->vla_heads == 64 && cfg->bert_hidden / cfg->bert_heads == 64, HCM_ERR_UNSUPPORTED,
+                "attention head dim must be 64");
+        REQUIRE(cfg->bert_hidden == 768 && cfg->instr_len >= 1 && cfg->instr_len <= 160 && cfg->instr_len <= cfg->bert_max_pos,
+                HCM_ERR_UNSUPPORTED, "BERT width must be 768 and 1 <= instr_len <= 160");
+        REQUIRE(cfg->vla_layers >= 1 && cfg->bert_layers >= 1, HCM_ERR_ARG, "layer counts must be >= 1");
+    }
+    REQUIRE(cfg->hidden == 512 || cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
+    REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
+    if (cfg->depth_encoder == HCM_ENC_RESNET)
+        REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0, HCM_ERR_UNSUPPORTED, "depth frame size must be a multiple of 64");
+    if (cfg->rgb_encoder == HCM_ENC_RESNET)
+        REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
+    REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
+    REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0, HCM_ERR_UNSUPPORTED, "encoder output sizes must be multiples of 4");
+    h = new hcm_ctx();
+    h->cfg = *cfg;
+    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
+    h->esz = dt_size(h->dt);
+    try {
+        if (cfg->build_high) build_spec_high(h);
+        if (cfg->build_low) build_spec_low(h);
+    } catch (const std::exception& e) {
+        std::string m = e.what();
+        delete h;
+        h = nullptr;
+        return fail(nullptr, HCM_ERR_ARG, m);
+    }
+    *out = h;
+    return HCM_OK;
+}
+
+int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    REQUIRE(!h->finalized, HCM_ERR_STATE, "hcm_load_tensor after hcm_finalize");
+    REQUIRE(model == HCM_HIGH || model == HCM_LOW, HCM_ERR_ARG, "model must be HCM_HIGH or HCM_LOW");
+    REQUIRE(key && data && (shape || ndim == 0), HCM_ERR_ARG, "null argument");
+    auto& sd = h->sd[model];
+    auto it = sd.find(key);
+    REQUIRE(it != sd.end(), HCM_ERR_KEY, std::string("Unexpected key in state_dict: ") + key);
+    HostTensor& t = it->second;
+    bool same = (int)t.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = t.shape[i] == shape[i];
+    if (!same) {
+        std::string m = std::string("size mismatch for ") + key + ": expected (";
+        for (auto d : t.shape) m += std::to_string(d) + ",";
+        m += ") got (";
+        for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
+        return fail(h, HCM_ERR_SHAPE, m + ")");
+    }
+    size_t n = 1;
+    for (auto d : t.shape) n *= (size_t)d;
+    t.f.resize(n);
+    if (dtype == HCM_F32) std::memcpy(t.f.data(), data, n * 4);
+    else if (dtype == HCM_I64) for (size_t i = 0; i < n; ++i) t.f[i] = (float)((const int64_t*)data)[i];
+    else return fail(h, HCM_ERR_ARG, "hcm_load_tensor: dtype must be HCM_F32 or HCM_I64");
+    t.loaded = true;
+    return HCM_OK;
+}
+
+static void dry_run(hcm_ctx* h, int B) {
+    h->arena.dry = true;
+    h->arena.peak = 0;
+    if (h->cfg.build_high) run_high(h, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr, 0, nullptr);
+    if (h->cfg.build_low) run_low(h, nullptr, DT_F32, nullptr, B, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
+}
+
+int hcm_finalize(hcm_handle h) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    REQUIRE(!h->finalized, HCM_ERR_STATE, "hcm_finalize called twice");
+    for (int m = 0; m < 2; ++m)
+        for (auto& kv : h->sd[m])
+            if (!kv.second.loaded) return fail(h, HCM_ERR_KEY, std::string("Missing key in state_dict: ") + kv.first);
+    try {
+        if (h->cfg.build_high) prepare_high(h);
+        if (h->cfg.build_low) prepare_low(h);
+        dry_run(h, h->cfg.max_batch);
+        h->arena.cap = h->arena.peak + 4096;
+        if (hipMalloc((void**)&h->arena.base, h->arena.cap) != hipSuccess)
+            return fail(h, HCM_ERR_NOMEM, "hipMalloc of the workspace failed (" + std::to_string(h->arena.cap) + " bytes)");
+        if (hipMalloc((void**)&h->pred_buf, (size_t)h->cfg.max_batch * sizeof(int64_t)) != hipSuccess)
+            return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+        h->arena.dry = false;
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, std::string("hcm_finalize: ") + e.what());
+    }
+    // host copies are no longer needed
+    for (int m = 0; m < 2; ++m)
+        for (auto& kv : h->sd[m]) { std::vector<float>().swap(kv.second.f); }
+    h->finalized = true;
+    return HCM_OK;
+}
+
+static int check_fwd(hcm_ctx* h, int B) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    REQUIRE(h->finalized, HCM_ERR_STATE, "forward before hcm_finalize");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, HCM_ERR_ARG, "batch must be in [1, max_batch]");
+    return HCM_OK;
+}
+
+static bool rgb_dt_ok(int d) { return d == HCM_F32 || d == HCM_U8; }
+static bool ids_dt_ok(int d) { return d == HCM_F32 || d == HCM_I32 || d == HCM_I64; }
+
+int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+                     const float* h_in, const float* mask, float* logits, float* h_out, void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
+    REQUIRE(rgb && depth && ids && h_in && mask && logits && h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
+    h->stream = (hipStream_t)stream;
+    try {
+        run_high(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, logits, h->cfg.num_actions, h_out);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, int B, const float* h_in,
+                    const float* mask, const int64_t* subtask, float* vel, float* stop, float* h_out, void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_low, HCM_ERR_STATE, "handle holds no low-level model");
+    REQUIRE(rgb && depth && h_in && mask && subtask && vel && stop && h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype), HCM_ERR_ARG, "unsupported rgb dtype");
+    h->stream = (hipStream_t)stream;
+    try {
+        run_low(h, rgb, rgb_dtype, depth, B, h_in, mask, subtask, vel, h->cfg.lo_actions, stop, 1, h_out);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+            const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+            void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_high && h->cfg.build_low, HCM_ERR_STATE, "hcm_act needs both models in the handle");
+    REQUIRE(rgb && depth && ids && hi_h_in && lo_h_in && mask && record && hi_h_out && lo_h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
+    REQUIRE(h->cfg.num_actions + h->cfg.lo_actions + 1 == 7, HCM_ERR_UNSUPPORTED, "record layout assumes 4 + 2 + 1 outputs");
+    h->stream = (hipStream_t)stream;
+    try {
+        const int ld = 7;
+        run_high(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, mask, record, ld, hi_h_out);
+        // pred = argmax(output, dim=1)  (hierarchical_trainer.py:1098)
+        if (launch_argmax(record, h->pred_buf, B, h->cfg.num_actions, ld, h->stream) != hipSuccess)
+            return fail(h, HCM_ERR_HIP, "argmax launch failed");
+        run_low(h, rgb, rgb_dtype, depth, B, lo_h_in, mask, h->pred_buf, record + 4, ld, record + 6, ld, lo_h_out);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_query(hcm_handle h, int what, int64_t* out) {
+    REQUIRE(h && out, HCM_ERR_ARG, "null argument");
+    switch (what) {
+        case HCM_NUM_RECURRENT_LAYERS: *out = h->cfg.rnn_type == HCM_LSTM ? 2 : 1; break;
+        case HCM_HIDDEN_SIZE: *out = h->cfg.hidden; break;
+        case HCM_NUM_ACTIONS: *out = h->cfg.num_actions; break;
+        case HCM_RECORD_WIDTH: *out = h->cfg.num_actions + h->cfg.lo_actions + 1; break;
+        case HCM_WORKSPACE_BYTES: *out = (int64_t)h->arena.cap; break;
+        case HCM_WEIGHT_BYTES: *out = (int64_t)h->weight_bytes; break;
+        case HCM_MAX_BATCH: *out = h->cfg.max_batch; break;
+        default: return fail(h, HCM_ERR_ARG, "hcm_query: unknown selector");
+    }
+    return HCM_OK;
+}
+
+const char* hcm_last_error(hcm_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+void hcm_destroy(hcm_handle h) {
+    if (!h) return;
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    if (h->arena.base) (void)hipFree(h->arena.base);
+    if (h->pred_buf) (void)hipFree(h->pred_buf);
+    for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    delete h;
+}
+
+int hcm_debug_enable_taps(hcm_handle h, int enable) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    h->taps_on = enable != 0;
+    return HCM_OK;
+}
+
+int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t capacity, int64_t* n_out, int64_t* shape_out) {
+    REQUIRE(h && name && n_out, HCM_ERR_ARG, "null argument");
+    auto it = h->taps.find(name);
+    REQUIRE(it != h->taps.end(), HCM_ERR_KEY, std::string("no such tap: ") + name);
+    const Tap& t = it->second;
+    *n_out = (int64_t)t.n;
+    if (shape_out) for (int i = 0; i < 4; ++i) shape_out[i] = i < (int)t.shape.size() ? t.shape[i] : 0;
+    if (host_out) {
+        REQUIRE(capacity >= (int64_t)t.n, HCM_ERR_ARG, "tap buffer too small");
+        if (hipDeviceSynchronize() != hipSuccess) return fail(h, HCM_ERR_HIP, "hipDeviceSynchronize failed");
+        if (hipMemcpy(host_out, t.dev, t.n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HCM_ERR_HIP, "tap copy failed");
+    }
+    return HCM_OK;
+}
+
+// ------------------------------------------------------------------ stand-alone operators (kernel-level parity tests)
+static int op_rc(hipError_t e) {
+    if (e == hipSuccess) return HCM_OK;
+    g_create_err = std::string("op launch failed: ") + hipGetErrorString(e);
+    return e == hipErrorInvalidValue ? HCM_ERR_ARG : HCM_ERR_HIP;
+}
+static int op_dt(int dtype) { return dtype == HCM_BF16 ? DT_BF16 : DT_F32; }
+
+int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y, int dtype, int B, int H,
+                  int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
+    IGemm g;
+    g.x = x; g.w = w_ohwi; g.bias = bias; g.res = residual; g.y = y;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.xC = Cin;
+    g.Ho = (H + 2 * pad - KH) / stride + 1; g.Wo = (W + 2 * pad - KW) / stride + 1;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = act;
+    return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+}
+int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y, int dtype, int M, int N, int K,
+                  int act, int out_f32, void* stream) {
+    IGemm g;
+    g.x = x; g.w = w; g.bias = bias; g.res = residual; g.y = y;
+    g.B = M; g.Cin = K; g.xC = K; g.M = M; g.N = N; g.K = K; g.Kp = K; g.ldy = N; g.ldr = N; g.act = act; g.out_f32 = out_f32;
+    return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+}
+int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int heads, int Lq, int Lk, int ldq,
+                     int ldk, int ldv, int ldo, void* stream) {
+    return op_rc(launch_attention(q, k, v, out, op_dt(dtype), B, heads, Lq, Lk, ldq, ldk, ldv, ldo, B, (hipStream_t)stream));
+}
+int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, const float* beta, void* y, int dtype, int rows,
+                     int D, float eps, void* stream) {
+    return op_rc(launch_layernorm(x, residual, gamma, beta, nullptr, 0, y, op_dt(dtype), rows, D, eps, (hipStream_t)stream));
+}
+int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta, int dtype, int B, int HW, int C,
+                     int groups, float eps, int relu, void* stream) {
+    float* stats = nullptr;
+    if (hipMalloc((void**)&stats, (size_t)B * groups * 2 * sizeof(float)) != hipSuccess) return HCM_ERR_NOMEM;
+    int rc = op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, stats, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(stats);
+    return rc;
+}
+int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    return op_rc(launch_maxpool3x3s2(x, y, op_dt(dtype), B, H, W, C, Ho, Wo, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,545 @@
+// Memory-bound kernels of the HCM step: first-layer im2col, pooling, GroupNorm, LayerNorm, BERT
+// embeddings, recurrent cells + heads, small glue.  All are HBM/L2-bound: 16-byte vector accesses,
+// grid-stride loops, wave64 reductions.
+#include "kernels.h"
+#include "dev.h"
+
+namespace hcm {
+
+static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------ im2col (first conv)
+// Replaces: `permute(0,3,1,2)`, `/255` (resnet_encoders.py:211-213, simple_cnns.py:144-145) + the gather half of
+// the first convolution (7x7/2 of both ResNets, 8x8/4 of SimpleCNN), whose Cin (1 or 3) is too narrow for the
+// 16-byte implicit-GEMM gather.  One thread produces one 16-byte chunk of the [M][Kp] matrix.
+template <typename S> __device__ __forceinline__ float ld_src(const S* p);
+template <> __device__ __forceinline__ float ld_src<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_src<uint8_t>(const uint8_t* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ld_src<bf16>(const bf16* p) { return bf2f(p->v); }
+
+template <typename S, typename T>
+__global__ void im2col_kernel(const S* __restrict__ x, T* __restrict__ a, int B, int H, int W, int C, int KH, int KW,
+                              int stride, int pad, int Ho, int Wo, int K, int Kp, float scale) {
+    constexpr int CH = Tr<T>::CH;
+    const int kchunks = Kp / CH;
+    const size_t total = (size_t)B * Ho * Wo * kchunks;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(e % kchunks);
+        const size_t m = e / kchunks;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((size_t)Wo * Ho));
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = kc * CH + j;
+            float val = 0.f;
+            if (k < K) {
+                const int ci = k % C;
+                const int khw = k / C;
+                const int kh = khw / KW, kw = khw - kh * KW;
+                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    val = ld_src<S>(x + ((size_t)(b * H + iy) * W + ix) * C + ci) * scale;
+            }
+            v[j] = val;
+        }
+        st_chunk(a + m * Kp + (size_t)kc * CH, v);
+    }
+}
+
+hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C, int KH, int KW,
+                         int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s) {
+    const int K = KH * KW * C;
+    const int CH = dt == DT_BF16 ? 8 : 4;
+    const size_t total = (size_t)B * Ho * Wo * (Kp / CH);
+    const int g = grid_for(total, 256, 256 * 32);
+#define L(S, T) hipLaunchKernelGGL((im2col_kernel<S, T>), dim3(g), dim3(256), 0, s, (const S*)x, (T*)a, B, H, W, C, KH, KW, stride, pad, Ho, Wo, K, Kp, scale)
+    if (dt == DT_BF16) {
+        if (src_dt == DT_F32) L(float, bf16); else if (src_dt == DT_U8) L(uint8_t, bf16); else if (src_dt == DT_BF16) L(bf16, bf16); else return hipErrorInvalidValue;
+    } else {
+        if (src_dt == DT_F32) L(float, float); else if (src_dt == DT_U8) L(uint8_t, float); else return hipErrorInvalidValue;
+    }
+#undef L
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ depth avg_pool2d(2)
+// habitat ResNetEncoder.forward: F.avg_pool2d(x, 2) on the (B,1,H,W) depth frame.
+template <typename T>
+__global__ void avgpool2_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % Wo);
+        const int oy = (int)((e / Wo) % Ho);
+        const int b = (int)(e / ((size_t)Wo * Ho));
+        const float* p = x + ((size_t)(b * H + 2 * oy) * W + 2 * ox);
+        const float2 r0 = *reinterpret_cast<const float2*>(p);
+        const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+        Tr<T>::st(y + e, ((r0.x + r0.y) + (r1.x + r1.y)) * 0.25f);
+    }
+}
+hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)B * (H / 2) * (W / 2);
+    if (W & 1) return hipErrorInvalidValue;
+    if (dt == DT_BF16) hipLaunchKernelGGL(avgpool2_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, B, H, W);
+    else hipLaunchKernelGGL(avgpool2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, B, H, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ MaxPool2d(3, 2, 1) NHWC
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CH = Tr<T>::CH;
+    const int cv = C / CH;
+    const size_t total = (size_t)B * Ho * Wo * cv;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % cv) * CH;
+        const size_t pix = e / cv;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((size_t)Wo * Ho));
+        float m[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) m[j] = -3.0e38f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float v[CH];
+                ld_chunk(x + ((size_t)(b * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        st_chunk(y + pix * C + c, m);
+    }
+}
+hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    const int CH = dt == DT_BF16 ? 8 : 4;
+    if (C % CH) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * Ho * Wo * (C / CH);
+    if (dt == DT_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ adaptive_avg_pool2d NHWC
+// F.adaptive_avg_pool2d(x,(OH,OW)) (resnet_encoders.py:160-166) / AdaptiveAvgPool2d(1): window [floor(i*H/OH), ceil((i+1)*H/OH)).
+template <typename T>
+__global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH, int OW, int ldy) {
+    constexpr int CH = Tr<T>::CH;
+    const int cv = C / CH;
+    const size_t total = (size_t)B * OH * OW * cv;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % cv) * CH;
+        const size_t pix = e / cv;
+        const int ox = (int)(pix % OW);
+        const int oy = (int)((pix / OW) % OH);
+        const int b = (int)(pix / ((size_t)OW * OH));
+        const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+        const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+        float acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                float v[CH];
+                ld_chunk(x + ((size_t)(b * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+                for (int j = 0; j < CH; ++j) acc[j] += v[j];
+            }
+        const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] *= inv;
+        st_chunk(y + pix * ldy + c, acc);
+    }
+}
+hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s) {
+    const int CH = dt == DT_BF16 ? 8 : 4;
+    if (C % CH || ldy % CH) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * OH * OW * (C / CH);
+    if (dt == DT_BF16) hipLaunchKernelGGL(adaptive_pool_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, H, W, C, OH, OW, ldy);
+    else hipLaunchKernelGGL(adaptive_pool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, OH, OW, ldy);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ mean over rows
+// AdaptiveAvgPool1d(1) over tokens: rgb_linear.0 (seq2seq_highlevel_cma.py:83-85), cross_pooler (:114-115,:209-210).
+template <typename T>
+__global__ void mean_rows_kernel(const T* __restrict__ x, void* __restrict__ y, int B, int S, int C, int ldx, int ldy, int out_f32) {
+    const size_t total = (size_t)B * C;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int b = (int)(e / C);
+        const T* p = x + (size_t)b * S * ldx + c;
+        float acc = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) acc += Tr<T>::ld(p + (size_t)s_ * ldx);
+        acc /= (float)S;
+        if (out_f32) reinterpret_cast<float*>(y)[(size_t)b * ldy + c] = acc;
+        else Tr<T>::st(reinterpret_cast<T*>(y) + (size_t)b * ldy + c, acc);
+    }
+}
+hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s) {
+    const size_t total = (size_t)B * C;
+    if (dt == DT_BF16) hipLaunchKernelGGL(mean_rows_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, y, B, S, C, ldx, ldy, out_f32);
+    else hipLaunchKernelGGL(mean_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, y, B, S, C, ldx, ldy, out_f32);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void fill_cols_kernel(const float* __restrict__ tab, T* __restrict__ y, int B, int S, int C, int ldy) {
+    const size_t total = (size_t)B * S * C;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const size_t row = e / C;            // b*S + s
+        const int s_ = (int)(row % S);
+        Tr<T>::st(y + row * ldy + c, tab[s_ * C + c]);
+    }
+}
+hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int C, int ldy, hipStream_t s) {
+    const size_t total = (size_t)B * S * C;
+    if (dt == DT_BF16) hipLaunchKernelGGL(fill_cols_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, tab, (bf16*)y, B, S, C, ldy);
+    else hipLaunchKernelGGL(fill_cols_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, tab, (float*)y, B, S, C, ldy);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm (NHWC, in place)
+// nn.GroupNorm(ngroups, C) after every conv of the habitat ResNet; statistics per (sample, group) in f32.
+// Pass 1: per-sample partial sums -> atomics into stats[b][g][{sum,sumsq}].  Pass 2: normalise (+res) (+ReLU).
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int HW, int C, int G) {
+    constexpr int CH = Tr<T>::CH;
+    __shared__ float sh[2 * 64];             // G <= 64
+    const int b = blockIdx.y;
+    const int cv = C / CH;
+    const int Cg = C / G;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    const size_t n = (size_t)HW * cv;
+    const T* xb = x + (size_t)b * HW * C;
+    // blockDim.x * gridDim.x is a multiple of cv, so a thread always sees the same channel chunk
+    const size_t start = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (size_t e = start; e < n; e += step) {
+        float v[CH];
+        ld_chunk(xb + e * CH, v);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+    }
+    if (start < n) {
+        const int c0 = (int)(start % cv) * CH;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int g = (c0 + j) / Cg;
+            atomicAdd(&sh[2 * g], s1[j]);
+            atomicAdd(&sh[2 * g + 1], s2[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(size_t)b * 2 * G + i], sh[i]);
+}
+
+template <typename T>
+__global__ void gn_apply_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ stats, int B, int HW, int C, int G,
+                                float eps, int relu) {
+    constexpr int CH = Tr<T>::CH;
+    const int cv = C / CH;
+    const int Cg = C / G;
+    const float inv_n = 1.0f / ((float)HW * (float)Cg);
+    const size_t per = (size_t)HW * cv;
+    const size_t total = (size_t)B * per;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / per);
+        const int c0 = (int)(e % cv) * CH;
+        float v[CH], r[CH];
+        ld_chunk(x + e * CH, v);
+        if (res) ld_chunk(res + e * CH, r);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = c0 + j;
+            const int g = c / Cg;
+            const float mean = stats[(size_t)b * 2 * G + 2 * g] * inv_n;
+            const float var = fmaxf(stats[(size_t)b * 2 * G + 2 * g + 1] * inv_n - mean * mean, 0.f);
+            float o = (v[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+            if (res) o += r[j];
+            if (relu) o = fmaxf(o, 0.f);
+            v[j] = o;
+        }
+        st_chunk(x + e * CH, v);
+    }
+}
+
+hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats, int dt, int B,
+                            int HW, int C, int G, float eps, int relu, hipStream_t s) {
+    const int CH = dt == DT_BF16 ? 8 : 4;
+    if (C % CH || C % G || G > 64) return hipErrorInvalidValue;
+    const int cv = C / CH;
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)B * 2 * G * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    // block size: multiple of cv (cv is a power of two <= 256 for every layer of the trunk; else fall back to cv-multiple)
+    int block = 256;
+    if (256 % cv) block = ((256 + cv - 1) / cv) * cv;
+    if (block > 1024) return hipErrorInvalidValue;
+    size_t n = (size_t)HW * cv;
+    int gx = (int)((n + block - 1) / block);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    if (dt == DT_BF16) {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(gx, B), dim3(block), 0, s, (const bf16*)x, stats, HW, C, G);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(grid_for((size_t)B * n)), dim3(256), 0, s, (bf16*)x, (const bf16*)res, gamma, beta, stats, B, HW, C, G, eps, relu);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(gx, B), dim3(block), 0, s, (const float*)x, stats, HW, C, G);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for((size_t)B * n)), dim3(256), 0, s, (float*)x, (const float*)res, gamma, beta, stats, B, HW, C, G, eps, relu);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+// nn.LayerNorm / BertLayerNorm: biased variance, eps inside the sqrt; two-pass in registers.
+template <typename T, int D>
+__global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ post, int post_rows,
+                                 T* __restrict__ y, int rows, float eps) {
+    constexpr int PER = D / 64;              // elements per lane, strided by 64 lanes in groups of VEC
+    constexpr int VEC = (PER % 4 == 0) ? 4 : 1;
+    constexpr int NV = PER / VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * D;
+    const T* rr = res ? res + (size_t)row * D : nullptr;
+    float v[PER];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = (i * 64 + lane) * VEC + j;
+            float a = Tr<T>::ld(xr + c);
+            if (rr) a += Tr<T>::ld(rr + c);
+            v[i * VEC + j] = a;
+            sum += a;
+        }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + eps);
+    const float* pp = post ? post + (size_t)(row % post_rows) * D : nullptr;
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = (i * 64 + lane) * VEC + j;
+            float o = (v[i * VEC + j] - mean) * rstd * gamma[c] + beta[c];
+            if (pp) o += pp[c];
+            Tr<T>::st(yr + c, o);
+        }
+}
+
+hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, const float* beta, const float* post,
+                            int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s) {
+    const int wpb = 4;
+    const dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
+#define L(T, DD) hipLaunchKernelGGL((layernorm_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, post_rows > 0 ? post_rows : 1, (T*)y, rows, eps)
+    if (dt == DT_BF16) {
+        if (D == 768) L(bf16, 768); else if (D == 256) L(bf16, 256); else if (D == 512) L(bf16, 512); else if (D == 128) L(bf16, 128); else return hipErrorInvalidValue;
+    } else {
+        if (D == 768) L(float, 768); else if (D == 256) L(float, 256); else if (D == 512) L(float, 512); else if (D == 128) L(float, 128); else return hipErrorInvalidValue;
+    }
+#undef L
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ BERT embeddings + LN
+// BertEmbeddings.forward: word[id] + position[l] + token_type[0] -> LayerNorm(eps 1e-12)  (call site seq2seq_highlevel_cma.py:192-195)
+template <typename T, typename I>
+__global__ void bert_embed_kernel(const I* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                  const float* __restrict__ type0, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  T* __restrict__ y, int rows, int L, int D, int vocab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    long id = (long)ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const int l = row % L;
+    const float* wr = word + (size_t)id * D;
+    const float* pr = pos + (size_t)l * D;
+    float v[16];                              // D <= 1024
+    const int per = D / 64;
+    float sum = 0.f;
+    for (int i = 0; i < per; ++i) {
+        const int c = i * 64 + lane;
+        const float a = wr[c] + pr[c] + type0[c];
+        v[i] = a;
+        sum += a;
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+    for (int i = 0; i < per; ++i) { const float d = v[i] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    for (int i = 0; i < per; ++i) {
+        const int c = i * 64 + lane;
+        Tr<T>::st(y + (size_t)row * D + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, const float* pos, const float* type0,
+                             const float* gamma, const float* beta, void* y, int dt, int B, int L, int D, int vocab,
+                             float eps, hipStream_t s) {
+    const int rows = B * L;
+    if (D % 64 || D > 1024) return hipErrorInvalidValue;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define L_(T, I) hipLaunchKernelGGL((bert_embed_kernel<T, I>), grid, block, 0, s, (const I*)ids, word, pos, type0, gamma, beta, (T*)y, rows, L, D, vocab, eps)
+    if (dt == DT_BF16) {
+        if (ids_dt == DT_I64) L_(bf16, int64_t); else if (ids_dt == DT_I32) L_(bf16, int32_t); else if (ids_dt == DT_F32) L_(bf16, float); else return hipErrorInvalidValue;
+    } else {
+        if (ids_dt == DT_I64) L_(float, int64_t); else if (ids_dt == DT_I32) L_(float, int32_t); else if (ids_dt == DT_F32) L_(float, float); else return hipErrorInvalidValue;
+    }
+#undef L_
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ recurrent cell + heads
+// RNNStateEncoder.single_forward (models/decoder/state_encoder.py:72-81): hidden * mask, one step, repack.
+__global__ void rnn_prep_kernel(const float* __restrict__ h_in, const float* __restrict__ mask, float* __restrict__ xh,
+                                int B, int Hd, int ld, int col0) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) xh[(size_t)b * ld + col0 + j] = h_in[(size_t)b * Hd + j] * mask[b];
+}
+hipError_t launch_rnn_prep(const float* h_in, const float* mask, float* xh, int B, int Hd, int ld, int col0, hipStream_t s) {
+    hipLaunchKernelGGL(rnn_prep_kernel, dim3(B), dim3(256), 0, s, h_in, mask, xh, B, Hd, ld, col0);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ void heads_eval(const float* hs, int Hd, const Heads& hd, int b) {
+    // hs: new hidden state of sample b in LDS; one wave per output row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < hd.r0 + hd.r1; r += nw) {
+        const bool first = r < hd.r0;
+        const int rr = first ? r : r - hd.r0;
+        const float* w = (first ? hd.w0 : hd.w1) + (size_t)rr * Hd;
+        float acc = 0.f;
+        for (int j = lane; j < Hd; j += 64) acc += w[j] * hs[j];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (first) hd.out0[(size_t)b * hd.ld0 + rr] = acc + hd.b0[rr];
+            else hd.out1[(size_t)b * hd.ld1 + rr] = acc + hd.b1[rr];
+        }
+    }
+}
+
+__global__ void lstm_cell_kernel(const float* __restrict__ gates, const float* __restrict__ h_in, const float* __restrict__ mask,
+                                 float* __restrict__ h_out, int B, int Hd, Heads hd) {
+    extern __shared__ float hs[];
+    const int b = blockIdx.x;
+    const float mk = mask[b];
+    const float* g = gates + (size_t)b * 4 * Hd;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        const float c = h_in[(size_t)(B + b) * Hd + j] * mk;          // hidden[1] = c
+        const float gi = sigmoidf_(g[j]), gf = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), go = sigmoidf_(g[3 * Hd + j]);
+        const float c2 = gf * c + gi * gg;
+        const float h2 = go * tanhf(c2);
+        hs[j] = h2;
+        h_out[(size_t)b * Hd + j] = h2;
+        h_out[(size_t)(B + b) * Hd + j] = c2;
+    }
+    __syncthreads();
+    heads_eval(hs, Hd, hd, b);
+}
+hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* mask, float* h_out, int B, int Hd,
+                            const Heads& heads, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(B), dim3(256), Hd * sizeof(float), s, gates, h_in, mask, h_out, B, Hd, heads);
+    return hipGetLastError();
+}
+
+__global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h_in,
+                                const float* __restrict__ mask, float* __restrict__ h_out, int B, int Hd, Heads hd) {
+    extern __shared__ float hs[];
+    const int b = blockIdx.x;
+    const float mk = mask[b];
+    const float* a = gi + (size_t)b * 3 * Hd;
+    const float* c = gh + (size_t)b * 3 * Hd;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        const float h = h_in[(size_t)b * Hd + j] * mk;
+        const float r = sigmoidf_(a[j] + c[j]);
+        const float z = sigmoidf_(a[Hd + j] + c[Hd + j]);
+        const float n = tanhf(a[2 * Hd + j] + r * c[2 * Hd + j]);
+        const float h2 = (1.f - z) * n + z * h;
+        hs[j] = h2;
+        h_out[(size_t)b * Hd + j] = h2;
+    }
+    __syncthreads();
+    heads_eval(hs, Hd, hd, b);
+}
+hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, const float* mask, float* h_out, int B,
+                           int Hd, const Heads& heads, hipStream_t s) {
+    hipLaunchKernelGGL(gru_cell_kernel, dim3(B), dim3(256), Hd * sizeof(float), s, gi, gh, h_in, mask, h_out, B, Hd, heads);
+    return hipGetLastError();
+}
+
+// torch.argmax(output, dim=1) (hierarchical_trainer.py:1098): first maximal index
+__global__ void argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ pred, int B, int n, int ld) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = logits + (size_t)b * ld;
+    int best = 0;
+    float bv = p[0];
+    for (int j = 1; j < n; ++j)
+        if (p[j] > bv) { bv = p[j]; best = j; }
+    pred[b] = best;
+}
+hipError_t launch_argmax(const float* logits, int64_t* pred, int B, int n, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_kernel, dim3((B + 63) / 64), dim3(64), 0, s, logits, pred, B, n, ld);
+    return hipGetLastError();
+}
+
+// sub_task_embedding lookup (seq2seq_lowlevel.py:141)
+__global__ void embed_rows_kernel(const float* __restrict__ emb, const int64_t* __restrict__ idx, float* __restrict__ y,
+                                  int B, int D, int ld, int col0, int nrows) {
+    const int b = blockIdx.x;
+    long i = idx[b];
+    if (i < 0) i = 0;
+    if (i >= nrows) i = nrows - 1;
+    for (int j = threadIdx.x; j < D; j += blockDim.x) y[(size_t)b * ld + col0 + j] = emb[(size_t)i * D + j];
+}
+hipError_t launch_embed_rows(const float* emb, const int64_t* idx, float* y, int B, int D, int ld, int col0, int nrows, hipStream_t s) {
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(64), 0, s, emb, idx, y, B, D, ld, col0, nrows);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) y[e] = Tr<T>::ld(x + e);
+}
+template <typename T>
+__global__ void from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) Tr<T>::st(y + e, x[e]);
+}
+hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL(to_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)x, y, n);
+    else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL(from_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, x, (bf16*)y, n);
+    else hipLaunchKernelGGL(from_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, x, (float*)y, n);
+    return hipGetLastError();
+}
+
+}  // namespace hcm

@@ -1,0 +1,372 @@
+// Forward orchestration of the two HCM models: enqueues the HIP kernels on the caller's stream.
+// No allocation and no host synchronisation inside a step: every intermediate lives in the per-handle
+// workspace arena, whose size is found by running this same code once in "dry" mode at hcm_finalize().
+#include <cstdio>
+#include <stdexcept>
+
+#include "model.h"
+
+namespace hcm {
+
+int depth_final_spatial(const hcm_config& c);
+int depth_compress_channels(const hcm_config& c);
+
+struct Act { void* p = nullptr; int B = 0, H = 0, W = 0, C = 0; };
+
+struct Fwd {
+    hcm_ctx* ctx;
+    Arena& ar;
+    hipStream_t s;
+    int dt;
+    size_t esz;
+    bool dry;
+
+    explicit Fwd(hcm_ctx* c) : ctx(c), ar(c->arena), s(c->stream), dt(c->dt), esz(c->esz), dry(c->arena.dry) {}
+
+    void ck(hipError_t e, const char* what) {
+        if (e != hipSuccess) {
+            ctx->failed = true;
+            throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+        }
+    }
+    void* alloc_t(size_t elems) { return ar.alloc(elems * esz); }
+    float* alloc_f(size_t elems) { return (float*)ar.alloc(elems * 4); }
+
+    void tap(const std::string& name, const void* p, bool is_t, Shape shape) {
+        if (dry || !ctx->taps_on) return;
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        Tap& t = ctx->taps[name];
+        if (t.cap < n) {
+            if (t.dev) (void)hipFree(t.dev);
+            ck(hipMalloc((void**)&t.dev, n * 4), "tap hipMalloc");
+            t.cap = n;
+        }
+        t.n = n;
+        t.shape = shape;
+        if (is_t) ck(launch_convert_to_f32(p, dt, t.dev, n, s), "tap convert");
+        else ck(hipMemcpyAsync(t.dev, p, n * 4, hipMemcpyDeviceToDevice, s), "tap copy");
+    }
+
+    // ---------------------------------------------------------------- primitive wrappers
+    void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo) {
+        if (dry) return;
+        IGemm g;
+        g.x = in.p; g.w = w.w; g.bias = w.bias; g.res = res; g.y = out;
+        g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
+        g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
+        g.M = in.B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
+        ck(launch_igemm(g, dt, s), "conv igemm");
+    }
+    // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
+    void linear(const LinW& w, const void* a, int M, int lda, void* y, int ldy, int act, bool out_f32,
+                const void* res = nullptr, int ldr = 0, int wdt = -1) {
+        if (dry) return;
+        IGemm g;
+        g.x = a; g.w = w.w; g.bias = w.bias; g.res = res; g.y = y;
+        g.B = M; g.Cin = w.K; g.xC = lda; g.M = M; g.N = w.N; g.K = w.K; g.Kp = w.Kp;
+        g.ldy = ldy; g.ldr = ldr ? ldr : w.N; g.act = act; g.out_f32 = out_f32 ? 1 : 0;
+        ck(launch_igemm(g, wdt < 0 ? w.dt : wdt, s), "linear igemm");
+    }
+    void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu) {
+        float* stats = alloc_f((size_t)B * 2 * G);
+        if (dry) return;
+        ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, 1e-5f, relu ? 1 : 0, s), "groupnorm");
+    }
+    void ln(const void* x, const void* res, const NormW& n, const float* post, int post_rows, void* y, int rows, int D, float eps) {
+        if (dry) return;
+        ck(launch_layernorm(x, res, n.gamma, n.beta, post, post_rows, y, dt, rows, D, eps, s), "layernorm");
+    }
+
+    // ---------------------------------------------------------------- ResNet-50 trunks
+    // torchvision resnet50 conv1..layer4 with BN folded (RGB), or habitat GN-ResNet50 (+compression) (depth).
+    // `first` is the im2col'ed input [B*Ho*Wo][Kp]; returns the trunk output living in arena memory.
+    Act trunk(const TrunkW& t, const void* first, int B, int Ho, int Wo, const std::string& tapname) {
+        const int c1 = t.conv1.Cout;
+        const size_t max_elems = (size_t)B * Ho * Wo * c1;      // conv1 output == layer1 output == largest activation
+        void* slot[4];
+        for (auto& p : slot) p = alloc_t(max_elems);
+        // conv1 as a plain GEMM over the im2col matrix
+        {
+            LinW l; l.w = t.conv1.w; l.bias = t.conv1.bias; l.N = c1; l.K = t.conv1.Kp; l.Kp = t.conv1.Kp; l.dt = dt;
+            linear(l, first, B * Ho * Wo, t.conv1.Kp, slot[0], c1, t.gn ? ACT_NONE : ACT_RELU, false);
+            if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, t.groups, true);
+        }
+        tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
+        const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+        if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
+        Act x{slot[1], B, Hp, Wp, c1};
+        int xi = 1;
+        int bidx = 0;
+        for (const BottleneckW& b : t.blocks) {
+            int fr[3], nf = 0;
+            for (int i = 0; i < 4; ++i) if (i != xi) fr[nf++] = i;
+            void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
+            const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
+            Act o1{sa, B, x.H, x.W, b.c1.Cout};
+            conv(b.c1, x, sa, 1, 0, nullptr, t.gn ? ACT_NONE : ACT_RELU, x.H, x.W);
+            if (t.gn) gn(sa, nullptr, b.n1, B, x.H * x.W, b.c1.Cout, t.groups, true);
+            Act o2{sb, B, Ho2, Wo2, b.c2.Cout};
+            conv(b.c2, o1, sb, b.stride, 1, nullptr, t.gn ? ACT_NONE : ACT_RELU, Ho2, Wo2);
+            if (t.gn) gn(sb, nullptr, b.n2, B, Ho2 * Wo2, b.c2.Cout, t.groups, true);
+            const void* idt = x.p;
+            if (b.has_ds) {
+                conv(b.ds, x, sa, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);       // o1 is dead: reuse its slot
+                if (t.gn) gn(sa, nullptr, b.nds, B, Ho2 * Wo2, b.ds.Cout, t.groups, false);
+                idt = sa;
+            }
+            if (t.gn) {
+                conv(b.c3, o2, sc, 1, 0, nullptr, ACT_NONE, Ho2, Wo2);
+                gn(sc, idt, b.n3, B, Ho2 * Wo2, b.c3.Cout, t.groups, true);        // relu(GN(conv) + identity)
+            } else {
+                conv(b.c3, o2, sc, 1, 0, idt, ACT_RELU, Ho2, Wo2);                  // relu(bn(conv) + identity), fused
+            }
+            x = Act{sc, B, Ho2, Wo2, b.c3.Cout};
+            xi = fr[2];
+            ++bidx;
+            if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16)
+                tap(tapname + "_layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4), x.p, true, {B, x.H, x.W, x.C});
+        }
+        if (t.gn) {
+            int fr = (xi + 1) & 3;
+            conv(t.compress, x, slot[fr], 1, 1, nullptr, ACT_NONE, x.H, x.W);
+            gn(slot[fr], nullptr, t.n_compress, B, x.H * x.W, t.compress.Cout, 1, true);
+            x = Act{slot[fr], B, x.H, x.W, t.compress.Cout};
+        }
+        return x;
+    }
+
+    Act rgb_trunk(const TrunkW& t, const void* rgb, int rgb_dt, int B, const std::string& tapname) {
+        const int H = ctx->cfg.rgb_h, W = ctx->cfg.rgb_w;
+        const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+        void* a = alloc_t((size_t)B * Ho * Wo * t.conv1.Kp);
+        // permute(0,3,1,2) + `/ 255.0` (resnet_encoders.py:211-213) folded into the im2col gather
+        if (!dry) ck(launch_im2col(rgb, rgb_dt, a, dt, B, H, W, 3, 7, 7, 2, 3, Ho, Wo, t.conv1.Kp, 1.0f / 255.0f, s), "im2col rgb");
+        return trunk(t, a, B, Ho, Wo, tapname);
+    }
+    Act depth_trunk(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
+        const int H = ctx->cfg.depth_h / 2, W = ctx->cfg.depth_w / 2;
+        void* pooled = alloc_t((size_t)B * H * W);
+        if (!dry) ck(launch_avgpool2_f32(depth, pooled, dt, B, ctx->cfg.depth_h, ctx->cfg.depth_w, s), "avgpool2");
+        const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+        void* a = alloc_t((size_t)B * Ho * Wo * t.conv1.Kp);
+        if (!dry) ck(launch_im2col(pooled, dt, a, dt, B, H, W, 1, 7, 7, 2, 3, Ho, Wo, t.conv1.Kp, 1.0f, s), "im2col depth");
+        return trunk(t, a, B, Ho, Wo, tapname);
+    }
+
+    // SimpleAllCNN.cnn (simple_cnns.py:76-100) -> f32 features into out[b*ld + col0 ..]
+    void simple_cnn(const SimpleCnnW& w, const void* x, int x_dt, float scale, int B, float* out, int ld) {
+        const int H = w.hw;
+        const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
+        void* a = alloc_t((size_t)B * h1 * h1 * w.c0.Kp);
+        if (!dry) ck(launch_im2col(x, x_dt, a, dt, B, H, H, w.cin, 8, 8, 4, 0, h1, h1, w.c0.Kp, scale, s), "im2col simple");
+        void* y0 = alloc_t((size_t)B * h1 * h1 * 32);
+        LinW l; l.w = w.c0.w; l.bias = w.c0.bias; l.N = 32; l.K = w.c0.Kp; l.Kp = w.c0.Kp; l.dt = dt;
+        linear(l, a, B * h1 * h1, w.c0.Kp, y0, 32, ACT_RELU, false);
+        void* y1 = alloc_t((size_t)B * h2 * h2 * 64);
+        conv(w.c1, Act{y0, B, h1, h1, 32}, y1, 2, 0, nullptr, ACT_RELU, h2, h2);
+        void* y2 = alloc_t((size_t)B * h3 * h3 * 32);
+        conv(w.c2, Act{y1, B, h2, h2, 64}, y2, 1, 0, nullptr, ACT_NONE, h3, h3);
+        linear(w.fc, y2, B, h3 * h3 * 32, out, ld, ACT_RELU, true);
+    }
+
+    // ---------------------------------------------------------------- BERT encoder
+    void* bert(const BertW& w, const void* ids, int ids_dt, int B) {
+        const hcm_config& c = ctx->cfg;
+        const int L = c.instr_len, D = c.bert_hidden, rows = B * L;
+        void* x = alloc_t((size_t)rows * D);
+        void* qkv = alloc_t((size_t)rows * 3 * D);
+        void* ctxb = alloc_t((size_t)rows * D);
+        void* tmp = alloc_t((size_t)rows * D);
+        void* hbuf = alloc_t((size_t)rows * c.bert_inter);
+        if (!dry) ck(launch_bert_embed(ids, ids_dt, w.word, w.pos, w.type0, w.ln.gamma, w.ln.beta, x, dt, B, L, D, c.bert_vocab, 1e-12f, s), "bert_embed");
+        tap("hi.bert_emb", x, true, {B, L, D});
+        int li = 0;
+        for (const BertLayerW& l : w.layers) {
+            linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
+            if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
+                                          L, L, 3 * D, 3 * D, 3 * D, D, B, s), "bert attention");
+            linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
+            ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
+            linear(l.ff1, x, rows, D, hbuf, c.bert_inter, ACT_GELU, false);
+            linear(l.ff2, hbuf, rows, c.bert_inter, tmp, D, ACT_NONE, false, x, D);
+            ln(tmp, nullptr, l.ln2, nullptr, 0, x, rows, D, 1e-12f);
+            if (li == 0) tap("hi.bert_l0", x, true, {B, L, D});
+            ++li;
+        }
+        return x;
+    }
+
+    // ---------------------------------------------------------------- recurrent step + heads
+    void rnn_step(const RnnW& w, float* xh, int ld, int B, const float* h_in, const float* mask, float* h_out, const Heads& heads) {
+        const int H = ctx->cfg.hidden;
+        if (!dry) ck(launch_rnn_prep(h_in, mask, xh, B, H, ld, w.in, s), "rnn_prep");
+        if (ctx->cfg.rnn_type == HCM_LSTM) {
+            float* gates = alloc_f((size_t)B * 4 * H);
+            linear(w.cat, xh, B, ld, gates, 4 * H, ACT_NONE, true);
+            if (!dry) ck(launch_lstm_cell(gates, h_in, mask, h_out, B, H, heads, s), "lstm_cell");
+        } else {
+            float* gi = alloc_f((size_t)B * 3 * H);
+            float* gh = alloc_f((size_t)B * 3 * H);
+            linear(w.ih, xh, B, ld, gi, 3 * H, ACT_NONE, true);
+            linear(w.hh, xh + w.in, B, ld, gh, 3 * H, ACT_NONE, true);
+            if (!dry) ck(launch_gru_cell(gi, gh, h_in, mask, h_out, B, H, heads, s), "gru_cell");
+        }
+    }
+
+    // ---------------------------------------------------------------- Seq2Seq_HighLevel_CMA.forward
+    void high(const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
+              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
+        const hcm_config& c = ctx->cfg;
+        const HighW& w = ctx->hi;
+        const int L = c.instr_len, d = c.d_model, H = c.hidden;
+        const int rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
+        const int in = w.rnn.in, ldx = in + H;
+        ar.reset();
+        // persistent (whole-forward) buffers first
+        void* rgb_tok = alloc_t((size_t)B * 16 * rC);            // (B,2112,16) of the reference, token-major
+        void* dep_tok = alloc_t((size_t)B * dS * dC);
+        float* xh = alloc_f((size_t)B * ldx);                    // [rgb_in | depth_in | ins_rgb | ins_depth | h*mask]
+
+        {   // depth_encoder (seq2seq_highlevel_cma.py:178-179): GN-ResNet50 + pos-emb channels
+            const size_t m = ar.mark();
+            Act o = depth_trunk(w.depth, depth, B, "hi.depth");
+            if (!dry) {
+                ck(launch_adaptive_avgpool(o.p, dep_tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
+                ck(launch_fill_cols(w.depth_pe, (char*)dep_tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+            }
+            ar.release(m);
+        }
+        tap("hi.depth_spatial", dep_tok, true, {B, dS, dC});
+        {   // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels
+            const size_t m = ar.mark();
+            Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "hi.rgb");
+            if (!dry) {
+                ck(launch_adaptive_avgpool(o.p, rgb_tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
+                ck(launch_fill_cols(w.rgb_pe, (char*)rgb_tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+            }
+            ar.release(m);
+        }
+        tap("hi.rgb_spatial", rgb_tok, true, {B, 16, rC});
+
+        // BERT (:189-195)
+        void* emb = bert(w.bert, ids, ids_dt, B);
+        tap("hi.bert", emb, true, {B, L, c.bert_hidden});
+
+        // Visual_Ling_Attn x2 (:198-201; models/transformer/transformer.py:251-281)
+        const VlaW& v = w.vla;
+        const int rows = B * L;
+        void* I = alloc_t((size_t)rows * d);
+        void* tmp = alloc_t((size_t)rows * d);
+        linear(v.ins_fc, emb, rows, c.bert_hidden, tmp, d, ACT_RELU, false);
+        ln(tmp, nullptr, v.ln, v.pe, L, I, rows, d, 1e-5f);     // LN then + PE; identical for both calls -> computed once
+        std::vector<void*> Q(v.layers.size());
+        for (size_t l = 0; l < v.layers.size(); ++l) {
+            Q[l] = alloc_t((size_t)rows * d);
+            linear(v.layers[l].q, I, rows, d, Q[l], d, ACT_NONE, false);
+        }
+        for (int stream = 0; stream < 2; ++stream) {
+            const size_t m = ar.mark();
+            const int S = stream == 0 ? 16 : dS;
+            const void* tok = stream == 0 ? rgb_tok : dep_tok;
+            const int tokC = stream == 0 ? rC : dC;
+            const LinW& kvproj = stream == 0 ? w.rgb_kv : w.depth_kv;
+            void* vis = alloc_t((size_t)B * S * c.vis_in);
+            linear(kvproj, tok, B * S, tokC, vis, c.vis_in, ACT_NONE, false);              // rgb_kv / depth_kv Conv1d(k=1)
+            tap(stream == 0 ? "hi.rgb_kv" : "hi.depth_kv", vis, true, {B, S, c.vis_in});
+            void* vtmp = alloc_t((size_t)B * S * d);
+            void* kvin = alloc_t((size_t)B * (S > L ? S : L) * d);
+            linear(v.vis_fc, vis, B * S, c.vis_in, vtmp, d, ACT_RELU, false);
+            ln(vtmp, nullptr, v.ln, nullptr, 0, kvin, B * S, d, 1e-5f);
+            int Lk = S;
+            void* kv = alloc_t((size_t)B * (S > L ? S : L) * 2 * d);
+            void* att = alloc_t((size_t)rows * d);
+            void* t2 = alloc_t((size_t)rows * d);
+            void* ffh = alloc_t((size_t)rows * c.d_ff);
+            void* out = alloc_t((size_t)rows * d);
+            const void* cur_kv = kvin;
+            for (size_t l = 0; l < v.layers.size(); ++l) {
+                const VlaLayerW& ly = v.layers[l];
+                linear(ly.kv, cur_kv, B * Lk, d, kv, 2 * d, ACT_NONE, false);
+                if (!dry) ck(launch_attention(Q[l], kv, (char*)kv + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s), "vla attention");
+                linear(ly.o, att, rows, d, t2, d, ACT_NONE, false, I, d);                 // queries + att
+                ln(t2, nullptr, ly.ln_att, nullptr, 0, att, rows, d, 1e-5f);             // MultiHeadAttention.layer_norm
+                linear(ly.ff1, att, rows, d, ffh, c.d_ff, ACT_RELU, false);
+                linear(ly.ff2, ffh, rows, c.d_ff, t2, d, ACT_NONE, false, att, d);
+                ln(t2, nullptr, ly.ln_ff, nullptr, 0, out, rows, d, 1e-5f);
+                if (l + 1 < v.layers.size()) {
+                    // next layer attends over this layer's output (B,L,d)
+                    if (!dry) ck(hipMemcpyAsync(kvin, out, (size_t)rows * d * esz, hipMemcpyDeviceToDevice, s), "vla copy");
+                    cur_kv = kvin;
+                    Lk = L;
+                }
+            }
+            tap(stream == 0 ? "hi.vla_rgb" : "hi.vla_depth", out, true, {B, L, d});
+            // cross_pooler: mean over all L tokens (:209-210) -> xh columns
+            if (!dry) ck(launch_mean_rows(out, xh + c.rgb_out + c.depth_out + stream * d, dt, B, L, d, d, ldx, 1, s), "cross_pooler");
+            ar.release(m);
+        }
+        // rgb_linear (:213): mean over 16 tokens -> Linear -> ReLU ; depth_linear (:214): Flatten -> Linear -> ReLU
+        void* rmean = alloc_t((size_t)B * rC);
+        if (!dry) ck(launch_mean_rows(rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
+        linear(w.rgb_linear, rmean, B, rC, xh, ldx, ACT_RELU, true);
+        linear(w.depth_linear, dep_tok, B, dS * dC, xh + c.rgb_out, ldx, ACT_RELU, true);
+        // state_encoder (:219) + linear head (:232)
+        Heads hd;
+        hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
+        rnn_step(w.rnn, xh, ldx, B, h_in, mask, h_out, hd);
+        tap("hi.rnn_in", xh, false, {B, ldx});
+    }
+
+    // ---------------------------------------------------------------- Seq2Seq_LowLevel.forward
+    void low(const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
+             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out) {
+        const hcm_config& c = ctx->cfg;
+        const LowW& w = ctx->lo;
+        const int H = c.hidden, in = w.rnn.in, ldx = in + H;
+        ar.reset();
+        float* xh = alloc_f((size_t)B * ldx);                    // [depth | rgb | subtask | h*mask]  (seq2seq_lowlevel.py:143)
+        {
+            const size_t m = ar.mark();
+            if (w.depth_simple) {
+                simple_cnn(w.depth_s, depth, DT_F32, 1.0f, B, xh, ldx);
+            } else {
+                Act o = depth_trunk(w.depth, depth, B, "lo.depth");
+                linear(w.depth_fc, o.p, B, o.H * o.W * o.C, xh, ldx, ACT_RELU, true);     // visual_fc
+            }
+            ar.release(m);
+        }
+        {
+            const size_t m = ar.mark();
+            if (w.rgb_simple) {
+                simple_cnn(w.rgb_s, rgb, rgb_dt, 1.0f / 255.0f, B, xh + c.depth_out, ldx);
+            } else {
+                Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "lo.rgb");
+                void* pooled = alloc_t((size_t)B * o.C);
+                if (!dry) ck(launch_adaptive_avgpool(o.p, pooled, dt, B, o.H, o.W, o.C, 1, 1, o.C, s), "global avgpool");
+                linear(w.rgb_fc, pooled, B, o.C, xh + c.depth_out, ldx, ACT_RELU, true);
+            }
+            ar.release(m);
+        }
+        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, xh, B, 32, ldx, c.depth_out + c.rgb_out, c.num_sub_tasks + 1, s), "subtask emb");
+        Heads hd;
+        hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;
+        hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = ld_stop;
+        rnn_step(w.rnn, xh, ldx, B, h_in, mask, h_out, hd);
+        tap("lo.rnn_in", xh, false, {B, ldx});
+    }
+};
+
+// entry points used by api.cpp
+void run_high(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
+              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
+    Fwd f(ctx);
+    f.high(rgb, rgb_dt, depth, ids, ids_dt, B, h_in, mask, logits, ld_logits, h_out);
+}
+void run_low(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
+             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out) {
+    Fwd f(ctx);
+    f.low(rgb, rgb_dt, depth, B, h_in, mask, subtask, vel, ld_vel, stop, ld_stop, h_out);
+}
+
+}  // namespace hcm

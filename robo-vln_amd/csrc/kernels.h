@@ -1,0 +1,80 @@
+// Launch-level interface between the model code (model.cpp / api.cpp) and the HIP kernels.
+// All pointers are device pointers.  `dt` is HCM_F32 (T=float) or HCM_BF16 (T=bf16 storage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace hcm {
+
+enum { DT_F32 = 0, DT_BF16 = 1, DT_I32 = 2, DT_I64 = 3, DT_U8 = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+inline size_t dt_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+// Implicit-GEMM convolution / linear layer:  y[m][n] = act( sum_k A[m][k] * w[n][k] + bias[n] + res[m][n] )
+//   A[m][k] is gathered on the fly from the NHWC activation x: m=(b,oy,ox), k=(kh,kw,ci).
+//   A plain row-major GEMM is the degenerate case H=W=KH=KW=1, B=M, Cin=K.
+struct IGemm {
+    const void* x = nullptr;     // [B,H,W,*] channels at pixel stride xC (elements of T)
+    const void* w = nullptr;     // [N][Kp] (T), k = (kh*KW+kw)*Cin + ci, rows zero-padded from K to Kp
+    const float* bias = nullptr; // [N] f32 or null
+    const void* res = nullptr;   // [M][ldr] (T) or null
+    void* y = nullptr;           // [M][ldy] T, or f32 when out_f32
+    int B = 1, H = 1, W = 1, Cin = 0, xC = 0;
+    int Ho = 1, Wo = 1, KH = 1, KW = 1, stride = 1, pad = 0;
+    int M = 0, N = 0, K = 0, Kp = 0;
+    int ldy = 0, ldr = 0;
+    int act = ACT_NONE;
+    int out_f32 = 0;
+};
+hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
+
+// First-layer im2col (Cin = 1 or 3): x [B,H,W,C] (src_dt: f32 / u8 / T) * scale -> A [B*Ho*Wo][Kp] (T), zero-padded K..Kp
+hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C,
+                         int KH, int KW, int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s);
+// depth pre-pool: f32 [B,H,W,1] -> avg_pool2d(2) -> T [B,H/2,W/2,1]
+hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
+hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel
+hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s);
+// mean over S rows: x [B,S,ldx(>=C)] (T) -> y [B, ldy] (T or f32 when out_f32) columns [0,C)
+hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s);
+// write a constant f32 table tab[S][C] into columns of y [B,S,ldy] (T)
+hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int C, int ldy, hipStream_t s);
+
+// GroupNorm over NHWC x [B,HW,C] in place: x = relu?( (x-mean)*rstd*gamma+beta (+res) ); stats scratch [B*G*2] f32
+hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats,
+                            int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s);
+// LayerNorm rows: y = LN(x (+res)) * gamma + beta (+ post[row % post_rows][:])
+hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, const float* beta,
+                            const float* post, int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s);
+// BERT embeddings: y[b,l,:] = LN(word[id] + pos[l] + type0) ; tables f32
+hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, const float* pos, const float* type0,
+                             const float* gamma, const float* beta, void* y, int dt, int B, int L, int D, int vocab,
+                             float eps, hipStream_t s);
+// softmax(Q K^T / sqrt(64)) V, head dim 64.  q batch index = b % q_batch_mod (shared queries)
+hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads,
+                            int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s);
+
+// RNN input assembly: xh[b][x_cols + j] = h_in[0][b][j] * mask[b]   (f32)
+hipError_t launch_rnn_prep(const float* h_in, const float* mask, float* xh, int B, int Hd, int ld, int col0, hipStream_t s);
+struct Heads {            // up to two small linear heads on the new hidden state
+    const float* w0 = nullptr; const float* b0 = nullptr; float* out0 = nullptr; int r0 = 0; int ld0 = 0;
+    const float* w1 = nullptr; const float* b1 = nullptr; float* out1 = nullptr; int r1 = 0; int ld1 = 0;
+};
+// LSTM cell from pre-activations gates [B][4H] (i,f,g,o), c_in = h_in[1]*mask; writes h_out (2,B,H)
+hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* mask, float* h_out, int B, int Hd,
+                            const Heads& heads, hipStream_t s);
+// GRU cell from gi, gh [B][3H] (r,z,n); h = h_in[0]*mask; writes h_out (1,B,H)
+hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, const float* mask, float* h_out,
+                           int B, int Hd, const Heads& heads, hipStream_t s);
+// pred[b] = argmax_j logits[b*ld + j] (first max), int64
+hipError_t launch_argmax(const float* logits, int64_t* pred, int B, int n, int ld, hipStream_t s);
+// xh[b][col0 + j] = emb[subtask[b]][j]
+hipError_t launch_embed_rows(const float* emb, const int64_t* idx, float* y, int B, int D, int ld, int col0, int nrows, hipStream_t s);
+// generic converts
+hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s);
+hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s);
+
+}  // namespace hcm

@@ -1,0 +1,135 @@
+// Host-side model state for libhcm: strict state_dict loader, device weights, workspace arena.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdint.h>
+
+#include "../../include/hcm.h"
+#include "kernels.h"
+
+namespace hcm {
+
+using Shape = std::vector<int64_t>;
+
+struct HostTensor {
+    std::vector<float> f;
+    Shape shape;
+    bool loaded = false;
+};
+
+struct ConvW {                 // [Cout][Kp] in compute dtype, k = (kh*KW+kw)*Cin + ci
+    void* w = nullptr;
+    float* bias = nullptr;     // f32 [Cout] or null
+    int Cout = 0, Cin = 0, KH = 1, KW = 1, K = 0, Kp = 0;
+};
+struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+struct LinW {                  // [N][Kp]; dt = compute dtype or f32 (recurrent weights)
+    void* w = nullptr;
+    float* bias = nullptr;
+    int N = 0, K = 0, Kp = 0, dt = 0;
+};
+
+struct BottleneckW {
+    ConvW c1, c2, c3, ds;
+    NormW n1, n2, n3, nds;     // GroupNorm variant only
+    bool has_ds = false;
+    int stride = 1;
+};
+struct TrunkW {
+    bool gn = false;           // false: BN folded into conv (torchvision); true: GroupNorm (habitat)
+    int groups = 0;
+    ConvW conv1;               // first conv, applied to the im2col matrix (KH=KW=1 from the kernel's view)
+    int k1 = 7, s1 = 2, p1 = 3, cin1 = 3;
+    NormW n_conv1;
+    std::vector<BottleneckW> blocks;
+    ConvW compress;            // habitat: 3x3 compression conv
+    NormW n_compress;
+    int out_c = 0;
+};
+struct SimpleCnnW {
+    ConvW c0, c1, c2;          // 8x8/4 (im2col), 4x4/2, 3x3/1
+    LinW fc;
+    int cin = 1, hw = 0, h3 = 0;
+};
+struct BertLayerW {
+    LinW qkv, o, ff1, ff2;
+    NormW ln1, ln2;
+};
+struct BertW {
+    float* word = nullptr; float* pos = nullptr; float* type0 = nullptr;
+    NormW ln;
+    std::vector<BertLayerW> layers;
+};
+struct VlaLayerW { LinW q, kv, o, ff1, ff2; NormW ln_att, ln_ff; };
+struct VlaW {
+    LinW vis_fc, ins_fc;
+    NormW ln;
+    std::vector<VlaLayerW> layers;
+    float* pe = nullptr;       // sinusoid table [L][d_model] f32, built once (common/utils.py:167-185)
+};
+struct RnnW {
+    LinW cat;                  // LSTM: [4H][in+H] f32, bias = b_ih + b_hh
+    LinW ih, hh;               // GRU: separate
+    int in = 0;
+};
+struct HighW {
+    TrunkW rgb, depth;
+    float* rgb_pe = nullptr;   // [16][64] transposed view of spatial_embeddings (the `.view` quirk)
+    float* depth_pe = nullptr; // [S][64]
+    int depth_S = 0, depth_C = 0;
+    BertW bert;
+    LinW rgb_kv, depth_kv, rgb_linear, depth_linear;
+    VlaW vla;
+    RnnW rnn;
+    float* head_w = nullptr; float* head_b = nullptr;
+};
+struct LowW {
+    bool rgb_simple = false, depth_simple = false;
+    TrunkW rgb, depth;
+    SimpleCnnW rgb_s, depth_s;
+    LinW rgb_fc, depth_fc;
+    float* subtask_emb = nullptr;
+    RnnW rnn;
+    float* lin_w = nullptr; float* lin_b = nullptr; float* stop_w = nullptr; float* stop_b = nullptr;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = true;
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        char* p = (dry ? (char*)0x1000 : base) + off;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    void reset() { off = 0; }
+};
+
+struct Tap { float* dev = nullptr; size_t cap = 0; size_t n = 0; Shape shape; };
+
+}  // namespace hcm
+
+struct hcm_ctx {
+    hcm_config cfg;
+    int dt = 0;                     // DT_F32 / DT_BF16
+    size_t esz = 4;
+    std::map<std::string, hcm::HostTensor> sd[2];
+    bool finalized = false;
+    std::vector<void*> dev_allocs;
+    size_t weight_bytes = 0;
+    hcm::HighW hi;
+    hcm::LowW lo;
+    hcm::Arena arena;
+    int64_t* pred_buf = nullptr;    // argmax output for hcm_act
+    std::string err;
+    bool taps_on = false;
+    std::map<std::string, hcm::Tap> taps;
+    hipStream_t stream = nullptr;
+    bool failed = false;            // a launch failed during the current forward
+};

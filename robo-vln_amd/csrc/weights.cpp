@@ -1,0 +1,481 @@
+// State-dict spec (strict keys/shapes), and weight preparation at hcm_finalize():
+// BatchNorm folding, OIHW -> OHWI re-layout for the NHWC implicit GEMM, flatten-order permutations,
+// fused QKV / KV / recurrent weight concatenation, conversion to the compute dtype, upload.
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "model.h"
+
+namespace hcm {
+
+static const int RESNET50_BLOCKS[4] = {3, 4, 6, 3};
+
+// ------------------------------------------------------------------------------------------------ spec
+struct SpecB {
+    std::map<std::string, HostTensor>& m;
+    void add(const std::string& k, Shape s) { m[k].shape = std::move(s); }
+    void conv(const std::string& k, int co, int ci, int kh, int kw) { add(k, {co, ci, kh, kw}); }
+    void linear(const std::string& p, int o, int i) { add(p + ".weight", {o, i}); add(p + ".bias", {o}); }
+    void norm(const std::string& p, int c) { add(p + ".weight", {c}); add(p + ".bias", {c}); }
+    void bn(const std::string& p, int c) {
+        norm(p, c); add(p + ".running_mean", {c}); add(p + ".running_var", {c}); add(p + ".num_batches_tracked", {});
+    }
+};
+
+static void spec_tv_resnet50(SpecB& s, const std::string& pre, bool with_fc) {
+    s.conv(pre + "conv1.weight", 64, 3, 7, 7); s.bn(pre + "bn1", 64);
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            s.conv(p + "conv1.weight", planes, inpl, 1, 1); s.bn(p + "bn1", planes);
+            s.conv(p + "conv2.weight", planes, planes, 3, 3); s.bn(p + "bn2", planes);
+            s.conv(p + "conv3.weight", planes * 4, planes, 1, 1); s.bn(p + "bn3", planes * 4);
+            if (bi == 0) { s.conv(p + "downsample.0.weight", planes * 4, inpl, 1, 1); s.bn(p + "downsample.1", planes * 4); }
+            inpl = planes * 4;
+        }
+    }
+    if (with_fc) s.linear(pre + "fc", 1000, 2048);
+}
+
+static void spec_gn_resnet50(SpecB& s, const std::string& pre, int in_ch, int base, int cc) {
+    const std::string bb = pre + "backbone.";
+    s.conv(bb + "conv1.0.weight", base, in_ch, 7, 7); s.norm(bb + "conv1.1", base);
+    int inpl = base;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = base << li;
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            s.conv(p + "convs.0.weight", planes, inpl, 1, 1); s.norm(p + "convs.1", planes);
+            s.conv(p + "convs.3.weight", planes, planes, 3, 3); s.norm(p + "convs.4", planes);
+            s.conv(p + "convs.6.weight", planes * 4, planes, 1, 1); s.norm(p + "convs.7", planes * 4);
+            if (bi == 0) { s.conv(p + "downsample.0.weight", planes * 4, inpl, 1, 1); s.norm(p + "downsample.1", planes * 4); }
+            inpl = planes * 4;
+        }
+    }
+    s.conv(pre + "compression.0.weight", cc, inpl, 3, 3); s.norm(pre + "compression.1", cc);
+}
+
+static int simple_cnn_out_hw(int hw) {
+    int d = hw;
+    const int ks[3] = {8, 4, 3}, st[3] = {4, 2, 1};
+    for (int i = 0; i < 3; ++i) d = (d - ks[i]) / st[i] + 1;
+    return d;
+}
+static void spec_simple_cnn(SpecB& s, const std::string& pre, int in_ch, int hw, int out_f) {
+    const int d = simple_cnn_out_hw(hw);
+    s.add(pre + "cnn.0.weight", {32, in_ch, 8, 8}); s.add(pre + "cnn.0.bias", {32});
+    s.add(pre + "cnn.2.weight", {64, 32, 4, 4}); s.add(pre + "cnn.2.bias", {64});
+    s.add(pre + "cnn.4.weight", {32, 64, 3, 3}); s.add(pre + "cnn.4.bias", {32});
+    s.linear(pre + "cnn.7", out_f, 32 * d * d);
+}
+
+static void spec_rnn(SpecB& s, const std::string& pre, const hcm_config& c, int in_f) {
+    const int g = c.rnn_type == HCM_LSTM ? 4 : 3;
+    s.add(pre + "weight_ih_l0", {g * c.hidden, in_f}); s.add(pre + "weight_hh_l0", {g * c.hidden, c.hidden});
+    s.add(pre + "bias_ih_l0", {g * c.hidden}); s.add(pre + "bias_hh_l0", {g * c.hidden});
+}
+
+int depth_final_spatial(const hcm_config& c) { return (c.depth_h / 2) / 32; }
+int depth_compress_channels(const hcm_config& c) {
+    const int fs = depth_final_spatial(c);
+    return (int)std::lround(2048.0 / (fs * fs));
+}
+
+void build_spec_high(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    SpecB s{ctx->sd[HCM_HIGH]};
+    const int h = c.bert_hidden;
+    const std::string e = "embedding_layer.embeddings.";
+    s.add(e + "word_embeddings.weight", {c.bert_vocab, h});
+    s.add(e + "position_embeddings.weight", {c.bert_max_pos, h});
+    s.add(e + "token_type_embeddings.weight", {2, h});
+    s.norm(e + "LayerNorm", h);
+    for (int i = 0; i < c.bert_layers; ++i) {
+        const std::string p = "embedding_layer.encoder.layer." + std::to_string(i) + ".";
+        s.linear(p + "attention.self.query", h, h); s.linear(p + "attention.self.key", h, h);
+        s.linear(p + "attention.self.value", h, h); s.linear(p + "attention.output.dense", h, h);
+        s.norm(p + "attention.output.LayerNorm", h);
+        s.linear(p + "intermediate.dense", c.bert_inter, h); s.linear(p + "output.dense", h, c.bert_inter);
+        s.norm(p + "output.LayerNorm", h);
+    }
+    s.linear("embedding_layer.pooler.dense", h, h);
+    s.linear("ins_fc", 256, 768);
+    const int fs = depth_final_spatial(c), cc = depth_compress_channels(c);
+    const int dC = cc + 64, rC = 2048 + 64;
+    spec_gn_resnet50(s, "depth_encoder.visual_encoder.", 1, c.depth_baseplanes, cc);
+    s.add("depth_encoder.spatial_embeddings.weight", {fs * fs, 64});
+    spec_tv_resnet50(s, "rgb_encoder.cnn.", false);
+    s.add("rgb_encoder.spatial_embeddings.weight", {16, 64});
+    s.linear("rgb_linear.2", c.rgb_out, rC);
+    s.linear("depth_linear.1", c.depth_out, dC * fs * fs);
+    s.add("rgb_kv.weight", {c.vis_in, rC, 1}); s.add("rgb_kv.bias", {c.vis_in});
+    s.add("depth_kv.weight", {c.vis_in, dC, 1}); s.add("depth_kv.bias", {c.vis_in});
+    const int d = c.d_model;
+    for (int i = 0; i < c.vla_layers; ++i) {
+        const std::string p = "image_cm_encoder.layers." + std::to_string(i) + ".";
+        const std::string a = p + "enc_att.attention.";
+        s.linear(a + "fc_q", d, d); s.linear(a + "fc_k", d, d); s.linear(a + "fc_v", d, d); s.linear(a + "fc_o", d, d);
+        s.norm(p + "enc_att.layer_norm", d);
+        s.linear(p + "pwff.fc1", c.d_ff, d); s.linear(p + "pwff.fc2", d, c.d_ff);
+        s.norm(p + "pwff.layer_norm", d);
+    }
+    s.linear("image_cm_encoder.vis_fc", d, c.vis_in);
+    s.linear("image_cm_encoder.ins_fc", d, c.ins_in);
+    s.norm("image_cm_encoder.layer_norm", d);
+    spec_rnn(s, "state_encoder.rnn.", c, 2 * 256 + c.depth_out + c.rgb_out);   // IMAGE_CROSS_MODAL_ENCODER.d_model = 256
+    s.linear("progress_monitor", 1, c.hidden);
+    s.linear("linear", c.num_actions, c.hidden);
+}
+
+void build_spec_low(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    SpecB s{ctx->sd[HCM_LOW]};
+    if (c.depth_encoder == HCM_ENC_RESNET) {
+        const int fs = depth_final_spatial(c), cc = depth_compress_channels(c);
+        spec_gn_resnet50(s, "depth_encoder.visual_encoder.", 1, c.depth_baseplanes, cc);
+        s.linear("depth_encoder.visual_fc.1", c.depth_out, cc * fs * fs);
+    } else {
+        spec_simple_cnn(s, "depth_encoder.", 1, c.depth_h, c.depth_out);
+    }
+    if (c.rgb_encoder == HCM_ENC_RESNET) {
+        spec_tv_resnet50(s, "rgb_encoder.cnn.", true);
+        s.linear("rgb_encoder.fc", c.rgb_out, 2048);
+    } else {
+        spec_simple_cnn(s, "rgb_encoder.", 3, c.rgb_h, c.rgb_out);
+    }
+    s.add("sub_task_embedding.weight", {c.num_sub_tasks + 1, 32});
+    spec_rnn(s, "state_encoder.rnn.", c, c.depth_out + c.rgb_out + 32);
+    s.linear("progress_monitor", 1, c.hidden);
+    s.linear("linear", c.lo_actions, c.hidden);
+    s.linear("stop_linear", 1, c.hidden);
+}
+
+// ------------------------------------------------------------------------------------------------ upload helpers
+static uint16_t f2bf_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct Uploader {
+    hcm_ctx* ctx;
+    void* raw(const void* src, size_t bytes) {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) throw std::runtime_error("hipMalloc failed for weights");
+        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy H2D failed");
+        ctx->dev_allocs.push_back(d);
+        ctx->weight_bytes += bytes;
+        return d;
+    }
+    float* f32(const std::vector<float>& v) { return (float*)raw(v.data(), v.size() * 4); }
+    void* typed(const std::vector<float>& v, int dt) {
+        if (dt == DT_F32) return raw(v.data(), v.size() * 4);
+        std::vector<uint16_t> h(v.size());
+        for (size_t i = 0; i < v.size(); ++i) h[i] = f2bf_host(v[i]);
+        return raw(h.data(), h.size() * 2);
+    }
+};
+
+static const HostTensor& T_(hcm_ctx* ctx, int model, const std::string& key) {
+    auto it = ctx->sd[model].find(key);
+    if (it == ctx->sd[model].end() || !it->second.loaded) throw std::runtime_error("missing state_dict key: " + key);
+    return it->second;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// conv weight OIHW (+ optional per-channel scale) -> [O][Kp] with k = (kh*KW+kw)*I + ci
+static ConvW make_conv(hcm_ctx* ctx, Uploader& up, const HostTensor& w, const std::vector<float>* scale,
+                       const std::vector<float>* bias) {
+    ConvW c;
+    c.Cout = (int)w.shape[0]; c.Cin = (int)w.shape[1]; c.KH = (int)w.shape[2]; c.KW = (int)w.shape[3];
+    c.K = c.KH * c.KW * c.Cin;
+    c.Kp = round_up(c.K, 32);
+    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
+    for (int o = 0; o < c.Cout; ++o) {
+        const float sc = scale ? (*scale)[o] : 1.f;
+        for (int i = 0; i < c.Cin; ++i)
+            for (int kh = 0; kh < c.KH; ++kh)
+                for (int kw = 0; kw < c.KW; ++kw)
+                    r[(size_t)o * c.Kp + (size_t)(kh * c.KW + kw) * c.Cin + i] =
+                        w.f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw] * sc;
+    }
+    c.w = up.typed(r, ctx->dt);
+    if (bias) c.bias = up.f32(*bias);
+    return c;
+}
+
+// eval-mode BatchNorm2d folded into the preceding bias-free conv: y = conv(x)*g/sqrt(v+eps) + (b - m*g/sqrt(v+eps))
+static ConvW make_conv_bn(hcm_ctx* ctx, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
+    const HostTensor& w = T_(ctx, model, wkey);
+    const HostTensor& g = T_(ctx, model, bn + ".weight");
+    const HostTensor& b = T_(ctx, model, bn + ".bias");
+    const HostTensor& m = T_(ctx, model, bn + ".running_mean");
+    const HostTensor& v = T_(ctx, model, bn + ".running_var");
+    const int C = (int)w.shape[0];
+    std::vector<float> scale(C), bias(C);
+    for (int o = 0; o < C; ++o) {
+        const float s = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
+        scale[o] = s;
+        bias[o] = b.f[o] - m.f[o] * s;
+    }
+    return make_conv(ctx, up, w, &scale, &bias);
+}
+
+static NormW make_norm(hcm_ctx* ctx, Uploader& up, int model, const std::string& p) {
+    NormW n;
+    const HostTensor& g = T_(ctx, model, p + ".weight");
+    n.gamma = up.f32(g.f);
+    n.beta = up.f32(T_(ctx, model, p + ".bias").f);
+    n.C = (int)g.shape[0];
+    return n;
+}
+
+// Linear weight [N][K] (rows optionally concatenated from several tensors), K zero-padded to a multiple of 32.
+// `perm` (size K) maps new column j -> source column perm[j].
+static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs,
+                        int dt, const std::vector<int>* perm = nullptr) {
+    LinW l;
+    l.K = (int)ws[0]->shape[1];
+    l.Kp = round_up(l.K, 32);
+    l.dt = dt;
+    int N = 0;
+    for (auto* w : ws) N += (int)w->shape[0];
+    l.N = N;
+    std::vector<float> r((size_t)N * l.Kp, 0.f);
+    int row = 0;
+    for (auto* w : ws) {
+        const int n = (int)w->shape[0];
+        for (int i = 0; i < n; ++i, ++row)
+            for (int j = 0; j < l.K; ++j) r[(size_t)row * l.Kp + j] = w->f[(size_t)i * l.K + (perm ? (*perm)[j] : j)];
+    }
+    l.w = up.typed(r, dt);
+    if (!bs.empty()) {
+        std::vector<float> b;
+        for (auto* t : bs) b.insert(b.end(), t->f.begin(), t->f.end());
+        l.bias = up.f32(b);
+    }
+    return l;
+}
+
+static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
+    TrunkW t;
+    t.gn = false;
+    t.cin1 = 3;
+    t.conv1 = make_conv_bn(ctx, up, model, pre + "conv1.weight", pre + "bn1");
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            BottleneckW b;
+            b.stride = (li > 0 && bi == 0) ? 2 : 1;
+            b.c1 = make_conv_bn(ctx, up, model, p + "conv1.weight", p + "bn1");
+            b.c2 = make_conv_bn(ctx, up, model, p + "conv2.weight", p + "bn2");
+            b.c3 = make_conv_bn(ctx, up, model, p + "conv3.weight", p + "bn3");
+            if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn(ctx, up, model, p + "downsample.0.weight", p + "downsample.1"); }
+            t.blocks.push_back(b);
+        }
+    t.out_c = 2048;
+    return t;
+}
+
+static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
+    TrunkW t;
+    t.gn = true;
+    t.groups = ctx->cfg.depth_baseplanes / 2;          // resnet_encoders.py:30
+    t.cin1 = 1;
+    const std::string bb = pre + "backbone.";
+    t.conv1 = make_conv(ctx, up, T_(ctx, model, bb + "conv1.0.weight"), nullptr, nullptr);
+    t.n_conv1 = make_norm(ctx, up, model, bb + "conv1.1");
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            BottleneckW b;
+            b.stride = (li > 0 && bi == 0) ? 2 : 1;
+            b.c1 = make_conv(ctx, up, T_(ctx, model, p + "convs.0.weight"), nullptr, nullptr); b.n1 = make_norm(ctx, up, model, p + "convs.1");
+            b.c2 = make_conv(ctx, up, T_(ctx, model, p + "convs.3.weight"), nullptr, nullptr); b.n2 = make_norm(ctx, up, model, p + "convs.4");
+            b.c3 = make_conv(ctx, up, T_(ctx, model, p + "convs.6.weight"), nullptr, nullptr); b.n3 = make_norm(ctx, up, model, p + "convs.7");
+            if (bi == 0) {
+                b.has_ds = true;
+                b.ds = make_conv(ctx, up, T_(ctx, model, p + "downsample.0.weight"), nullptr, nullptr);
+                b.nds = make_norm(ctx, up, model, p + "downsample.1");
+            }
+            t.blocks.push_back(b);
+        }
+    t.compress = make_conv(ctx, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr);
+    t.n_compress = make_norm(ctx, up, model, pre + "compression.1");
+    t.out_c = t.compress.Cout;
+    return t;
+}
+
+static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre, int cin, int hw) {
+    SimpleCnnW s;
+    s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
+    s.c0 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.0.weight"), nullptr, &T_(ctx, model, pre + "cnn.0.bias").f);
+    s.c1 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
+    s.c2 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
+    // Flatten() of the NCHW (B,32,h,w) tensor: source column c*S + s; ours is NHWC: s*32 + c
+    const int S = s.h3 * s.h3;
+    std::vector<int> perm((size_t)S * 32);
+    for (int sp = 0; sp < S; ++sp)
+        for (int c = 0; c < 32; ++c) perm[(size_t)sp * 32 + c] = c * S + sp;
+    s.fc = make_linear(up, {&T_(ctx, model, pre + "cnn.7.weight")}, {&T_(ctx, model, pre + "cnn.7.bias")}, ctx->dt, &perm);
+    return s;
+}
+
+static RnnW make_rnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
+    RnnW r;
+    const HostTensor& wih = T_(ctx, model, pre + "weight_ih_l0");
+    const HostTensor& whh = T_(ctx, model, pre + "weight_hh_l0");
+    const HostTensor& bih = T_(ctx, model, pre + "bias_ih_l0");
+    const HostTensor& bhh = T_(ctx, model, pre + "bias_hh_l0");
+    r.in = (int)wih.shape[1];
+    const int H = ctx->cfg.hidden;
+    if (ctx->cfg.rnn_type == HCM_LSTM) {
+        const int N = 4 * H, K = r.in + H;
+        HostTensor cat;
+        cat.shape = {N, K};
+        cat.f.resize((size_t)N * K);
+        for (int n = 0; n < N; ++n) {
+            std::memcpy(&cat.f[(size_t)n * K], &wih.f[(size_t)n * r.in], r.in * 4);
+            std::memcpy(&cat.f[(size_t)n * K + r.in], &whh.f[(size_t)n * H], H * 4);
+        }
+        HostTensor b;
+        b.shape = {N};
+        b.f.resize(N);
+        for (int n = 0; n < N; ++n) b.f[n] = bih.f[n] + bhh.f[n];
+        r.cat = make_linear(up, {&cat}, {&b}, DT_F32);
+    } else {
+        r.ih = make_linear(up, {&wih}, {&bih}, DT_F32);
+        r.hh = make_linear(up, {&whh}, {&bhh}, DT_F32);
+    }
+    return r;
+}
+
+// spatial_embeddings (S,64) viewed as (1,64,h,w): channel c, token s reads E.flat[c*S + s]  (resnet_encoders.py:91-104,:218-231)
+static float* make_pe_view(Uploader& up, const HostTensor& E) {
+    const int S = (int)E.shape[0], C = (int)E.shape[1];
+    std::vector<float> t((size_t)S * C);
+    for (int s = 0; s < S; ++s)
+        for (int c = 0; c < C; ++c) t[(size_t)s * C + c] = E.f[(size_t)c * S + s];
+    return up.f32(t);
+}
+
+void prepare_high(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    const int M = HCM_HIGH;
+    Uploader up{ctx};
+    HighW& h = ctx->hi;
+    h.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
+    h.depth = make_gn_trunk(ctx, up, M, "depth_encoder.visual_encoder.");
+    h.rgb_pe = make_pe_view(up, T_(ctx, M, "rgb_encoder.spatial_embeddings.weight"));
+    h.depth_pe = make_pe_view(up, T_(ctx, M, "depth_encoder.spatial_embeddings.weight"));
+    const int fs = depth_final_spatial(c);
+    h.depth_S = fs * fs;
+    h.depth_C = depth_compress_channels(c) + 64;
+    // BERT
+    const std::string e = "embedding_layer.embeddings.";
+    h.bert.word = up.f32(T_(ctx, M, e + "word_embeddings.weight").f);
+    h.bert.pos = up.f32(T_(ctx, M, e + "position_embeddings.weight").f);
+    {
+        const HostTensor& tt = T_(ctx, M, e + "token_type_embeddings.weight");
+        std::vector<float> t0(tt.f.begin(), tt.f.begin() + c.bert_hidden);
+        h.bert.type0 = up.f32(t0);
+    }
+    h.bert.ln = make_norm(ctx, up, M, e + "LayerNorm");
+    for (int i = 0; i < c.bert_layers; ++i) {
+        const std::string p = "embedding_layer.encoder.layer." + std::to_string(i) + ".";
+        BertLayerW L;
+        L.qkv = make_linear(up, {&T_(ctx, M, p + "attention.self.query.weight"), &T_(ctx, M, p + "attention.self.key.weight"), &T_(ctx, M, p + "attention.self.value.weight")},
+                            {&T_(ctx, M, p + "attention.self.query.bias"), &T_(ctx, M, p + "attention.self.key.bias"), &T_(ctx, M, p + "attention.self.value.bias")}, ctx->dt);
+        L.o = make_linear(up, {&T_(ctx, M, p + "attention.output.dense.weight")}, {&T_(ctx, M, p + "attention.output.dense.bias")}, ctx->dt);
+        L.ln1 = make_norm(ctx, up, M, p + "attention.output.LayerNorm");
+        L.ff1 = make_linear(up, {&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, ctx->dt);
+        L.ff2 = make_linear(up, {&T_(ctx, M, p + "output.dense.weight")}, {&T_(ctx, M, p + "output.dense.bias")}, ctx->dt);
+        L.ln2 = make_norm(ctx, up, M, p + "output.LayerNorm");
+        h.bert.layers.push_back(L);
+    }
+    // Conv1d(k=1) weights (out,in,1) are linear layers over the token axis
+    h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt);
+    h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt);
+    h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt);
+    {
+        // depth_linear: Flatten of (B, dC, S) -> column c*S + s; ours [B][S][dC] -> s*dC + c
+        const int S = h.depth_S, dC = h.depth_C;
+        std::vector<int> perm((size_t)S * dC);
+        for (int s = 0; s < S; ++s)
+            for (int ch = 0; ch < dC; ++ch) perm[(size_t)s * dC + ch] = ch * S + s;
+        h.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt, &perm);
+    }
+    // Visual_Ling_Attn
+    VlaW& v = h.vla;
+    v.vis_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.vis_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.vis_fc.bias")}, ctx->dt);
+    v.ins_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.ins_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.ins_fc.bias")}, ctx->dt);
+    v.ln = make_norm(ctx, up, M, "image_cm_encoder.layer_norm");
+    for (int i = 0; i < c.vla_layers; ++i) {
+        const std::string p = "image_cm_encoder.layers." + std::to_string(i) + ".";
+        const std::string a = p + "enc_att.attention.";
+        VlaLayerW L;
+        L.q = make_linear(up, {&T_(ctx, M, a + "fc_q.weight")}, {&T_(ctx, M, a + "fc_q.bias")}, ctx->dt);
+        L.kv = make_linear(up, {&T_(ctx, M, a + "fc_k.weight"), &T_(ctx, M, a + "fc_v.weight")}, {&T_(ctx, M, a + "fc_k.bias"), &T_(ctx, M, a + "fc_v.bias")}, ctx->dt);
+        L.o = make_linear(up, {&T_(ctx, M, a + "fc_o.weight")}, {&T_(ctx, M, a + "fc_o.bias")}, ctx->dt);
+        L.ln_att = make_norm(ctx, up, M, p + "enc_att.layer_norm");
+        L.ff1 = make_linear(up, {&T_(ctx, M, p + "pwff.fc1.weight")}, {&T_(ctx, M, p + "pwff.fc1.bias")}, ctx->dt);
+        L.ff2 = make_linear(up, {&T_(ctx, M, p + "pwff.fc2.weight")}, {&T_(ctx, M, p + "pwff.fc2.bias")}, ctx->dt);
+        L.ln_ff = make_norm(ctx, up, M, p + "pwff.layer_norm");
+        v.layers.push_back(L);
+    }
+    {
+        // sinusoid_encoding_table(L, d): pe[p,2i] = sin(p / 10000^(2i/d)), pe[p,2i+1] = cos(same)  (common/utils.py:167-185)
+        const int L = c.instr_len, d = c.d_model;
+        std::vector<float> pe((size_t)L * d);
+        for (int p = 0; p < L; ++p)
+            for (int i = 0; i < d / 2; ++i) {
+                const float div = std::pow(10000.0f, (2.0f * (float)i) / (float)d);
+                const float ang = (float)p / div;
+                pe[(size_t)p * d + 2 * i] = std::sin(ang);
+                pe[(size_t)p * d + 2 * i + 1] = std::cos(ang);
+            }
+        v.pe = up.f32(pe);
+    }
+    h.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
+    h.head_w = up.f32(T_(ctx, M, "linear.weight").f);
+    h.head_b = up.f32(T_(ctx, M, "linear.bias").f);
+}
+
+void prepare_low(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    const int M = HCM_LOW;
+    Uploader up{ctx};
+    LowW& l = ctx->lo;
+    l.depth_simple = c.depth_encoder == HCM_ENC_SIMPLECNN;
+    l.rgb_simple = c.rgb_encoder == HCM_ENC_SIMPLECNN;
+    if (!l.depth_simple) {
+        l.depth = make_gn_trunk(ctx, up, M, "depth_encoder.visual_encoder.");
+        // visual_fc: Flatten of (B, cc, fs, fs) -> c*S + s ; ours s*cc + c
+        const int fs = depth_final_spatial(c), S = fs * fs, cc = depth_compress_channels(c);
+        std::vector<int> perm((size_t)S * cc);
+        for (int s = 0; s < S; ++s)
+            for (int ch = 0; ch < cc; ++ch) perm[(size_t)s * cc + ch] = ch * S + s;
+        l.depth_fc = make_linear(up, {&T_(ctx, M, "depth_encoder.visual_fc.1.weight")}, {&T_(ctx, M, "depth_encoder.visual_fc.1.bias")}, ctx->dt, &perm);
+    } else {
+        l.depth_s = make_simple_cnn(ctx, up, M, "depth_encoder.", 1, c.depth_h);
+    }
+    if (!l.rgb_simple) {
+        l.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
+        l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt);
+    } else {
+        l.rgb_s = make_simple_cnn(ctx, up, M, "rgb_encoder.", 3, c.rgb_h);
+    }
+    l.subtask_emb = up.f32(T_(ctx, M, "sub_task_embedding.weight").f);
+    l.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
+    l.lin_w = up.f32(T_(ctx, M, "linear.weight").f);
+    l.lin_b = up.f32(T_(ctx, M, "linear.bias").f);
+    l.stop_w = up.f32(T_(ctx, M, "stop_linear.weight").f);
+    l.stop_b = up.f32(T_(ctx, M, "stop_linear.bias").f);
+}
+
+}  // namespace hcm

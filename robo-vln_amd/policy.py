@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's model-call interface for the HCM hot path.
+
+`Seq2Seq_HighLevel_CMA` / `Seq2Seq_LowLevel` keep the reference's tuple-in / tuple-out `forward(batch)`
+contracts (robo_vln_baselines/models/seq2seq_highlevel_cma.py:170-233, seq2seq_lowlevel.py:116-162) and
+properties, so the eval loop of hierarchical_trainer.py:1088-1197 can call them unchanged; `Policy.act()` is
+the fused step (hi -> argmax -> lo) of :1095-1101.  All arithmetic happens in libhcm.so (HIP, gfx950);
+torch is used only for device buffers and streams.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import HCMConfig
+
+_TORCH_DT = {torch.float32: _lib.HCM_F32, torch.uint8: _lib.HCM_U8, torch.int32: _lib.HCM_I32, torch.int64: _lib.HCM_I64}
+
+
+def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low):
+    s = _lib.HcmConfigStruct()
+    s.struct_size = C.sizeof(_lib.HcmConfigStruct)
+    s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
+    s.max_batch = max_batch
+    s.rgb_h = s.rgb_w = cfg.rgb_hw
+    s.depth_h = s.depth_w = cfg.depth_hw
+    s.instr_len = cfg.instr_len
+    s.rgb_encoder = _lib.HCM_ENC_RESNET if cfg.rgb_encoder == "TorchVisionResNet50" else _lib.HCM_ENC_SIMPLECNN
+    s.depth_encoder = _lib.HCM_ENC_RESNET if cfg.depth_encoder == "VlnResnetDepthEncoder" else _lib.HCM_ENC_SIMPLECNN
+    s.rgb_out, s.depth_out, s.depth_baseplanes = cfg.rgb_out, cfg.depth_out, cfg.depth_baseplanes
+    s.vla_layers, s.d_model, s.vla_heads, s.d_ff = cfg.vla_layers, cfg.d_model, cfg.vla_heads, cfg.d_ff
+    s.vis_in, s.ins_in = cfg.vis_in, cfg.ins_in
+    s.hidden = cfg.hidden
+    s.rnn_type = _lib.HCM_LSTM if cfg.rnn_type == "LSTM" else _lib.HCM_GRU
+    s.num_actions, s.num_sub_tasks, s.lo_actions = cfg.num_actions, cfg.num_sub_tasks, cfg.lo_actions
+    s.bert_layers, s.bert_hidden, s.bert_heads = cfg.bert_layers, cfg.bert_hidden, cfg.bert_heads
+    s.bert_inter, s.bert_vocab, s.bert_max_pos = cfg.bert_inter, cfg.bert_vocab, cfg.bert_max_pos
+    s.build_high, s.build_low = int(build_high), int(build_low)
+    s.use_prev_action, s.ablate_instruction = int(cfg.use_prev_action), int(cfg.ablate_instruction)
+    s.progress_monitor = int(cfg.progress_monitor)
+    return s
+
+
+def _np32(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    v = np.asarray(v)
+    if v.dtype == np.int64:
+        return np.require(v, requirements="C"), _lib.HCM_I64          # keeps 0-d (num_batches_tracked) 0-d
+    return np.require(v, dtype=np.float32, requirements="C"), _lib.HCM_F32
+
+
+class HCMEngine:
+    """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
+
+    def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
+                 precision="bf16", device=None):
+        cfg.validate()
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.precision = precision
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._lib = _lib.lib()
+        self._h = C.c_void_p()
+        self.has_high = high_level_state_dict is not None
+        self.has_low = low_level_state_dict is not None
+        with torch.cuda.device(self.device):
+            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low)
+            _lib.check(self._lib.hcm_create(C.byref(st), C.byref(self._h)))
+            try:
+                # load_state_dict(strict=True) semantics (hierarchical_trainer.py:343-345)
+                for model, sd in ((_lib.HCM_HIGH, high_level_state_dict), (_lib.HCM_LOW, low_level_state_dict)):
+                    if sd is None:
+                        continue
+                    for k, v in sd.items():
+                        a, dt = _np32(v)
+                        shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+                        _lib.check(self._lib.hcm_load_tensor(self._h, model, k.encode(), a.ctypes.data_as(C.c_void_p), dt,
+                                                             shape, a.ndim), self._h)
+                _lib.check(self._lib.hcm_finalize(self._h), self._h)
+            except Exception:
+                self._lib.hcm_destroy(self._h)
+                self._h = C.c_void_p()
+                raise
+
+    def query(self, what):
+        out = C.c_int64()
+        _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
+        return out.value
+
+    @property
+    def num_recurrent_layers(self):
+        return self.query(_lib.HCM_NUM_RECURRENT_LAYERS)
+
+    def close(self):
+        if self._h:
+            self._lib.hcm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _dev(self, t, dtypes):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        if t.dtype not in dtypes:
+            t = t.to(dtypes[0])
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    def _obs(self, observations, need_ids):
+        rgb = self._dev(observations["rgb"], (torch.float32, torch.uint8))
+        depth = self._dev(observations["depth"], (torch.float32,))
+        B = rgb.shape[0]
+        c = self.cfg
+        if tuple(rgb.shape[1:]) != (c.rgb_hw, c.rgb_hw, 3):
+            raise ValueError(f"rgb must be (B,{c.rgb_hw},{c.rgb_hw},3), got {tuple(rgb.shape)}")
+        if tuple(depth.shape) != (B, c.depth_hw, c.depth_hw, 1):
+            raise ValueError(f"depth must be (B,{c.depth_hw},{c.depth_hw},1), got {tuple(depth.shape)}")
+        ids = None
+        if need_ids:
+            ids = self._dev(observations["instruction"], (torch.int64, torch.int32, torch.float32))
+            if ids.dim() != 2 or ids.shape[1] != c.instr_len:
+                raise ValueError(f"instruction must be (B or 1, {c.instr_len}), got {tuple(ids.shape)}")
+            # instruction.expand(B, L) (seq2seq_highlevel_cma.py:189-190)
+            ids = ids.expand(B, ids.shape[1]).contiguous()
+        return rgb, depth, ids, B
+
+    def _mask(self, masks, B):
+        m = self._dev(masks, (torch.float32,))
+        # the reference reads masks[:,0] (seq2seq_highlevel_cma.py:208); accept (B,), (B,1), (B,2), (B,2,1)
+        m = m.reshape(B, -1)[:, 0].contiguous()
+        return m
+
+    def _hidden(self, h, B):
+        h = self._dev(h, (torch.float32,))
+        R = self.num_recurrent_layers
+        if tuple(h.shape) != (R, B, self.cfg.hidden):
+            raise ValueError(f"hidden state must be ({R},{B},{self.cfg.hidden}), got {tuple(h.shape)}")
+        return h
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- the three calls
+    def high_forward(self, observations, hidden, masks):
+        with torch.cuda.device(self.device):
+            rgb, depth, ids, B = self._obs(observations, True)
+            h_in, m = self._hidden(hidden, B), self._mask(masks, B)
+            logits = torch.empty(B, self.cfg.num_actions, device=self.device, dtype=torch.float32)
+            h_out = torch.empty_like(h_in)
+            _lib.check(self._lib.hcm_high_forward(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(),
+                                                  ids.data_ptr(), _TORCH_DT[ids.dtype], B, h_in.data_ptr(), m.data_ptr(),
+                                                  logits.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
+        return logits, h_out
+
+    def low_forward(self, observations, hidden, masks, subtask):
+        with torch.cuda.device(self.device):
+            rgb, depth, _, B = self._obs(observations, False)
+            h_in, m = self._hidden(hidden, B), self._mask(masks, B)
+            st = self._dev(subtask, (torch.int64,)).reshape(B)
+            vel = torch.empty(B, self.cfg.lo_actions, device=self.device, dtype=torch.float32)
+            stop = torch.empty(B, 1, device=self.device, dtype=torch.float32)
+            h_out = torch.empty_like(h_in)
+            _lib.check(self._lib.hcm_low_forward(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), B,
+                                                 h_in.data_ptr(), m.data_ptr(), st.data_ptr(), vel.data_ptr(),
+                                                 stop.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
+        return vel, stop, h_out
+
+    def act(self, observations, hi_hidden, lo_hidden, masks, out=None):
+        with torch.cuda.device(self.device):
+            rgb, depth, ids, B = self._obs(observations, True)
+            hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
+            rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
+            hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)
+            _lib.check(self._lib.hcm_act(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
+                                         _TORCH_DT[ids.dtype], B, hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
+                                         rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), self._stream()), self._h)
+        return rec, hh2, lh2
+
+    # ---- debug taps
+    def enable_taps(self, on=True):
+        _lib.check(self._lib.hcm_debug_enable_taps(self._h, int(on)), self._h)
+
+    def get_tap(self, name):
+        n = C.c_int64()
+        shape = (C.c_int64 * 4)()
+        _lib.check(self._lib.hcm_debug_get_tap(self._h, name.encode(), None, 0, C.byref(n), shape), self._h)
+        buf = np.empty(n.value, dtype=np.float32)
+        _lib.check(self._lib.hcm_debug_get_tap(self._h, name.encode(), buf.ctypes.data_as(C.c_void_p), n.value,
+                                               C.byref(n), shape), self._h)
+        return buf.reshape([d for d in shape if d > 0])
+
+
+class _ModelBase:
+    def __init__(self, engine: HCMEngine):
+        self.engine = engine
+        self.model_config = engine.cfg
+
+    def __call__(self, batch):
+        return self.forward(batch)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def output_size(self):
+        return self.engine.cfg.hidden
+
+    @property
+    def is_blind(self):
+        return False
+
+    @property
+    def num_recurrent_layers(self):
+        return self.engine.num_recurrent_layers
+
+
+class Seq2Seq_HighLevel_CMA(_ModelBase):
+    """Drop-in for robo_vln_baselines.models.seq2seq_highlevel_cma.Seq2Seq_HighLevel_CMA (inference)."""
+
+    def forward(self, batch):
+        observations, rnn_hidden_states, prev_actions, masks = batch   # prev_actions unused (use_prev_action=False)
+        logits, hidden = self.engine.high_forward(observations, rnn_hidden_states, masks)
+        # the reference mutates the caller's dict (seq2seq_highlevel_cma.py:196)
+        if isinstance(observations, dict) and "instruction" in observations:
+            del observations["instruction"]
+        return logits, hidden
+
+
+class Seq2Seq_LowLevel(_ModelBase):
+    """Drop-in for robo_vln_baselines.models.seq2seq_lowlevel.Seq2Seq_LowLevel (inference)."""
+
+    def forward(self, batch):
+        observations, rnn_hidden_states, prev_actions, masks, discrete_actions = batch
+        return self.engine.low_forward(observations, rnn_hidden_states, masks, discrete_actions)
+
+
+class Policy:
+    """`act()`-shaped wrapper over the fused step (the reference has no Policy class)."""
+
+    def __init__(self, engine: HCMEngine):
+        self.engine = engine
+        self.high_level = Seq2Seq_HighLevel_CMA(engine)
+        self.low_level = Seq2Seq_LowLevel(engine)
+
+    def act(self, observations, hi_hidden, lo_hidden, prev_actions, masks, deterministic=True):
+        """-> (record (B,7) = [4 sub-task logits, lin_vel, ang_vel, stop logit], hi_hidden', lo_hidden')."""
+        return self.engine.act(observations, hi_hidden, lo_hidden, masks)
+
+    def get_value(self, *a, **k):
+        """Imitation-learned agent: the reference has no critic / value head anywhere."""
+        return None

@@ -1,0 +1,102 @@
+"""Shared helpers: replay a golden case through the HIP engine and the CPU oracle."""
+import numpy as np
+import torch
+
+from oracle import cases, hcm_oracle
+from robo_vln_amd import synth
+from robo_vln_amd.policy import HCMEngine
+
+
+def build_engine(cfg, which, precision, max_batch):
+    hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED) if which in ("both", "hi") else None
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED) if which in ("both", "lo") else None
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=max_batch, precision=precision)
+    return eng, hi_sd, lo_sd
+
+
+def _cmp(a, b):
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = np.abs(a - b)
+    return float(d.max()), float(d.mean()), float(np.abs(b).max())
+
+
+def run_case(name, precision, taps=True, rgb_uint8=False):
+    """Returns dict: per-step record errors vs oracle and vs the committed golden, per-tap errors (step 0)."""
+    cfg, B, T, which = cases.case_config(name)
+    eng, hi_sd, lo_sd = build_engine(cfg, which, precision, B)
+    hi_o = hcm_oracle.HighLevelOracle(cfg, hi_sd) if hi_sd is not None else None
+    lo_o = hcm_oracle.LowLevelOracle(cfg, lo_sd) if lo_sd is not None else None
+    R = cfg.num_recurrent_layers
+    dev = eng.device
+    hi_h = torch.zeros(R, B, cfg.hidden, device=dev)
+    lo_h = torch.zeros(R, B, cfg.hidden, device=dev)
+    o_hi_h = torch.zeros(R, B, cfg.hidden)
+    o_lo_h = torch.zeros(R, B, cfg.hidden)
+    rep = {"case": name, "precision": precision, "steps": [], "taps": {}}
+    recs = []
+    for t in range(T):
+        obs_np = synth.make_observations(cfg, B, step=t, seed=cases.SEED, rgb_uint8=rgb_uint8)
+        obs = {k: torch.from_numpy(v).to(dev) for k, v in obs_np.items()}
+        m = cases.step_masks(B, t)
+        mt = torch.from_numpy(m).to(dev)
+        eng.enable_taps(taps and t == 0)
+        th, tl = {}, {}
+        if which == "both":
+            rec, hi_h, lo_h = eng.act(obs, hi_h, lo_h, mt)
+            pred = torch.argmax(rec[:, :4], 1).cpu()
+        elif which == "hi":
+            logits, hi_h = eng.high_forward(obs, hi_h, mt)
+            rec = torch.cat([logits, torch.zeros(B, 3, device=dev)], 1)
+        else:
+            pred = torch.from_numpy(cases.fixed_subtask(B, t))
+            vel, stop, lo_h = eng.low_forward(obs, lo_h, mt, pred.to(dev))
+            rec = torch.cat([torch.zeros(B, 4, device=dev), vel, stop], 1)
+        rec = rec.cpu().numpy()
+        # oracle on the same inputs; the low-level oracle is fed the HIP path's sub-task choice so that a
+        # near-tie in the 4 logits cannot turn a rounding difference into a different branch
+        obs_o = dict(obs_np)
+        obs_o["rgb"] = obs_np["rgb"].astype(np.float32)
+        if hi_o is not None:
+            lg, o_hi_h = hi_o.forward(obs_o, o_hi_h, m, th if t == 0 else None)
+        else:
+            lg = torch.zeros(B, 4)
+        if lo_o is not None:
+            vl, sp, o_lo_h = lo_o.forward(obs_o, o_lo_h, m, pred, tl if t == 0 else None)
+        else:
+            vl, sp = torch.zeros(B, 2), torch.zeros(B, 1)
+        orec = torch.cat([lg, vl, sp], 1).numpy()
+        e = _cmp(rec, orec)
+        same_branch = bool((torch.argmax(lg, 1) == pred).all()) if which == "both" else True
+        rep["steps"].append({"t": t, "max_abs": e[0], "mean_abs": e[1], "same_branch": same_branch})
+        recs.append(rec)
+        if taps and t == 0:
+            pairs = []
+            if hi_o is not None:
+                pairs += [("hi.depth_spatial", th["depth_spatial"].transpose(1, 2)), ("hi.rgb_spatial", th["rgb_spatial"].transpose(1, 2)),
+                          ("hi.bert", th["bert"]), ("hi.rgb_kv", th["rgb_kv"].transpose(1, 2)), ("hi.depth_kv", th["depth_kv"].transpose(1, 2)),
+                          ("hi.vla_rgb", th["vla_rgb"]), ("hi.vla_depth", th["vla_depth"]), ("hi.rnn_in", th["rnn_in"])]
+            if lo_o is not None:
+                pairs += [("lo.rnn_in", tl["rnn_in"])]
+            for nm, ref in pairs:
+                got = eng.get_tap(nm)
+                ref = ref.contiguous().numpy()
+                if nm.endswith("rnn_in"):
+                    got = got[:, :ref.shape[1]]
+                rep["taps"][nm] = _cmp(got, ref)
+    rep["hi_hidden"] = _cmp(hi_h.cpu().numpy(), o_hi_h.numpy())
+    rep["lo_hidden"] = _cmp(lo_h.cpu().numpy(), o_lo_h.numpy())
+    rep["records"] = np.stack(recs)
+    eng.close()
+    return rep
+
+
+def format_report(rep):
+    lines = [f"== {rep['case']} [{rep['precision']}]"]
+    for k, (mx, mean, ref) in rep["taps"].items():
+        lines.append(f"   tap {k:18s} max_abs {mx:.3e} mean_abs {mean:.3e} |ref|max {ref:.3f}")
+    for s in rep["steps"]:
+        lines.append(f"   step {s['t']} record max_abs {s['max_abs']:.3e} mean {s['mean_abs']:.3e} same_branch {s['same_branch']}")
+    lines.append(f"   hi_hidden max_abs {rep['hi_hidden'][0]:.3e}  lo_hidden max_abs {rep['lo_hidden'][0]:.3e}")
+    return "\n".join(lines)

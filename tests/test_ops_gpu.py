@@ -1,0 +1,173 @@
+"""Kernel-level parity: each HIP operator (through the C ABI hcm_op_* entry points) vs the plain torch fp32
+op it replaces, on the GPU, for both storage types."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp32": (0, torch.float32, 2e-4), "bf16": (1, torch.bfloat16, 2e-2)}
+
+
+def _lib():
+    from robo_vln_amd import _lib
+    return _lib.lib(), _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, K, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (2, 16, 16, 64, 128, 3, 1, 1),
+    (3, 17, 15, 32, 32, 3, 2, 1),
+    (2, 16, 16, 256, 512, 1, 2, 0),
+    (1, 8, 8, 1024, 128, 3, 1, 1),
+    (2, 30, 30, 32, 64, 4, 2, 0),
+    (5, 9, 9, 128, 36, 3, 1, 1),
+])
+@pytest.mark.parametrize("epi", ["none", "bias_relu", "bias_res_relu"])
+def test_conv2d(prec, shape, epi):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cin, Cout, K, stride, pad = shape
+    x = _rnd(B, Cin, H, W).to(tdt).float()
+    w = (_rnd(Cout, Cin, K, K, seed=1) * (3.0 / (Cin * K * K)) ** 0.5).to(tdt).float()
+    bias = _rnd(Cout, seed=2) if epi != "none" else None
+    ref = F.conv2d(x, w, bias, stride=stride, padding=pad)
+    res = None
+    if epi == "bias_res_relu":
+        res = _rnd(*ref.shape, seed=3).to(tdt).float()
+        ref = ref + res
+    if epi != "none":
+        ref = F.relu(ref)
+    dev = "cuda"
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev, tdt)          # OHWI
+    bd = bias.to(dev) if bias is not None else None
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev, tdt) if res is not None else None
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev, dtype=tdt)
+    rc = lib.hcm_op_conv2d(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, B, H, W, Cin, Cout, K, K, stride, pad,
+                           L.ACT_RELU if epi != "none" else L.ACT_NONE, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("mnk", [(5, 4, 512), (64, 2048, 1408), (160, 768, 768), (1000, 3072, 768), (333, 256, 2112), (40, 128, 3072), (7, 1536, 416)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear(prec, mnk, act):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    M, N, K = mnk
+    x = _rnd(M, K).to(tdt).float()
+    w = (_rnd(N, K, seed=1) * (3.0 / K) ** 0.5).to(tdt).float()
+    b = _rnd(N, seed=2)
+    res = _rnd(M, N, seed=3).to(tdt).float()
+    ref = x @ w.t() + b + res
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    dev = "cuda"
+    xd, wd, bd, rd = x.to(dev, tdt), w.to(dev, tdt), b.to(dev), res.to(dev, tdt)   # keep alive: raw pointers are passed
+    for out_f32 in (0, 1):
+        y = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if out_f32 else tdt)
+        rc = lib.hcm_op_linear(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, M, N, K, act, out_f32, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        err = (y.float().cpu() - ref).abs().max().item()
+        assert err <= (tol if not out_f32 or prec == "fp32" else 2e-3) * max(1.0, ref.abs().max().item()), (err, out_f32)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 12, 80, 80), (3, 4, 80, 16), (1, 4, 20, 4), (2, 12, 160, 160), (2, 4, 160, 160), (1, 12, 7, 7)])
+def test_attention(prec, cfg):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, h, Lq, Lk = cfg
+    D = h * 64
+    q = _rnd(B, Lq, D, scale=2.0).to(tdt).float()
+    k = _rnd(B, Lk, D, scale=2.0, seed=1).to(tdt).float()
+    v = _rnd(B, Lk, D, seed=2).to(tdt).float()
+    qh = q.view(B, Lq, h, 64).transpose(1, 2)
+    kh = k.view(B, Lk, h, 64).transpose(1, 2)
+    vh = v.view(B, Lk, h, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(B, Lq, D)
+    dev = "cuda"
+    y = torch.full((B, Lq, D), float("nan"), device=dev, dtype=tdt)
+    qd, kd, vd = q.to(dev, tdt), k.to(dev, tdt), v.to(dev, tdt)
+    rc = lib.hcm_op_attention(_p(qd), _p(kd), _p(vd), _p(y), code, B, h, Lq, Lk, D, D, D, D, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("D", [768, 256])
+def test_layernorm(prec, D):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    rows = 37
+    x = _rnd(rows, D, scale=3.0).to(tdt).float()
+    r = _rnd(rows, D, seed=1).to(tdt).float()
+    g, b = _rnd(D, seed=2) + 1.5, _rnd(D, seed=3)
+    ref = F.layer_norm(x + r, (D,), g, b, 1e-12)
+    dev = "cuda"
+    y = torch.full((rows, D), float("nan"), device=dev, dtype=tdt)
+    xd, rd, gd, bd = x.to(dev, tdt), r.to(dev, tdt), g.to(dev), b.to(dev)
+    rc = lib.hcm_op_layernorm(_p(xd), _p(rd), _p(gd), _p(bd), _p(y), code, rows, D, 1e-12, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= tol * 3, err
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 32, 16), (3, 16, 16, 256, 16), (2, 4, 4, 1024, 16), (2, 4, 4, 128, 1), (1, 64, 64, 32, 16)])
+def test_groupnorm(prec, cfg):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cc, G = cfg
+    x = (_rnd(B, Cc, H, W, scale=2.0) + 0.3).to(tdt).float()
+    r = _rnd(B, Cc, H, W, seed=1).to(tdt).float()
+    g, b = _rnd(Cc, seed=2) + 1.5, _rnd(Cc, seed=3)
+    ref = F.relu(F.group_norm(x, G, g, b, 1e-5) + r)
+    dev = "cuda"
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    gd, bd = g.to(dev), b.to(dev)
+    rc = lib.hcm_op_groupnorm(_p(xd), _p(rd), _p(gd), _p(bd), code, B, H * W, Cc, G, 1e-5, 1, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (xd.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= tol * 3, err
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_maxpool(prec):
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cc = 2, 17, 16, 64
+    x = _rnd(B, Cc, H, W).to(tdt).float()
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dev = "cuda"
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    y = torch.full((B, ref.shape[2], ref.shape[3], Cc), float("nan"), device=dev, dtype=tdt)
+    rc = lib.hcm_op_maxpool3x3s2(_p(xd), _p(y), code, B, H, W, Cc, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)
