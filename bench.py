@@ -1,0 +1,203 @@
+"""bench.py -- policy env-steps/sec of the batched HCM act() on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]/[2]): per GPU 64 environments, 256x256 RGB-D frames, 80-token
+instruction, full HCM model (2x ResNet-50 RGB, 2x GN-ResNet-50 depth, BERT-base, cross-modal block,
+2x LSTM + heads), bf16 storage / fp32 accumulate, random-init weights, synthetic inputs resident in HBM.
+One step = one fused act() (hi -> argmax -> lo) over the rank's 64 environments, followed (N>1) by ONE
+RCCL all-gather of the (64,7) action records.  Weak scaling: global batch = 64 * N.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_STEP = 36.9          # SURVEY.md 8a / BASELINE.md section 2: config 2/3, 2xMAC conv+matmul+attention+RNN
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PER_GPU_BATCH = 64
+
+
+def host_cores():
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
+    """The CPU oracle (kind 'port': torch-CPU fp32 restatement validated against the imported reference)
+    timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, batch, cfg.hidden)
+    lh = torch.zeros(R, batch, cfg.hidden)
+    obs = synth.make_observations(cfg, batch, step=0, seed=0)
+    mask = np.zeros(batch, np.float32)
+    _, hh, lh = ora.act(obs, hh, lh, mask)                 # warm-up
+    mask[:] = 1
+    t0 = time.time()
+    for _ in range(steps):
+        _, hh, lh = ora.act(obs, hh, lh, mask)
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "env-steps/s", "cores": ncores, "kind": "port",
+            "sample": f"{steps} act() steps at batch {batch}, 256x256 RGB-D, L=80, fp32, torch {torch.__version__} "
+                      f"with {torch.get_num_threads()} threads"}
+
+
+def dominant_kernel_probe(batch):
+    """The dominant kernel is the bf16 MFMA implicit-GEMM (igemm_kernel<bf16,128,128>); time it live with HIP
+    events (torch events on the launch stream) on the heaviest layer shape of the step: the 3x3/1 conv of
+    ResNet-50 layer1 (64->64 ch at 64x64, per-launch algorithmic FLOPs = 2*M*N*K)."""
+    import ctypes as C
+    import torch
+    from robo_vln_amd import _lib
+    lib = _lib.lib()
+    B, H, W, Cin, Cout = batch, 64, 64, 64, 64
+    x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cout, device="cuda")
+    y = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        rc = lib.hcm_op_conv2d(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), _lib.HCM_BF16, B, H, W, Cin, Cout,
+                               3, 3, 1, 1, _lib.ACT_RELU, st)
+        assert rc == 0
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * H * W * Cout * 9 * Cin
+    return {"kernel": "igemm_kernel<bf16,128,64> conv3x3 64->64 @64x64", "us_per_launch": round(ms * 1e3, 2),
+            "tflops": round(flops / ms / 1e9, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="environments per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hcm_pkg
+    hcm_pkg.load()
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import baseline_config
+    from robo_vln_amd.policy import HCMEngine
+    from robo_vln_amd.rollout import shard_range, gather_records
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = baseline_config(1)
+    B = args.batch
+    global_B = B * world
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=args.precision)
+    # this rank's contiguous block of environments e -> rank e // B
+    lo_e, hi_e = shard_range(global_B, world, rank)
+    obs_np = synth.make_observations(cfg, B, step=rank, seed=0)    # distinct frames per rank, same shapes
+    obs = {"rgb": torch.from_numpy(obs_np["rgb"]).cuda(), "depth": torch.from_numpy(obs_np["depth"]).cuda(),
+           "instruction": torch.from_numpy(obs_np["instruction"]).cuda()}
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, B, cfg.hidden, device="cuda")
+    lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+    mask0 = torch.zeros(B, device="cuda")
+    mask1 = torch.ones(B, device="cuda")
+    rec = torch.empty(B, 7, device="cuda")
+    all_rec = torch.empty(global_B, 7, device="cuda") if world > 1 else rec
+
+    def step(mask):
+        nonlocal hh, lh
+        _, hh, lh = eng.act(obs, hh, lh, mask, out=rec)
+        if world > 1:
+            gather_records(rec, all_rec)
+
+    step(mask0)
+    for _ in range(max(0, args.warmup - 1)):
+        step(mask1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(mask1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(all_rec).all()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = global_B * args.steps / dt
+        achieved = value * GFLOP_PER_STEP / 1e3               # TFLOP/s, algorithmic
+        out = {
+            "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr",
+            "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic (random-init weights, random RGB-D frames and token ids, resident in HBM)",
+            "config": {"workload": "BASELINE.json configs[1]: full HCM act() (hi->argmax->lo), 256x256 RGB-D, L=80, VLA N=1, LSTM-512",
+                       "per_gpu_batch": B, "global_batch": global_B,
+                       "parallelism": f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4), "traffic": None,
+                         "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s"},
+        }
+        if args.precision == "bf16":
+            try:
+                out["roofline"]["dominant_kernel"] = dominant_kernel_probe(B)
+            except Exception as e:       # never lose the headline number to the probe
+                out["roofline"]["dominant_kernel"] = {"error": str(e)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, hi_sd, lo_sd)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,7 +34,7 @@ enum hcm_status {
     HCM_ERR_NOMEM = -7
 };
 
-enum hcm_dtype { HCM_F32 = 0, HCM_BF16 = 1, HCM_I32 = 2, HCM_I64 = 3, HCM_U8 = 4 };
+enum hcm_dtype { HCM_F32 = 0, HCM_BF16 = 1, HCM_I32 = 2, HCM_I64 = 3, HCM_U8 = 4, HCM_F16 = 5 };
 enum hcm_model { HCM_HIGH = 0, HCM_LOW = 1 };
 enum hcm_encoder { HCM_ENC_RESNET = 0, HCM_ENC_SIMPLECNN = 1 };
 enum hcm_rnn { HCM_LSTM = 0, HCM_GRU = 1 };
@@ -55,7 +55,7 @@ enum hcm_query_what {
  * :180-199).  Zero-initialise, set struct_size = sizeof(hcm_config), fill. */
 typedef struct hcm_config {
     int32_t struct_size;
-    int32_t precision;        /* HCM_BF16 (bf16 storage + MFMA, fp32 accumulate) or HCM_F32 (fp32 storage + fp32 MFMA) */
+    int32_t precision;        /* HCM_BF16 (16-bit storage + MFMA, fp32 accumulate; recurrent cells fp32) or HCM_F32 (fp32 MFMA) */
     int32_t max_batch;        /* workspace is sized for this many environments per call */
     int32_t rgb_h, rgb_w;     /* frames are NHWC */
     int32_t depth_h, depth_w;
@@ -70,7 +70,8 @@ typedef struct hcm_config {
     int32_t use_prev_action;            /* must be 0: broken branch in the reference (seq2seq_highlevel_cma.py:203-207) */
     int32_t ablate_instruction;         /* must be 0: broken branch (:183-184) */
     int32_t progress_monitor;           /* must be 0 in forward (:221-225 references an undefined name) */
-    int32_t reserved[8];
+    int32_t reserved[8];                /* [0..3]: storage-type override (hcm_dtype + 1, 0 = default) for the depth trunk /
+                                           BERT / cross-modal block / RGB trunk; see DESIGN.md section 5 */
 } hcm_config;
 
 /* Replaces model construction, hierarchical_trainer.py:315-328 (Seq2Seq_HighLevel_CMA.__init__

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhcm.so")
 
-HCM_F32, HCM_BF16, HCM_I32, HCM_I64, HCM_U8 = 0, 1, 2, 3, 4
+HCM_F32, HCM_BF16, HCM_I32, HCM_I64, HCM_U8, HCM_F16 = 0, 1, 2, 3, 4, 5
 HCM_HIGH, HCM_LOW = 0, 1
 HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1

@@ -67,7 +67,21 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     h = new hcm_ctx();
     h->cfg = *cfg;
     h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
-    h->esz = dt_size(h->dt);
+    // per-sub-network storage type; reserved[0..3] = (dtype + 1) overrides for depth / bert / vla / rgb, 0 = default.
+    // Default in bf16 mode: RGB trunks + cross-modal block on bf16 MFMA tiles; the GroupNorm depth trunk and BERT on
+    // fp16 tiles (same MFMA rate, 3 more mantissa bits) -- measured error budget in DESIGN.md section 5.
+    h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
+    if (h->dt == DT_BF16) { h->dt_depth = DT_F16; h->dt_bert = DT_F16; }
+    {
+        int* slots[4] = {&h->dt_depth, &h->dt_bert, &h->dt_vla, &h->dt_rgb};
+        for (int i = 0; i < 4; ++i) {
+            const int ov = cfg->reserved[i];
+            if (ov == 0) continue;
+            const int d = ov - 1;
+            if (d != HCM_F32 && d != HCM_BF16 && d != HCM_F16) { delete h; h = nullptr; return fail(nullptr, HCM_ERR_ARG, "bad sub-network precision override"); }
+            *slots[i] = d == HCM_F32 ? DT_F32 : d == HCM_BF16 ? DT_BF16 : DT_F16;
+        }
+    }
     try {
         if (cfg->build_high) build_spec_high(h);
         if (cfg->build_low) build_spec_low(h);
@@ -260,7 +274,7 @@ static int op_rc(hipError_t e) {
     g_create_err = std::string("op launch failed: ") + hipGetErrorString(e);
     return e == hipErrorInvalidValue ? HCM_ERR_ARG : HCM_ERR_HIP;
 }
-static int op_dt(int dtype) { return dtype == HCM_BF16 ? DT_BF16 : DT_F32; }
+static int op_dt(int dtype) { return dtype == HCM_BF16 ? DT_BF16 : dtype == HCM_F16 ? DT_F16 : DT_F32; }
 
 int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y, int dtype, int B, int H,
                   int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {

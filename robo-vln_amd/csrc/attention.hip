@@ -99,19 +99,19 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
                             int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s) {
     const size_t lds = (size_t)Lk * 64 * sizeof(float) * 2;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int CH = dt == DT_BF16 ? 8 : 4;
+    const int CH = dt_chunk(dt);
     if ((ldq % CH) || (ldk % CH) || (ldv % CH) || (ldo % CH)) return hipErrorInvalidValue;
     if (q_batch_mod <= 0) q_batch_mod = B;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (dt == DT_BF16)
-        hipLaunchKernelGGL(attention_kernel<bf16>, dim3(B * heads), dim3(256), lds, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod);
-    else
-        hipLaunchKernelGGL(attention_kernel<float>, dim3(B * heads), dim3(256), lds, s, (const float*)q, (const float*)k, (const float*)v, (float*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod);
+#define LA(T) hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), lds, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod)
+    if (dt == DT_BF16) LA(bf16); else if (dt == DT_F16) LA(f16); else if (dt == DT_F32) LA(float); else return hipErrorInvalidValue;
+#undef LA
     return hipGetLastError();
 }
 

@@ -14,6 +14,10 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 
+struct f16 { uint16_t v; };
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float8_t __attribute__((ext_vector_type(8)));
+
 template <typename T> struct Tr;
 template <> struct Tr<float> {
     static constexpr int CH = 4;     // elements per 16-byte chunk
@@ -24,6 +28,12 @@ template <> struct Tr<bf16> {
     static constexpr int CH = 8;
     static __device__ __forceinline__ float ld(const bf16* p) { return bf2f(p->v); }
     static __device__ __forceinline__ void st(bf16* p, float v) { p->v = f2bf(v); }
+};
+
+template <> struct Tr<f16> {
+    static constexpr int CH = 8;
+    static __device__ __forceinline__ float ld(const f16* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+    static __device__ __forceinline__ void st(f16* p, float v) { p->v = __builtin_bit_cast(uint16_t, (_Float16)v); }
 };
 
 // load / store CH consecutive elements (16 bytes) as floats
@@ -48,6 +58,19 @@ __device__ __forceinline__ void st_chunk(bf16* p, const float (&o)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ void ld_chunk(const f16* p, float (&o)[8]) {
+    const half8_t h = *reinterpret_cast<const half8_t*>(p);
+    const float8_t f = __builtin_convertvector(h, float8_t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f[i];
+}
+__device__ __forceinline__ void st_chunk(f16* p, const float (&o)[8]) {
+    float8_t f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = o[i];
+    *reinterpret_cast<half8_t*>(p) = __builtin_convertvector(f, half8_t);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

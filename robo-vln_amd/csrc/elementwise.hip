@@ -6,6 +6,15 @@
 
 namespace hcm {
 
+// run `...` with T bound to the storage type named by dt
+#define HCM_DISPATCH_T(dt, ...)                                           \
+    do {                                                                  \
+        if ((dt) == DT_BF16) { using T = bf16; __VA_ARGS__; }             \
+        else if ((dt) == DT_F16) { using T = f16; __VA_ARGS__; }          \
+        else if ((dt) == DT_F32) { using T = float; __VA_ARGS__; }        \
+        else return hipErrorInvalidValue;                                 \
+    } while (0)
+
 static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
     size_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -21,6 +30,7 @@ template <typename S> __device__ __forceinline__ float ld_src(const S* p);
 template <> __device__ __forceinline__ float ld_src<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld_src<uint8_t>(const uint8_t* p) { return (float)*p; }
 template <> __device__ __forceinline__ float ld_src<bf16>(const bf16* p) { return bf2f(p->v); }
+template <> __device__ __forceinline__ float ld_src<f16>(const f16* p) { return Tr<f16>::ld(p); }
 
 template <typename S, typename T>
 __global__ void im2col_kernel(const S* __restrict__ x, T* __restrict__ a, int B, int H, int W, int C, int KH, int KW,
@@ -56,15 +66,16 @@ __global__ void im2col_kernel(const S* __restrict__ x, T* __restrict__ a, int B,
 hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C, int KH, int KW,
                          int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s) {
     const int K = KH * KW * C;
-    const int CH = dt == DT_BF16 ? 8 : 4;
+    const int CH = dt_chunk(dt);
     const size_t total = (size_t)B * Ho * Wo * (Kp / CH);
     const int g = grid_for(total, 256, 256 * 32);
-#define L(S, T) hipLaunchKernelGGL((im2col_kernel<S, T>), dim3(g), dim3(256), 0, s, (const S*)x, (T*)a, B, H, W, C, KH, KW, stride, pad, Ho, Wo, K, Kp, scale)
-    if (dt == DT_BF16) {
-        if (src_dt == DT_F32) L(float, bf16); else if (src_dt == DT_U8) L(uint8_t, bf16); else if (src_dt == DT_BF16) L(bf16, bf16); else return hipErrorInvalidValue;
-    } else {
-        if (src_dt == DT_F32) L(float, float); else if (src_dt == DT_U8) L(uint8_t, float); else return hipErrorInvalidValue;
-    }
+#define L(S) hipLaunchKernelGGL((im2col_kernel<S, T>), dim3(g), dim3(256), 0, s, (const S*)x, (T*)a, B, H, W, C, KH, KW, stride, pad, Ho, Wo, K, Kp, scale)
+    HCM_DISPATCH_T(dt, {
+        if (src_dt == DT_F32) L(float);
+        else if (src_dt == DT_U8) L(uint8_t);
+        else if (src_dt == dt) L(T);
+        else return hipErrorInvalidValue;
+    });
 #undef L
     return hipGetLastError();
 }
@@ -88,8 +99,7 @@ __global__ void avgpool2_kernel(const float* __restrict__ x, T* __restrict__ y, 
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s) {
     const size_t total = (size_t)B * (H / 2) * (W / 2);
     if (W & 1) return hipErrorInvalidValue;
-    if (dt == DT_BF16) hipLaunchKernelGGL(avgpool2_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, B, H, W);
-    else hipLaunchKernelGGL(avgpool2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, B, H, W);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(avgpool2_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, (T*)y, B, H, W));
     return hipGetLastError();
 }
 
@@ -124,11 +134,10 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
     }
 }
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
-    const int CH = dt == DT_BF16 ? 8 : 4;
+    const int CH = dt_chunk(dt);
     if (C % CH) return hipErrorInvalidValue;
     const size_t total = (size_t)B * Ho * Wo * (C / CH);
-    if (dt == DT_BF16) hipLaunchKernelGGL(maxpool_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, H, W, C, Ho, Wo);
-    else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, B, H, W, C, Ho, Wo));
     return hipGetLastError();
 }
 
@@ -164,11 +173,10 @@ __global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y,
     }
 }
 hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s) {
-    const int CH = dt == DT_BF16 ? 8 : 4;
+    const int CH = dt_chunk(dt);
     if (C % CH || ldy % CH) return hipErrorInvalidValue;
     const size_t total = (size_t)B * OH * OW * (C / CH);
-    if (dt == DT_BF16) hipLaunchKernelGGL(adaptive_pool_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, H, W, C, OH, OW, ldy);
-    else hipLaunchKernelGGL(adaptive_pool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, OH, OW, ldy);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(adaptive_pool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, B, H, W, C, OH, OW, ldy));
     return hipGetLastError();
 }
 
@@ -190,8 +198,7 @@ __global__ void mean_rows_kernel(const T* __restrict__ x, void* __restrict__ y, 
 }
 hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s) {
     const size_t total = (size_t)B * C;
-    if (dt == DT_BF16) hipLaunchKernelGGL(mean_rows_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, y, B, S, C, ldx, ldy, out_f32);
-    else hipLaunchKernelGGL(mean_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, y, B, S, C, ldx, ldy, out_f32);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(mean_rows_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, y, B, S, C, ldx, ldy, out_f32));
     return hipGetLastError();
 }
 
@@ -207,103 +214,98 @@ __global__ void fill_cols_kernel(const float* __restrict__ tab, T* __restrict__ 
 }
 hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int C, int ldy, hipStream_t s) {
     const size_t total = (size_t)B * S * C;
-    if (dt == DT_BF16) hipLaunchKernelGGL(fill_cols_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, tab, (bf16*)y, B, S, C, ldy);
-    else hipLaunchKernelGGL(fill_cols_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, tab, (float*)y, B, S, C, ldy);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(fill_cols_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, tab, (T*)y, B, S, C, ldy));
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm (NHWC, in place)
-// nn.GroupNorm(ngroups, C) after every conv of the habitat ResNet; statistics per (sample, group) in f32.
-// Pass 1: per-sample partial sums -> atomics into stats[b][g][{sum,sumsq}].  Pass 2: normalise (+res) (+ReLU).
+// nn.GroupNorm(G, C) after every conv of the habitat ResNet (+ residual + ReLU of the bottleneck), ONE launch:
+// a workgroup owns (sample b, slab of CS channels made of whole groups): pass 1 accumulates per-channel sum / sum of
+// squares in registers (a thread always sees the same 16-byte channel chunk), wave-shuffle + LDS reduce to per-group
+// mean / rstd in f32; pass 2 re-reads the slab (L2-resident: HW*CS*2 B <= 64 KB for every layer of the trunk),
+// normalises, adds the residual, applies ReLU and stores.  No atomics, no memset, no stats buffer.
 template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int HW, int C, int G) {
+__global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int HW, int C, int G, int CS, float eps, int relu) {
     constexpr int CH = Tr<T>::CH;
-    __shared__ float sh[2 * 64];             // G <= 64
-    const int b = blockIdx.y;
-    const int cv = C / CH;
+    __shared__ float s_sum[1024], s_sq[1024], s_mean[1024], s_rstd[1024];  // per channel of the slab (CS <= 1024)
+    const int slabs = C / CS;
+    const int b = blockIdx.x / slabs;
+    const int c_base = (blockIdx.x % slabs) * CS;
     const int Cg = C / G;
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sh[i] = 0.f;
+    const int cpr = CS / CH;                 // 16-byte chunks per pixel inside the slab (power of two, <= 32)
+    const int tid = threadIdx.x;
+    const int cc = tid % cpr;                // this thread's chunk column (fixed)
+    const int prow = tid / cpr;              // first pixel
+    const int pstep = 256 / cpr;
+    T* xb = x + (size_t)b * HW * C + c_base + cc * CH;
+    const T* rb = res ? res + (size_t)b * HW * C + c_base + cc * CH : nullptr;
+    for (int i = tid; i < CS; i += 256) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
     __syncthreads();
-    const size_t n = (size_t)HW * cv;
-    const T* xb = x + (size_t)b * HW * C;
-    // blockDim.x * gridDim.x is a multiple of cv, so a thread always sees the same channel chunk
-    const size_t start = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * blockDim.x;
     float s1[CH], s2[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    for (size_t e = start; e < n; e += step) {
+    for (int p = prow; p < HW; p += pstep) {
         float v[CH];
-        ld_chunk(xb + e * CH, v);
+        ld_chunk(xb + (size_t)p * C, v);
 #pragma unroll
         for (int j = 0; j < CH; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
     }
-    if (start < n) {
-        const int c0 = (int)(start % cv) * CH;
+    // lanes with equal (lane % cpr) hold the same channels: butterfly over the other lane bits
+    for (int o = 32; o >= cpr; o >>= 1) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int g = (c0 + j) / Cg;
-            atomicAdd(&sh[2 * g], s1[j]);
-            atomicAdd(&sh[2 * g + 1], s2[j]);
-        }
+        for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if ((tid & 63) < cpr) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { atomicAdd(&s_sum[cc * CH + j], s1[j]); atomicAdd(&s_sq[cc * CH + j], s2[j]); }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&stats[(size_t)b * 2 * G + i], sh[i]);
-}
-
-template <typename T>
-__global__ void gn_apply_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ stats, int B, int HW, int C, int G,
-                                float eps, int relu) {
-    constexpr int CH = Tr<T>::CH;
-    const int cv = C / CH;
-    const int Cg = C / G;
-    const float inv_n = 1.0f / ((float)HW * (float)Cg);
-    const size_t per = (size_t)HW * cv;
-    const size_t total = (size_t)B * per;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(e / per);
-        const int c0 = (int)(e % cv) * CH;
+    for (int ch = tid; ch < CS; ch += 256) {
+        const int g0 = (ch / Cg) * Cg;       // first channel of this channel's group (inside the slab)
+        float a = 0.f, q = 0.f;
+        for (int j = 0; j < Cg; ++j) { a += s_sum[g0 + j]; q += s_sq[g0 + j]; }
+        const float inv_n = 1.0f / ((float)HW * (float)Cg);
+        const float mean = a * inv_n;
+        const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        const float ga = gamma[c_base + ch];
+        s_mean[ch] = mean * rstd * ga - beta[c_base + ch];     // y = x*scale - shift'
+        s_rstd[ch] = rstd * ga;
+    }
+    __syncthreads();
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sc[j] = s_rstd[cc * CH + j]; sh[j] = s_mean[cc * CH + j]; }
+    for (int p = prow; p < HW; p += pstep) {
         float v[CH], r[CH];
-        ld_chunk(x + e * CH, v);
-        if (res) ld_chunk(res + e * CH, r);
+        ld_chunk(xb + (size_t)p * C, v);
+        if (rb) ld_chunk(rb + (size_t)p * C, r);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int c = c0 + j;
-            const int g = c / Cg;
-            const float mean = stats[(size_t)b * 2 * G + 2 * g] * inv_n;
-            const float var = fmaxf(stats[(size_t)b * 2 * G + 2 * g + 1] * inv_n - mean * mean, 0.f);
-            float o = (v[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
-            if (res) o += r[j];
+            float o = v[j] * sc[j] - sh[j];
+            if (rb) o += r[j];
             if (relu) o = fmaxf(o, 0.f);
             v[j] = o;
         }
-        st_chunk(x + e * CH, v);
+        st_chunk(xb + (size_t)p * C, v);
     }
 }
 
-hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats, int dt, int B,
+hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* /*stats*/, int dt, int B,
                             int HW, int C, int G, float eps, int relu, hipStream_t s) {
-    const int CH = dt == DT_BF16 ? 8 : 4;
-    if (C % CH || C % G || G > 64) return hipErrorInvalidValue;
-    const int cv = C / CH;
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)B * 2 * G * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    // block size: multiple of cv (cv is a power of two <= 256 for every layer of the trunk; else fall back to cv-multiple)
-    int block = 256;
-    if (256 % cv) block = ((256 + cv - 1) / cv) * cv;
-    if (block > 1024) return hipErrorInvalidValue;
-    size_t n = (size_t)HW * cv;
-    int gx = (int)((n + block - 1) / block);
-    if (gx > 64) gx = 64;
-    if (gx < 1) gx = 1;
-    if (dt == DT_BF16) {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(gx, B), dim3(block), 0, s, (const bf16*)x, stats, HW, C, G);
-        hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(grid_for((size_t)B * n)), dim3(256), 0, s, (bf16*)x, (const bf16*)res, gamma, beta, stats, B, HW, C, G, eps, relu);
-    } else {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(gx, B), dim3(block), 0, s, (const float*)x, stats, HW, C, G);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for((size_t)B * n)), dim3(256), 0, s, (float*)x, (const float*)res, gamma, beta, stats, B, HW, C, G, eps, relu);
-    }
+    const int CH = dt_chunk(dt);
+    if (C % CH || C % G) return hipErrorInvalidValue;
+    const int Cg = C / G;
+    // slab: whole groups, multiple of the chunk, power-of-two chunk count <= 32, about 32 K elements per workgroup
+    int unit = Cg > CH ? Cg : CH;
+    if (unit % Cg || unit % CH) return hipErrorInvalidValue;
+    int CS = unit;
+    while (CS * 2 <= C && CS * 2 <= 256 && (CS * 2) / CH <= 32 && (long)HW * CS * 2 <= 32768 && C % (CS * 2) == 0) CS *= 2;
+    const int cpr = CS / CH;
+    if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) return hipErrorInvalidValue;
+    const int grid = B * (C / CS);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, CS, eps, relu));
     return hipGetLastError();
 }
 
@@ -355,12 +357,10 @@ hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, 
                             int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s) {
     const int wpb = 4;
     const dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
-#define L(T, DD) hipLaunchKernelGGL((layernorm_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, post_rows > 0 ? post_rows : 1, (T*)y, rows, eps)
-    if (dt == DT_BF16) {
-        if (D == 768) L(bf16, 768); else if (D == 256) L(bf16, 256); else if (D == 512) L(bf16, 512); else if (D == 128) L(bf16, 128); else return hipErrorInvalidValue;
-    } else {
-        if (D == 768) L(float, 768); else if (D == 256) L(float, 256); else if (D == 512) L(float, 512); else if (D == 128) L(float, 128); else return hipErrorInvalidValue;
-    }
+#define L(DD) hipLaunchKernelGGL((layernorm_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, post_rows > 0 ? post_rows : 1, (T*)y, rows, eps)
+    HCM_DISPATCH_T(dt, {
+        if (D == 768) L(768); else if (D == 256) L(256); else if (D == 512) L(512); else if (D == 128) L(128); else return hipErrorInvalidValue;
+    });
 #undef L
     return hipGetLastError();
 }
@@ -405,12 +405,10 @@ hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, con
     const int rows = B * L;
     if (D % 64 || D > 1024) return hipErrorInvalidValue;
     const dim3 grid((rows + 3) / 4), block(256);
-#define L_(T, I) hipLaunchKernelGGL((bert_embed_kernel<T, I>), grid, block, 0, s, (const I*)ids, word, pos, type0, gamma, beta, (T*)y, rows, L, D, vocab, eps)
-    if (dt == DT_BF16) {
-        if (ids_dt == DT_I64) L_(bf16, int64_t); else if (ids_dt == DT_I32) L_(bf16, int32_t); else if (ids_dt == DT_F32) L_(bf16, float); else return hipErrorInvalidValue;
-    } else {
-        if (ids_dt == DT_I64) L_(float, int64_t); else if (ids_dt == DT_I32) L_(float, int32_t); else if (ids_dt == DT_F32) L_(float, float); else return hipErrorInvalidValue;
-    }
+#define L_(I) hipLaunchKernelGGL((bert_embed_kernel<T, I>), grid, block, 0, s, (const I*)ids, word, pos, type0, gamma, beta, (T*)y, rows, L, D, vocab, eps)
+    HCM_DISPATCH_T(dt, {
+        if (ids_dt == DT_I64) L_(int64_t); else if (ids_dt == DT_I32) L_(int32_t); else if (ids_dt == DT_F32) L_(float); else return hipErrorInvalidValue;
+    });
 #undef L_
     return hipGetLastError();
 }
@@ -532,13 +530,27 @@ __global__ void from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, 
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) Tr<T>::st(y + e, x[e]);
 }
 hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s) {
-    if (dt == DT_BF16) hipLaunchKernelGGL(to_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)x, y, n);
-    else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, y, n);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(to_f32_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, y, n));
     return hipGetLastError();
 }
 hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s) {
-    if (dt == DT_BF16) hipLaunchKernelGGL(from_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, x, (bf16*)y, n);
-    else hipLaunchKernelGGL(from_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, x, (float*)y, n);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(from_f32_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, x, (T*)y, n));
+    return hipGetLastError();
+}
+
+template <typename A, typename B_>
+__global__ void convert_kernel(const A* __restrict__ x, B_* __restrict__ y, size_t n) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) Tr<B_>::st(y + e, Tr<A>::ld(x + e));
+}
+hipError_t launch_convert(const void* x, int dt_in, void* y, int dt_out, size_t n, hipStream_t s) {
+    if (dt_in == dt_out) return hipMemcpyAsync(y, x, n * dt_size(dt_in), hipMemcpyDeviceToDevice, s);
+    HCM_DISPATCH_T(dt_in, {
+        using A = T;
+        if (dt_out == DT_BF16) hipLaunchKernelGGL((convert_kernel<A, bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const A*)x, (bf16*)y, n);
+        else if (dt_out == DT_F16) hipLaunchKernelGGL((convert_kernel<A, f16>), dim3(grid_for(n)), dim3(256), 0, s, (const A*)x, (f16*)y, n);
+        else if (dt_out == DT_F32) hipLaunchKernelGGL((convert_kernel<A, float>), dim3(grid_for(n)), dim3(256), 0, s, (const A*)x, (float*)y, n);
+        else return hipErrorInvalidValue;
+    });
     return hipGetLastError();
 }
 

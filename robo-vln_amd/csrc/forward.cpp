@@ -21,7 +21,10 @@ struct Fwd {
     size_t esz;
     bool dry;
 
-    explicit Fwd(hcm_ctx* c) : ctx(c), ar(c->arena), s(c->stream), dt(c->dt), esz(c->esz), dry(c->arena.dry) {}
+    explicit Fwd(hcm_ctx* c) : ctx(c), ar(c->arena), s(c->stream), dt(c->dt_vla), esz(dt_size(c->dt_vla)), dry(c->arena.dry) {}
+
+    // switch the storage type of the sub-network being enqueued
+    void use(int d) { dt = d; esz = dt_size(d); }
 
     void ck(hipError_t e, const char* what) {
         if (e != hipSuccess) {
@@ -56,7 +59,7 @@ struct Fwd {
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
         g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
         g.M = in.B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
-        ck(launch_igemm(g, dt, s), "conv igemm");
+        ck(launch_igemm(g, w.dt, s), "conv igemm");
     }
     // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
     void linear(const LinW& w, const void* a, int M, int lda, void* y, int ldy, int act, bool out_f32,
@@ -223,6 +226,7 @@ struct Fwd {
         const int rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
         const int in = w.rnn.in, ldx = in + H;
         ar.reset();
+        use(ctx->dt_vla);
         // persistent (whole-forward) buffers first
         void* rgb_tok = alloc_t((size_t)B * 16 * rC);            // (B,2112,16) of the reference, token-major
         void* dep_tok = alloc_t((size_t)B * dS * dC);
@@ -230,28 +234,42 @@ struct Fwd {
 
         {   // depth_encoder (seq2seq_highlevel_cma.py:178-179): GN-ResNet50 + pos-emb channels
             const size_t m = ar.mark();
+            use(ctx->dt_depth);
             Act o = depth_trunk(w.depth, depth, B, "hi.depth");
+            void* tok = ctx->dt_depth == ctx->dt_vla ? dep_tok : alloc_t((size_t)B * dS * dC);
             if (!dry) {
-                ck(launch_adaptive_avgpool(o.p, dep_tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
-                ck(launch_fill_cols(w.depth_pe, (char*)dep_tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
+                ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+                if (tok != dep_tok) ck(launch_convert(tok, ctx->dt_depth, dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
             }
             ar.release(m);
         }
-        tap("hi.depth_spatial", dep_tok, true, {B, dS, dC});
         {   // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels
             const size_t m = ar.mark();
+            use(ctx->dt_rgb);
             Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "hi.rgb");
+            void* tok = ctx->dt_rgb == ctx->dt_vla ? rgb_tok : alloc_t((size_t)B * 16 * rC);
             if (!dry) {
-                ck(launch_adaptive_avgpool(o.p, rgb_tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
-                ck(launch_fill_cols(w.rgb_pe, (char*)rgb_tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
+                ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+                if (tok != rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
             }
             ar.release(m);
         }
+        use(ctx->dt_vla);
+        tap("hi.depth_spatial", dep_tok, true, {B, dS, dC});
         tap("hi.rgb_spatial", rgb_tok, true, {B, 16, rC});
 
         // BERT (:189-195)
+        use(ctx->dt_bert);
         void* emb = bert(w.bert, ids, ids_dt, B);
         tap("hi.bert", emb, true, {B, L, c.bert_hidden});
+        use(ctx->dt_vla);
+        if (ctx->dt_bert != ctx->dt_vla) {
+            void* e2 = alloc_t((size_t)B * L * c.bert_hidden);
+            if (!dry) ck(launch_convert(emb, ctx->dt_bert, e2, ctx->dt_vla, (size_t)B * L * c.bert_hidden, s), "bert out convert");
+            emb = e2;
+        }
 
         // Visual_Ling_Attn x2 (:198-201; models/transformer/transformer.py:251-281)
         const VlaW& v = w.vla;
@@ -328,6 +346,7 @@ struct Fwd {
         float* xh = alloc_f((size_t)B * ldx);                    // [depth | rgb | subtask | h*mask]  (seq2seq_lowlevel.py:143)
         {
             const size_t m = ar.mark();
+            use(ctx->dt_depth);
             if (w.depth_simple) {
                 simple_cnn(w.depth_s, depth, DT_F32, 1.0f, B, xh, ldx);
             } else {
@@ -338,6 +357,7 @@ struct Fwd {
         }
         {
             const size_t m = ar.mark();
+            use(ctx->dt_rgb);
             if (w.rgb_simple) {
                 simple_cnn(w.rgb_s, rgb, rgb_dt, 1.0f / 255.0f, B, xh + c.depth_out, ldx);
             } else {
@@ -348,6 +368,7 @@ struct Fwd {
             }
             ar.release(m);
         }
+        use(ctx->dt_vla);
         if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, xh, B, 32, ldx, c.depth_out + c.rgb_out, c.num_sub_tasks + 1, s), "subtask emb");
         Heads hd;
         hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;

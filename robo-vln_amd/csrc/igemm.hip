@@ -40,6 +40,11 @@ template <> struct Mma<bf16> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), acc, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -217,10 +222,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
             } else if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.y) + (size_t)m * p.ldy + n) = o;
+                T o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o4);
             }
         }
     }
@@ -260,7 +265,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.Ho = g.Ho; d.Wo = g.Wo; d.KH = g.KH; d.KW = g.KW; d.stride = g.stride; d.pad = g.pad;
     d.M = g.M; d.N = g.N; d.K = g.K; d.Kp = g.Kp ? g.Kp : g.K;
     d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32;
-    const int CH = dt == DT_BF16 ? 8 : 4;
+    const int CH = dt_chunk(dt);
     d.cin_shift = 0;
     d.kw_rcp = (65536 + g.KW - 1) / g.KW;
     if (g.KH * g.KW > 1) {
@@ -271,6 +276,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if ((g.Cin % CH) || (d.xC % CH) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
         return hipErrorInvalidValue;
     if (dt == DT_BF16) return launch_t<bf16>(d, s);
+    if (dt == DT_F16) return launch_t<f16>(d, s);
     if (dt == DT_F32) return launch_t<float>(d, s);
     return hipErrorInvalidValue;
 }

@@ -7,10 +7,11 @@
 
 namespace hcm {
 
-enum { DT_F32 = 0, DT_BF16 = 1, DT_I32 = 2, DT_I64 = 3, DT_U8 = 4 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_I32 = 2, DT_I64 = 3, DT_U8 = 4, DT_F16 = 5 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
-inline size_t dt_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+inline size_t dt_size(int dt) { return (dt == DT_BF16 || dt == DT_F16) ? 2 : 4; }
+inline int dt_chunk(int dt) { return (dt == DT_BF16 || dt == DT_F16) ? 8 : 4; }
 
 // Implicit-GEMM convolution / linear layer:  y[m][n] = act( sum_k A[m][k] * w[n][k] + bias[n] + res[m][n] )
 //   A[m][k] is gathered on the fly from the NHWC activation x: m=(b,oy,ox), k=(kh,kw,ci).
@@ -76,5 +77,7 @@ hipError_t launch_embed_rows(const float* emb, const int64_t* idx, float* y, int
 // generic converts
 hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s);
 hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s);
+// storage-type conversion between sub-networks (e.g. fp16 depth tokens -> bf16 cross-modal block)
+hipError_t launch_convert(const void* x, int dt_in, void* y, int dt_out, size_t n, hipStream_t s);
 
 }  // namespace hcm

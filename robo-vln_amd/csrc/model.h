@@ -19,8 +19,9 @@ struct HostTensor {
     bool loaded = false;
 };
 
-struct ConvW {                 // [Cout][Kp] in compute dtype, k = (kh*KW+kw)*Cin + ci
+struct ConvW {                 // [Cout][Kp] in the sub-network's storage dtype, k = (kh*KW+kw)*Cin + ci
     void* w = nullptr;
+    int dt = 0;
     float* bias = nullptr;     // f32 [Cout] or null
     int Cout = 0, Cin = 0, KH = 1, KW = 1, K = 0, Kp = 0;
 };
@@ -117,8 +118,10 @@ struct Tap { float* dev = nullptr; size_t cap = 0; size_t n = 0; Shape shape; };
 
 struct hcm_ctx {
     hcm_config cfg;
-    int dt = 0;                     // DT_F32 / DT_BF16
-    size_t esz = 4;
+    int dt = 0;                     // headline precision: DT_F32 / DT_BF16
+    // storage / MFMA input type per sub-network: in bf16 mode the GroupNorm depth trunk runs
+    // on fp16 MFMA tiles (same rate, 3 more mantissa bits), everything else on bf16
+    int dt_rgb = 0, dt_depth = 0, dt_bert = 0, dt_vla = 0;
     std::map<std::string, hcm::HostTensor> sd[2];
     bool finalized = false;
     std::vector<void*> dev_allocs;

@@ -175,7 +175,8 @@ struct Uploader {
     void* typed(const std::vector<float>& v, int dt) {
         if (dt == DT_F32) return raw(v.data(), v.size() * 4);
         std::vector<uint16_t> h(v.size());
-        for (size_t i = 0; i < v.size(); ++i) h[i] = f2bf_host(v[i]);
+        if (dt == DT_BF16) for (size_t i = 0; i < v.size(); ++i) h[i] = f2bf_host(v[i]);
+        else for (size_t i = 0; i < v.size(); ++i) { _Float16 x = (_Float16)v[i]; std::memcpy(&h[i], &x, 2); }
         return raw(h.data(), h.size() * 2);
     }
 };
@@ -189,9 +190,10 @@ static const HostTensor& T_(hcm_ctx* ctx, int model, const std::string& key) {
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // conv weight OIHW (+ optional per-channel scale) -> [O][Kp] with k = (kh*KW+kw)*I + ci
-static ConvW make_conv(hcm_ctx* ctx, Uploader& up, const HostTensor& w, const std::vector<float>* scale,
+static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vector<float>* scale,
                        const std::vector<float>* bias) {
     ConvW c;
+    c.dt = dt;
     c.Cout = (int)w.shape[0]; c.Cin = (int)w.shape[1]; c.KH = (int)w.shape[2]; c.KW = (int)w.shape[3];
     c.K = c.KH * c.KW * c.Cin;
     c.Kp = round_up(c.K, 32);
@@ -204,13 +206,13 @@ static ConvW make_conv(hcm_ctx* ctx, Uploader& up, const HostTensor& w, const st
                     r[(size_t)o * c.Kp + (size_t)(kh * c.KW + kw) * c.Cin + i] =
                         w.f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw] * sc;
     }
-    c.w = up.typed(r, ctx->dt);
+    c.w = up.typed(r, dt);
     if (bias) c.bias = up.f32(*bias);
     return c;
 }
 
 // eval-mode BatchNorm2d folded into the preceding bias-free conv: y = conv(x)*g/sqrt(v+eps) + (b - m*g/sqrt(v+eps))
-static ConvW make_conv_bn(hcm_ctx* ctx, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
+static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
     const HostTensor& w = T_(ctx, model, wkey);
     const HostTensor& g = T_(ctx, model, bn + ".weight");
     const HostTensor& b = T_(ctx, model, bn + ".bias");
@@ -223,7 +225,7 @@ static ConvW make_conv_bn(hcm_ctx* ctx, Uploader& up, int model, const std::stri
         scale[o] = s;
         bias[o] = b.f[o] - m.f[o] * s;
     }
-    return make_conv(ctx, up, w, &scale, &bias);
+    return make_conv(dt, up, w, &scale, &bias);
 }
 
 static NormW make_norm(hcm_ctx* ctx, Uploader& up, int model, const std::string& p) {
@@ -264,18 +266,19 @@ static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, 
 
 static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
+    const int dt = ctx->dt_rgb;
     t.gn = false;
     t.cin1 = 3;
-    t.conv1 = make_conv_bn(ctx, up, model, pre + "conv1.weight", pre + "bn1");
+    t.conv1 = make_conv_bn(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
             const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
             BottleneckW b;
             b.stride = (li > 0 && bi == 0) ? 2 : 1;
-            b.c1 = make_conv_bn(ctx, up, model, p + "conv1.weight", p + "bn1");
-            b.c2 = make_conv_bn(ctx, up, model, p + "conv2.weight", p + "bn2");
-            b.c3 = make_conv_bn(ctx, up, model, p + "conv3.weight", p + "bn3");
-            if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn(ctx, up, model, p + "downsample.0.weight", p + "downsample.1"); }
+            b.c1 = make_conv_bn(ctx, dt, up, model, p + "conv1.weight", p + "bn1");
+            b.c2 = make_conv_bn(ctx, dt, up, model, p + "conv2.weight", p + "bn2");
+            b.c3 = make_conv_bn(ctx, dt, up, model, p + "conv3.weight", p + "bn3");
+            if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn(ctx, dt, up, model, p + "downsample.0.weight", p + "downsample.1"); }
             t.blocks.push_back(b);
         }
     t.out_c = 2048;
@@ -284,45 +287,46 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
 
 static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
+    const int dt = ctx->dt_depth;
     t.gn = true;
     t.groups = ctx->cfg.depth_baseplanes / 2;          // resnet_encoders.py:30
     t.cin1 = 1;
     const std::string bb = pre + "backbone.";
-    t.conv1 = make_conv(ctx, up, T_(ctx, model, bb + "conv1.0.weight"), nullptr, nullptr);
+    t.conv1 = make_conv(dt, up, T_(ctx, model, bb + "conv1.0.weight"), nullptr, nullptr);
     t.n_conv1 = make_norm(ctx, up, model, bb + "conv1.1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
             const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
             BottleneckW b;
             b.stride = (li > 0 && bi == 0) ? 2 : 1;
-            b.c1 = make_conv(ctx, up, T_(ctx, model, p + "convs.0.weight"), nullptr, nullptr); b.n1 = make_norm(ctx, up, model, p + "convs.1");
-            b.c2 = make_conv(ctx, up, T_(ctx, model, p + "convs.3.weight"), nullptr, nullptr); b.n2 = make_norm(ctx, up, model, p + "convs.4");
-            b.c3 = make_conv(ctx, up, T_(ctx, model, p + "convs.6.weight"), nullptr, nullptr); b.n3 = make_norm(ctx, up, model, p + "convs.7");
+            b.c1 = make_conv(dt, up, T_(ctx, model, p + "convs.0.weight"), nullptr, nullptr); b.n1 = make_norm(ctx, up, model, p + "convs.1");
+            b.c2 = make_conv(dt, up, T_(ctx, model, p + "convs.3.weight"), nullptr, nullptr); b.n2 = make_norm(ctx, up, model, p + "convs.4");
+            b.c3 = make_conv(dt, up, T_(ctx, model, p + "convs.6.weight"), nullptr, nullptr); b.n3 = make_norm(ctx, up, model, p + "convs.7");
             if (bi == 0) {
                 b.has_ds = true;
-                b.ds = make_conv(ctx, up, T_(ctx, model, p + "downsample.0.weight"), nullptr, nullptr);
+                b.ds = make_conv(dt, up, T_(ctx, model, p + "downsample.0.weight"), nullptr, nullptr);
                 b.nds = make_norm(ctx, up, model, p + "downsample.1");
             }
             t.blocks.push_back(b);
         }
-    t.compress = make_conv(ctx, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr);
+    t.compress = make_conv(dt, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr);
     t.n_compress = make_norm(ctx, up, model, pre + "compression.1");
     t.out_c = t.compress.Cout;
     return t;
 }
 
-static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre, int cin, int hw) {
+static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& pre, int cin, int hw) {
     SimpleCnnW s;
     s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
-    s.c0 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.0.weight"), nullptr, &T_(ctx, model, pre + "cnn.0.bias").f);
-    s.c1 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
-    s.c2 = make_conv(ctx, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
+    s.c0 = make_conv(dt, up, T_(ctx, model, pre + "cnn.0.weight"), nullptr, &T_(ctx, model, pre + "cnn.0.bias").f);
+    s.c1 = make_conv(dt, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
+    s.c2 = make_conv(dt, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
     // Flatten() of the NCHW (B,32,h,w) tensor: source column c*S + s; ours is NHWC: s*32 + c
     const int S = s.h3 * s.h3;
     std::vector<int> perm((size_t)S * 32);
     for (int sp = 0; sp < S; ++sp)
         for (int c = 0; c < 32; ++c) perm[(size_t)sp * 32 + c] = c * S + sp;
-    s.fc = make_linear(up, {&T_(ctx, model, pre + "cnn.7.weight")}, {&T_(ctx, model, pre + "cnn.7.bias")}, ctx->dt, &perm);
+    s.fc = make_linear(up, {&T_(ctx, model, pre + "cnn.7.weight")}, {&T_(ctx, model, pre + "cnn.7.bias")}, dt, &perm);
     return s;
 }
 
@@ -390,41 +394,41 @@ void prepare_high(hcm_ctx* ctx) {
         const std::string p = "embedding_layer.encoder.layer." + std::to_string(i) + ".";
         BertLayerW L;
         L.qkv = make_linear(up, {&T_(ctx, M, p + "attention.self.query.weight"), &T_(ctx, M, p + "attention.self.key.weight"), &T_(ctx, M, p + "attention.self.value.weight")},
-                            {&T_(ctx, M, p + "attention.self.query.bias"), &T_(ctx, M, p + "attention.self.key.bias"), &T_(ctx, M, p + "attention.self.value.bias")}, ctx->dt);
-        L.o = make_linear(up, {&T_(ctx, M, p + "attention.output.dense.weight")}, {&T_(ctx, M, p + "attention.output.dense.bias")}, ctx->dt);
+                            {&T_(ctx, M, p + "attention.self.query.bias"), &T_(ctx, M, p + "attention.self.key.bias"), &T_(ctx, M, p + "attention.self.value.bias")}, ctx->dt_bert);
+        L.o = make_linear(up, {&T_(ctx, M, p + "attention.output.dense.weight")}, {&T_(ctx, M, p + "attention.output.dense.bias")}, ctx->dt_bert);
         L.ln1 = make_norm(ctx, up, M, p + "attention.output.LayerNorm");
-        L.ff1 = make_linear(up, {&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, ctx->dt);
-        L.ff2 = make_linear(up, {&T_(ctx, M, p + "output.dense.weight")}, {&T_(ctx, M, p + "output.dense.bias")}, ctx->dt);
+        L.ff1 = make_linear(up, {&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, ctx->dt_bert);
+        L.ff2 = make_linear(up, {&T_(ctx, M, p + "output.dense.weight")}, {&T_(ctx, M, p + "output.dense.bias")}, ctx->dt_bert);
         L.ln2 = make_norm(ctx, up, M, p + "output.LayerNorm");
         h.bert.layers.push_back(L);
     }
     // Conv1d(k=1) weights (out,in,1) are linear layers over the token axis
-    h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt);
-    h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt);
-    h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt);
+    h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
+    h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla);
+    h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
     {
         // depth_linear: Flatten of (B, dC, S) -> column c*S + s; ours [B][S][dC] -> s*dC + c
         const int S = h.depth_S, dC = h.depth_C;
         std::vector<int> perm((size_t)S * dC);
         for (int s = 0; s < S; ++s)
             for (int ch = 0; ch < dC; ++ch) perm[(size_t)s * dC + ch] = ch * S + s;
-        h.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt, &perm);
+        h.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt_vla, &perm);
     }
     // Visual_Ling_Attn
     VlaW& v = h.vla;
-    v.vis_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.vis_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.vis_fc.bias")}, ctx->dt);
-    v.ins_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.ins_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.ins_fc.bias")}, ctx->dt);
+    v.vis_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.vis_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.vis_fc.bias")}, ctx->dt_vla);
+    v.ins_fc = make_linear(up, {&T_(ctx, M, "image_cm_encoder.ins_fc.weight")}, {&T_(ctx, M, "image_cm_encoder.ins_fc.bias")}, ctx->dt_vla);
     v.ln = make_norm(ctx, up, M, "image_cm_encoder.layer_norm");
     for (int i = 0; i < c.vla_layers; ++i) {
         const std::string p = "image_cm_encoder.layers." + std::to_string(i) + ".";
         const std::string a = p + "enc_att.attention.";
         VlaLayerW L;
-        L.q = make_linear(up, {&T_(ctx, M, a + "fc_q.weight")}, {&T_(ctx, M, a + "fc_q.bias")}, ctx->dt);
-        L.kv = make_linear(up, {&T_(ctx, M, a + "fc_k.weight"), &T_(ctx, M, a + "fc_v.weight")}, {&T_(ctx, M, a + "fc_k.bias"), &T_(ctx, M, a + "fc_v.bias")}, ctx->dt);
-        L.o = make_linear(up, {&T_(ctx, M, a + "fc_o.weight")}, {&T_(ctx, M, a + "fc_o.bias")}, ctx->dt);
+        L.q = make_linear(up, {&T_(ctx, M, a + "fc_q.weight")}, {&T_(ctx, M, a + "fc_q.bias")}, ctx->dt_vla);
+        L.kv = make_linear(up, {&T_(ctx, M, a + "fc_k.weight"), &T_(ctx, M, a + "fc_v.weight")}, {&T_(ctx, M, a + "fc_k.bias"), &T_(ctx, M, a + "fc_v.bias")}, ctx->dt_vla);
+        L.o = make_linear(up, {&T_(ctx, M, a + "fc_o.weight")}, {&T_(ctx, M, a + "fc_o.bias")}, ctx->dt_vla);
         L.ln_att = make_norm(ctx, up, M, p + "enc_att.layer_norm");
-        L.ff1 = make_linear(up, {&T_(ctx, M, p + "pwff.fc1.weight")}, {&T_(ctx, M, p + "pwff.fc1.bias")}, ctx->dt);
-        L.ff2 = make_linear(up, {&T_(ctx, M, p + "pwff.fc2.weight")}, {&T_(ctx, M, p + "pwff.fc2.bias")}, ctx->dt);
+        L.ff1 = make_linear(up, {&T_(ctx, M, p + "pwff.fc1.weight")}, {&T_(ctx, M, p + "pwff.fc1.bias")}, ctx->dt_vla);
+        L.ff2 = make_linear(up, {&T_(ctx, M, p + "pwff.fc2.weight")}, {&T_(ctx, M, p + "pwff.fc2.bias")}, ctx->dt_vla);
         L.ln_ff = make_norm(ctx, up, M, p + "pwff.layer_norm");
         v.layers.push_back(L);
     }
@@ -460,15 +464,15 @@ void prepare_low(hcm_ctx* ctx) {
         std::vector<int> perm((size_t)S * cc);
         for (int s = 0; s < S; ++s)
             for (int ch = 0; ch < cc; ++ch) perm[(size_t)s * cc + ch] = ch * S + s;
-        l.depth_fc = make_linear(up, {&T_(ctx, M, "depth_encoder.visual_fc.1.weight")}, {&T_(ctx, M, "depth_encoder.visual_fc.1.bias")}, ctx->dt, &perm);
+        l.depth_fc = make_linear(up, {&T_(ctx, M, "depth_encoder.visual_fc.1.weight")}, {&T_(ctx, M, "depth_encoder.visual_fc.1.bias")}, ctx->dt_depth, &perm);
     } else {
-        l.depth_s = make_simple_cnn(ctx, up, M, "depth_encoder.", 1, c.depth_h);
+        l.depth_s = make_simple_cnn(ctx, ctx->dt_depth, up, M, "depth_encoder.", 1, c.depth_h);
     }
     if (!l.rgb_simple) {
         l.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
-        l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt);
+        l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt_rgb);
     } else {
-        l.rgb_s = make_simple_cnn(ctx, up, M, "rgb_encoder.", 3, c.rgb_h);
+        l.rgb_s = make_simple_cnn(ctx, ctx->dt_rgb, up, M, "rgb_encoder.", 3, c.rgb_h);
     }
     l.subtask_emb = up.f32(T_(ctx, M, "sub_task_embedding.weight").f);
     l.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");

@@ -17,8 +17,14 @@ from .config import HCMConfig
 _TORCH_DT = {torch.float32: _lib.HCM_F32, torch.uint8: _lib.HCM_U8, torch.int32: _lib.HCM_I32, torch.int64: _lib.HCM_I64}
 
 
-def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low):
+_SUB_SLOTS = {"depth": 0, "bert": 1, "vla": 2, "rgb": 3}
+_SUB_DT = {"fp32": _lib.HCM_F32, "bf16": _lib.HCM_BF16, "fp16": _lib.HCM_F16}
+
+
+def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None):
     s = _lib.HcmConfigStruct()
+    for name, p in (sub_precision or {}).items():
+        s.reserved[_SUB_SLOTS[name]] = _SUB_DT[p] + 1
     s.struct_size = C.sizeof(_lib.HcmConfigStruct)
     s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
     s.max_batch = max_batch
@@ -54,7 +60,10 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="bf16", device=None):
+                 precision="bf16", device=None, sub_precision=None):
+        """precision: "bf16" (16-bit storage + MFMA with fp32 accumulate; by default the GroupNorm depth trunk uses
+        fp16 tiles and everything else bf16, recurrent cells/heads fp32) or "fp32".  `sub_precision` overrides the
+        storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb)."""
         cfg.validate()
         self.cfg = cfg
         self.max_batch = max_batch
@@ -65,7 +74,7 @@ class HCMEngine:
         self.has_high = high_level_state_dict is not None
         self.has_low = low_level_state_dict is not None
         with torch.cuda.device(self.device):
-            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low)
+            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision)
             _lib.check(self._lib.hcm_create(C.byref(st), C.byref(self._h)))
             try:
                 # load_state_dict(strict=True) semantics (hierarchical_trainer.py:343-345)

@@ -1,0 +1,71 @@
+"""Rollout-side glue of the hot path: the per-step state handling of the reference's eval loop
+(robo_vln_baselines/hierarchical_trainer.py:1052-1068 state init, :1095-1101 hi->argmax->lo,
+:1103 masks to ones, :1143-1159 reset on episode end) for a batch of environments, and the
+environment-sharded data-parallel variant: env e lives on rank e // (B/world), each rank
+holds a full weight replica and its own recurrent state, and the only data-path collective is ONE
+all-gather of the (B/world, 7) action records per step (RCCL over xGMI on GPU; gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+RECORD_WIDTH = 7    # [4 sub-task logits, lin_vel, ang_vel, stop logit]
+
+
+def shard_range(global_batch: int, world: int, rank: int):
+    """Contiguous block of environments owned by `rank`."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def gather_records(local_rec: torch.Tensor, out: torch.Tensor):
+    """out[(world*B_local), 7] <- all ranks' (B_local, 7) records, rank-major == environment order."""
+    dist.all_gather_into_tensor(out, local_rec.contiguous())
+    return out
+
+
+def records_to_actions(rec: torch.Tensor):
+    """What the eval loop derives from a step's outputs: sub-task id (argmax, :1098), the velocity command
+    with the angular component clipped to [-1, 1] (:1104-1107), and stop = round(sigmoid(stop_logit)) (:1111)."""
+    subtask = torch.argmax(rec[:, :4], dim=1)
+    lin = rec[:, 4]
+    ang = rec[:, 5].clamp(-1.0, 1.0)
+    stop = torch.round(torch.sigmoid(rec[:, 6]))
+    return subtask, lin, ang, stop
+
+
+class RolloutState:
+    """Recurrent state + masks for the environments owned by this rank."""
+
+    def __init__(self, num_envs, num_recurrent_layers, hidden, device):
+        self.hi_hidden = torch.zeros(num_recurrent_layers, num_envs, hidden, device=device)   # :1052-1057
+        self.lo_hidden = torch.zeros(num_recurrent_layers, num_envs, hidden, device=device)   # :1058-1063
+        self.masks = torch.zeros(num_envs, device=device)                                     # :1068 (column 0)
+
+    def after_step(self, hi_hidden, lo_hidden, dones):
+        """`dones` (B,) bool: environments whose episode ended in this step get mask 0 for the next one, which
+        zeroes their h and c inside the state encoder (the reference additionally zeroes the tensors, :1143-1159;
+        the product with mask 0 is the same value)."""
+        self.hi_hidden, self.lo_hidden = hi_hidden, lo_hidden
+        self.masks = (~dones.to(self.masks.device)).to(self.masks.dtype)                      # :1103 / :1147
+
+
+def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidden, device, world=1, rank=0):
+    """Drive `policy.act` for `steps` steps over this rank's environments.
+    obs_fn(t, lo, hi) -> observations dict for global envs [lo, hi); done_fn(t, lo, hi) -> (hi-lo,) bool.
+    Returns the (steps, global_envs, 7) records (gathered when world > 1)."""
+    global_envs = num_envs * world
+    lo, hi = shard_range(global_envs, world, rank)
+    st = RolloutState(num_envs, num_recurrent_layers, hidden, device)
+    out = []
+    for t in range(steps):
+        rec, hh, lh = policy.act(obs_fn(t, lo, hi), st.hi_hidden, st.lo_hidden, None, st.masks)
+        if world > 1:
+            full = torch.empty(global_envs, RECORD_WIDTH, device=rec.device, dtype=rec.dtype)
+            gather_records(rec, full)
+        else:
+            full = rec
+        out.append(full.clone())
+        st.after_step(hh, lh, done_fn(t, lo, hi))
+    return torch.stack(out)

@@ -7,10 +7,10 @@ from robo_vln_amd import synth
 from robo_vln_amd.policy import HCMEngine
 
 
-def build_engine(cfg, which, precision, max_batch):
+def build_engine(cfg, which, precision, max_batch, sub_precision=None):
     hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED) if which in ("both", "hi") else None
     lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED) if which in ("both", "lo") else None
-    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=max_batch, precision=precision)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=max_batch, precision=precision, sub_precision=sub_precision)
     return eng, hi_sd, lo_sd
 
 
@@ -22,10 +22,12 @@ def _cmp(a, b):
     return float(d.max()), float(d.mean()), float(np.abs(b).max())
 
 
-def run_case(name, precision, taps=True, rgb_uint8=False):
+def run_case(name, precision, taps=True, rgb_uint8=False, sub_precision=None, batch=None):
     """Returns dict: per-step record errors vs oracle and vs the committed golden, per-tap errors (step 0)."""
     cfg, B, T, which = cases.case_config(name)
-    eng, hi_sd, lo_sd = build_engine(cfg, which, precision, B)
+    if batch is not None:
+        B = batch
+    eng, hi_sd, lo_sd = build_engine(cfg, which, precision, B, sub_precision)
     hi_o = hcm_oracle.HighLevelOracle(cfg, hi_sd) if hi_sd is not None else None
     lo_o = hcm_oracle.LowLevelOracle(cfg, lo_sd) if lo_sd is not None else None
     R = cfg.num_recurrent_layers

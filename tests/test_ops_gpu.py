@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DT = {"fp32": (0, torch.float32, 2e-4), "bf16": (1, torch.bfloat16, 2e-2)}
+DT = {"fp32": (0, torch.float32, 2e-4), "bf16": (1, torch.bfloat16, 2e-2), "fp16": (5, torch.float16, 3e-3)}
 
 
 def _lib():
@@ -26,7 +26,7 @@ def _rnd(*shape, scale=1.0, seed=0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [
     # B, H, W, Cin, Cout, K, stride, pad
     (2, 16, 16, 64, 64, 1, 1, 0),
@@ -68,7 +68,7 @@ def test_conv2d(prec, shape, epi):
     assert err <= tol * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("mnk", [(5, 4, 512), (64, 2048, 1408), (160, 768, 768), (1000, 3072, 768), (333, 256, 2112), (40, 128, 3072), (7, 1536, 416)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_linear(prec, mnk, act):
@@ -92,7 +92,7 @@ def test_linear(prec, mnk, act):
         assert err <= (tol if not out_f32 or prec == "fp32" else 2e-3) * max(1.0, ref.abs().max().item()), (err, out_f32)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(2, 12, 80, 80), (3, 4, 80, 16), (1, 4, 20, 4), (2, 12, 160, 160), (2, 4, 160, 160), (1, 12, 7, 7)])
 def test_attention(prec, cfg):
     lib, L = _lib()
@@ -116,7 +116,7 @@ def test_attention(prec, cfg):
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("D", [768, 256])
 def test_layernorm(prec, D):
     lib, L = _lib()
@@ -136,8 +136,8 @@ def test_layernorm(prec, D):
     assert err <= tol * 3, err
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg", [(2, 32, 32, 32, 16), (3, 16, 16, 256, 16), (2, 4, 4, 1024, 16), (2, 4, 4, 128, 1), (1, 64, 64, 32, 16)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 32, 16), (3, 16, 16, 256, 16), (2, 4, 4, 1024, 16), (2, 4, 4, 128, 1), (1, 64, 64, 32, 16), (2, 2, 2, 512, 1), (2, 8, 8, 512, 16), (1, 32, 32, 128, 16)])
 def test_groupnorm(prec, cfg):
     lib, L = _lib()
     code, tdt, tol = DT[prec]
@@ -157,7 +157,7 @@ def test_groupnorm(prec, cfg):
     assert err <= tol * 3, err
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_maxpool(prec):
     lib, L = _lib()
     code, tdt, tol = DT[prec]
