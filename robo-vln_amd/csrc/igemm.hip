@@ -19,6 +19,7 @@
 //
 // Reference ops replaced: cuDNN conv fwd + BatchNorm(eval) + ReLU of torchvision resnet50, the GN-ResNet
 // convs, and every nn.Linear / Conv1d(k=1) on the path.
+#include <cstdlib>
 #include "kernels.h"
 #include "dev.h"
 
@@ -191,41 +192,104 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels n..n+3 of pixel m ----
+    // ---- epilogue ----
+    // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
+    // output tile (the A/B tiles are dead: the K loop ended with a barrier).  Phase 2: each thread takes 8
+    // consecutive channels of a row, applies bias + residual + activation in f32, rounds once, and stores 16 B --
+    // a row of the tile leaves as one contiguous BN*sizeof(T)-byte run (the accumulator layout alone would store
+    // 32-byte fragments).  Row stride BN+4 floats keeps the ds_write_b128 of phase 1 conflict free.
+    constexpr int LDC = BN + 4;
+    float* sc = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * (BM / 2) + j * 16 + fr;
-        if (m >= p.M) continue;
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * (BN / 2) + i * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (p.res) {
-                const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
+            const int r = wm * (BM / 2) + j * 16 + fr;
+            const int cc = wn * (BN / 2) + i * 16 + fg * 4;
+            *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 8;            // threads per tile row
+    constexpr int RPP = 256 / TPR;         // rows per pass
+    const int c8 = (tid % TPR) * 8;
+    const int n = n0 + c8;
+    if (n >= p.N) return;
+    const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        if (hi_ok) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+    }
+    const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
+    const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += Tr<T>::ld(rp + e);
-            }
-            if (p.act == ACT_RELU) {
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int r = pass * RPP + tid / TPR;
+        const int m = m0 + r;
+        if (m >= p.M) continue;
+        float v[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(sc + r * LDC + c8);
+            const float4 a1 = *reinterpret_cast<const float4*>(sc + r * LDC + c8 + 4);
+            v[0] = a0.x + bias8[0]; v[1] = a0.y + bias8[1]; v[2] = a0.z + bias8[2]; v[3] = a0.w + bias8[3];
+            v[4] = a1.x + bias8[4]; v[5] = a1.y + bias8[5]; v[6] = a1.z + bias8[6]; v[7] = a1.w + bias8[7];
+        }
+        if (p.res) {
+            const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
+            if constexpr (sizeof(T) == 2) {
+                if (wide16r) {
+                    float rr[8];
+                    ld_chunk(rp, rr);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == ACT_GELU) {
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
-            if (p.out_f32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    for (int e = 0; e < 4; ++e) v[e] += Tr<T>::ld(rp + e);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 4; e < 8; ++e) v[e] += Tr<T>::ld(rp + e);
+                    }
+                }
             } else {
-                T o4[4];
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (hi_ok) {
+                    const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+            }
+        }
+        if (p.act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o4);
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.out_f32 || sizeof(T) == 4) {
+            float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (hi_ok) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            if constexpr (sizeof(T) == 2) {
+                T* yp = reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n;
+                if (wide16) {
+                    st_chunk(yp, v);
+                } else {
+                    T o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<const uint2*>(o4);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[4 + e]);
+                        *reinterpret_cast<uint2*>(yp + 4) = *reinterpret_cast<const uint2*>(o4);
+                    }
+                }
             }
         }
     }
@@ -237,13 +301,39 @@ static hipError_t launch_cfg(IGemmDev d, hipStream_t s) {
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
     const int grid = tm8 * 8 * d.tilesN;
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
+    if (lds_c > lds) lds = lds_c;
+    if (lds > 64 * 1024) {
+        static bool attr_done = false;                        // one flag per template instantiation
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+    }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
     return hipGetLastError();
 }
 
 template <typename T>
+static hipError_t launch_forced(const IGemmDev& d, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch_cfg<T, 128, 128>(d, s);
+        case 1: return launch_cfg<T, 128, 64>(d, s);
+        case 2: return launch_cfg<T, 64, 64>(d, s);
+        case 3: return launch_cfg<T, 64, 32>(d, s);
+        case 4: return launch_cfg<T, 128, 32>(d, s);
+        case 5: return launch_cfg<T, 64, 128>(d, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
 static hipError_t launch_t(const IGemmDev& d, hipStream_t s) {
+    static const char* force = getenv("HCM_IGEMM_FORCE");
+    if (force) return launch_forced<T>(d, atoi(force), s);
     // tile choice: largest tile that still gives the 256 CUs at least ~2 workgroups each
     const long blocks128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
     const long blocks12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);

@@ -19,7 +19,8 @@ def _cmp(a, b):
     b = np.asarray(b, dtype=np.float32)
     assert a.shape == b.shape, (a.shape, b.shape)
     d = np.abs(a - b)
-    return float(d.max()), float(d.mean()), float(np.abs(b).max())
+    rel = float(np.linalg.norm((a - b).ravel()) / max(1e-30, np.linalg.norm(b.ravel())))
+    return float(d.max()), float(d.mean()), float(np.abs(b).max()), rel
 
 
 def run_case(name, precision, taps=True, rgb_uint8=False, sub_precision=None, batch=None):
@@ -96,9 +97,9 @@ def run_case(name, precision, taps=True, rgb_uint8=False, sub_precision=None, ba
 
 def format_report(rep):
     lines = [f"== {rep['case']} [{rep['precision']}]"]
-    for k, (mx, mean, ref) in rep["taps"].items():
-        lines.append(f"   tap {k:18s} max_abs {mx:.3e} mean_abs {mean:.3e} |ref|max {ref:.3f}")
+    for k, (mx, mean, ref, rel) in rep["taps"].items():
+        lines.append(f"   tap {k:18s} max_abs {mx:.3e} mean_abs {mean:.3e} |ref|max {ref:.3f} rel_l2 {rel:.3e}")
     for s in rep["steps"]:
         lines.append(f"   step {s['t']} record max_abs {s['max_abs']:.3e} mean {s['mean_abs']:.3e} same_branch {s['same_branch']}")
-    lines.append(f"   hi_hidden max_abs {rep['hi_hidden'][0]:.3e}  lo_hidden max_abs {rep['lo_hidden'][0]:.3e}")
+    lines.append(f"   hi_hidden max_abs {rep['hi_hidden'][0]:.3e} rel_l2 {rep['hi_hidden'][3]:.3e}  lo_hidden max_abs {rep['lo_hidden'][0]:.3e} rel_l2 {rep['lo_hidden'][3]:.3e}")
     return "\n".join(lines)

@@ -21,8 +21,9 @@ def _check(name, precision, **kw):
     tol = TOL[precision]
     for s in rep["steps"]:
         assert s["max_abs"] <= tol, f"{name}[{precision}] step {s['t']}: record max-abs {s['max_abs']:.3e} > {tol}"
-    assert rep["hi_hidden"][0] <= max(tol, 1e-2 * rep["hi_hidden"][2])
-    assert rep["lo_hidden"][0] <= max(tol, 1e-2 * rep["lo_hidden"][2])
+    # hidden states: relative (l2) error <= 1e-2; an all-zero reference (model absent) compares exactly
+    for key in ("hi_hidden", "lo_hidden"):
+        assert rep[key][3] <= 1e-2 or rep[key][0] == 0.0, (key, rep[key])
     # golden vectors from the imported reference (valid whenever the hi branch choice agreed with the oracle)
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     if all(s["same_branch"] for s in rep["steps"]):
@@ -39,6 +40,19 @@ def test_fp32_path_matches_oracle(name):
 @pytest.mark.parametrize("name", ["cfg0_128_L20_N2", "gru_128_L20", "lo_simplecnn_256", "native_224_256", "cfg4_L160_N6", "cfg1_256_L80_N1"])
 def test_bf16_path_matches_oracle(name):
     _check(name, "bf16")
+
+
+def test_baseline_config2_batch64_bf16():
+    """BASELINE.json configs[1]: batch=64, 256x256 RGB-D, 80-token instruction, full HCM model, 16-bit path on one
+    MI355X -- parity vs the CPU oracle within 1e-2 on the (B,7) record over consecutive steps."""
+    from tests import parity_util
+    import torch
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rep = parity_util.run_case("cfg1_256_L80_N1", "bf16", taps=False, batch=64)
+    print(parity_util.format_report(rep))
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-2, s
+    assert rep["records"].shape == (2, 64, 7)
 
 
 def test_uint8_rgb_equals_float_rgb():
