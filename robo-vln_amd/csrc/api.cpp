@@ -1,4 +1,5 @@
 // C ABI of libhcm (include/hcm.h).
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -10,10 +11,9 @@ void build_spec_high(hcm_ctx* ctx);
 void build_spec_low(hcm_ctx* ctx);
 void prepare_high(hcm_ctx* ctx);
 void prepare_low(hcm_ctx* ctx);
-void run_high(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
-              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out);
-void run_low(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
-             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out);
+void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
+              int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
+              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out);
 }  // namespace hcm
 
 using namespace hcm;
@@ -126,8 +126,8 @@ int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, 
 static void dry_run(hcm_ctx* h, int B) {
     h->arena.dry = true;
     h->arena.peak = 0;
-    if (h->cfg.build_high) run_high(h, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr, 0, nullptr);
-    if (h->cfg.build_low) run_low(h, nullptr, DT_F32, nullptr, B, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
+    run_step(h, h->cfg.build_high != 0, h->cfg.build_low != 0, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr,
+             nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr);
 }
 
 int hcm_finalize(hcm_handle h) {
@@ -146,6 +146,12 @@ int hcm_finalize(hcm_handle h) {
         if (hipMalloc((void**)&h->pred_buf, (size_t)h->cfg.max_batch * sizeof(int64_t)) != hipSuccess)
             return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
         h->arena.dry = false;
+        for (int i = 0; i < 3; ++i) {
+            if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
+            if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
+        }
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
+        if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, std::string("hcm_finalize: ") + e.what());
     }
@@ -175,7 +181,8 @@ int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* 
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     h->stream = (hipStream_t)stream;
     try {
-        run_high(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, logits, h->cfg.num_actions, h_out);
+        run_step(h, true, false, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, nullptr, mask, nullptr, logits, h->cfg.num_actions,
+                 nullptr, 0, nullptr, 0, h_out, nullptr);
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, e.what());
     }
@@ -191,7 +198,8 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
     REQUIRE(rgb_dt_ok(rgb_dtype), HCM_ERR_ARG, "unsupported rgb dtype");
     h->stream = (hipStream_t)stream;
     try {
-        run_low(h, rgb, rgb_dtype, depth, B, h_in, mask, subtask, vel, h->cfg.lo_actions, stop, 1, h_out);
+        run_step(h, false, true, rgb, rgb_dtype, depth, nullptr, DT_I64, B, nullptr, h_in, mask, subtask, nullptr, 0, vel,
+                 h->cfg.lo_actions, stop, 1, nullptr, h_out);
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, e.what());
     }
@@ -210,11 +218,8 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, co
     h->stream = (hipStream_t)stream;
     try {
         const int ld = 7;
-        run_high(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, mask, record, ld, hi_h_out);
-        // pred = argmax(output, dim=1)  (hierarchical_trainer.py:1098)
-        if (launch_argmax(record, h->pred_buf, B, h->cfg.num_actions, ld, h->stream) != hipSuccess)
-            return fail(h, HCM_ERR_HIP, "argmax launch failed");
-        run_low(h, rgb, rgb_dtype, depth, B, lo_h_in, mask, h->pred_buf, record + 4, ld, record + 6, ld, lo_h_out);
+        run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
+                 record + 6, ld, hi_h_out, lo_h_out);
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, e.what());
     }
@@ -244,6 +249,11 @@ void hcm_destroy(hcm_handle h) {
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (int i = 0; i < 3; ++i) {
+        if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
 }
 

@@ -228,6 +228,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int HW, int C, int G, int CS, float eps, int relu) {
     constexpr int CH = Tr<T>::CH;
+    __shared__ float s_p1[4][1024], s_p2[4][1024];                         // per-wave partials (fixed summation order)
     __shared__ float s_sum[1024], s_sq[1024], s_mean[1024], s_rstd[1024];  // per channel of the slab (CS <= 1024)
     const int slabs = C / CS;
     const int b = blockIdx.x / slabs;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
     const int pstep = 256 / cpr;
     T* xb = x + (size_t)b * HW * C + c_base + cc * CH;
     const T* rb = res ? res + (size_t)b * HW * C + c_base + cc * CH : nullptr;
-    for (int i = tid; i < CS; i += 256) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
+    for (int i = tid; i < 4 * 1024; i += 256) { (&s_p1[0][0])[i] = 0.f; (&s_p2[0][0])[i] = 0.f; }
     __syncthreads();
     float s1[CH], s2[CH];
 #pragma unroll
@@ -257,8 +258,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
         for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
     }
     if ((tid & 63) < cpr) {
+        const int wv = tid >> 6;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { atomicAdd(&s_sum[cc * CH + j], s1[j]); atomicAdd(&s_sq[cc * CH + j], s2[j]); }
+        for (int j = 0; j < CH; ++j) { s_p1[wv][cc * CH + j] = s1[j]; s_p2[wv][cc * CH + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int ch = tid; ch < CS; ch += 256) {
+        s_sum[ch] = (s_p1[0][ch] + s_p1[1][ch]) + (s_p1[2][ch] + s_p1[3][ch]);
+        s_sq[ch] = (s_p2[0][ch] + s_p2[1][ch]) + (s_p2[2][ch] + s_p2[3][ch]);
     }
     __syncthreads();
     for (int ch = tid; ch < CS; ch += 256) {

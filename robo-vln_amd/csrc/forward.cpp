@@ -174,10 +174,9 @@ struct Fwd {
     }
 
     // ---------------------------------------------------------------- BERT encoder
-    void* bert(const BertW& w, const void* ids, int ids_dt, int B) {
+    void bert(const BertW& w, const void* ids, int ids_dt, int B, void* x) {
         const hcm_config& c = ctx->cfg;
         const int L = c.instr_len, D = c.bert_hidden, rows = B * L;
-        void* x = alloc_t((size_t)rows * D);
         void* qkv = alloc_t((size_t)rows * 3 * D);
         void* ctxb = alloc_t((size_t)rows * D);
         void* tmp = alloc_t((size_t)rows * D);
@@ -197,7 +196,6 @@ struct Fwd {
             if (li == 0) tap("hi.bert_l0", x, true, {B, L, D});
             ++li;
         }
-        return x;
     }
 
     // ---------------------------------------------------------------- recurrent step + heads
@@ -217,60 +215,87 @@ struct Fwd {
         }
     }
 
-    // ---------------------------------------------------------------- Seq2Seq_HighLevel_CMA.forward
-    void high(const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
-              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
+    // ---------------------------------------------------------------- stages of Seq2Seq_HighLevel_CMA.forward
+    struct HiBufs {
+        void* rgb_tok = nullptr;   // (B,2112,16) of the reference, token-major [B][16][2112]      (dt_vla)
+        void* dep_tok = nullptr;   // [B][S][dC]                                                    (dt_vla)
+        void* emb = nullptr;       // BERT last hidden state [B][L][768]                            (dt_bert)
+        float* xh = nullptr;       // [rgb_in | depth_in | ins_rgb | ins_depth | h*mask]  f32
+        int ldx = 0;
+    };
+    struct LoBufs { float* xh = nullptr; int ldx = 0; };   // [depth | rgb | subtask | h*mask] (seq2seq_lowlevel.py:143)
+
+    HiBufs hi_alloc(int B) {
         const hcm_config& c = ctx->cfg;
         const HighW& w = ctx->hi;
-        const int L = c.instr_len, d = c.d_model, H = c.hidden;
-        const int rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
-        const int in = w.rnn.in, ldx = in + H;
-        ar.reset();
+        HiBufs b;
         use(ctx->dt_vla);
-        // persistent (whole-forward) buffers first
-        void* rgb_tok = alloc_t((size_t)B * 16 * rC);            // (B,2112,16) of the reference, token-major
-        void* dep_tok = alloc_t((size_t)B * dS * dC);
-        float* xh = alloc_f((size_t)B * ldx);                    // [rgb_in | depth_in | ins_rgb | ins_depth | h*mask]
-
-        {   // depth_encoder (seq2seq_highlevel_cma.py:178-179): GN-ResNet50 + pos-emb channels
-            const size_t m = ar.mark();
-            use(ctx->dt_depth);
-            Act o = depth_trunk(w.depth, depth, B, "hi.depth");
-            void* tok = ctx->dt_depth == ctx->dt_vla ? dep_tok : alloc_t((size_t)B * dS * dC);
-            if (!dry) {
-                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
-                ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
-                if (tok != dep_tok) ck(launch_convert(tok, ctx->dt_depth, dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
-            }
-            ar.release(m);
-        }
-        {   // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels
-            const size_t m = ar.mark();
-            use(ctx->dt_rgb);
-            Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "hi.rgb");
-            void* tok = ctx->dt_rgb == ctx->dt_vla ? rgb_tok : alloc_t((size_t)B * 16 * rC);
-            if (!dry) {
-                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
-                ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
-                if (tok != rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
-            }
-            ar.release(m);
-        }
-        use(ctx->dt_vla);
-        tap("hi.depth_spatial", dep_tok, true, {B, dS, dC});
-        tap("hi.rgb_spatial", rgb_tok, true, {B, 16, rC});
-
-        // BERT (:189-195)
+        b.rgb_tok = alloc_t((size_t)B * 16 * (2048 + 64));
+        b.dep_tok = alloc_t((size_t)B * w.depth_S * w.depth_C);
         use(ctx->dt_bert);
-        void* emb = bert(w.bert, ids, ids_dt, B);
-        tap("hi.bert", emb, true, {B, L, c.bert_hidden});
+        b.emb = alloc_t((size_t)B * c.instr_len * c.bert_hidden);
+        b.ldx = w.rnn.in + c.hidden;
+        b.xh = alloc_f((size_t)B * b.ldx);
+        return b;
+    }
+    LoBufs lo_alloc(int B) {
+        LoBufs b;
+        b.ldx = ctx->lo.rnn.in + ctx->cfg.hidden;
+        b.xh = alloc_f((size_t)B * b.ldx);
+        return b;
+    }
+
+    // depth_encoder (seq2seq_highlevel_cma.py:178-179): GN-ResNet50 + pos-emb channels -> dep_tok
+    void hi_depth(const float* depth, int B, HiBufs& hb) {
+        const HighW& w = ctx->hi;
+        const int dS = w.depth_S, dC = w.depth_C;
+        use(ctx->dt_depth);
+        Act o = depth_trunk(w.depth, depth, B, "hi.depth");
+        void* tok = ctx->dt_depth == ctx->dt_vla ? hb.dep_tok : alloc_t((size_t)B * dS * dC);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
+            ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+            if (tok != hb.dep_tok) ck(launch_convert(tok, ctx->dt_depth, hb.dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
+        }
         use(ctx->dt_vla);
+        tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
+    }
+    // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels -> rgb_tok
+    void hi_rgb(const void* rgb, int rgb_dt, int B, HiBufs& hb) {
+        const HighW& w = ctx->hi;
+        const int rC = 2048 + 64;
+        use(ctx->dt_rgb);
+        Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "hi.rgb");
+        void* tok = ctx->dt_rgb == ctx->dt_vla ? hb.rgb_tok : alloc_t((size_t)B * 16 * rC);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
+            ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+            if (tok != hb.rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, hb.rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
+        }
+        use(ctx->dt_vla);
+        tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
+    }
+    // BERT (:189-195) -> emb
+    void hi_bert(const void* ids, int ids_dt, int B, HiBufs& hb) {
+        use(ctx->dt_bert);
+        bert(ctx->hi.bert, ids, ids_dt, B, hb.emb);
+        tap("hi.bert", hb.emb, true, {B, ctx->cfg.instr_len, ctx->cfg.bert_hidden});
+    }
+    // Visual_Ling_Attn x2, poolers, projections, state encoder, head (:198-232)
+    void hi_tail(int B, HiBufs& hb, const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
+        const hcm_config& c = ctx->cfg;
+        const HighW& w = ctx->hi;
+        const int L = c.instr_len, d = c.d_model;
+        const int rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
+        const int ldx = hb.ldx;
+        float* xh = hb.xh;
+        use(ctx->dt_vla);
+        void* emb = hb.emb;
         if (ctx->dt_bert != ctx->dt_vla) {
             void* e2 = alloc_t((size_t)B * L * c.bert_hidden);
             if (!dry) ck(launch_convert(emb, ctx->dt_bert, e2, ctx->dt_vla, (size_t)B * L * c.bert_hidden, s), "bert out convert");
             emb = e2;
         }
-
         // Visual_Ling_Attn x2 (:198-201; models/transformer/transformer.py:251-281)
         const VlaW& v = w.vla;
         const int rows = B * L;
@@ -286,7 +311,7 @@ struct Fwd {
         for (int stream = 0; stream < 2; ++stream) {
             const size_t m = ar.mark();
             const int S = stream == 0 ? 16 : dS;
-            const void* tok = stream == 0 ? rgb_tok : dep_tok;
+            const void* tok = stream == 0 ? hb.rgb_tok : hb.dep_tok;
             const int tokC = stream == 0 ? rC : dC;
             const LinW& kvproj = stream == 0 ? w.rgb_kv : w.depth_kv;
             void* vis = alloc_t((size_t)B * S * c.vis_in);
@@ -326,9 +351,9 @@ struct Fwd {
         }
         // rgb_linear (:213): mean over 16 tokens -> Linear -> ReLU ; depth_linear (:214): Flatten -> Linear -> ReLU
         void* rmean = alloc_t((size_t)B * rC);
-        if (!dry) ck(launch_mean_rows(rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
+        if (!dry) ck(launch_mean_rows(hb.rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
         linear(w.rgb_linear, rmean, B, rC, xh, ldx, ACT_RELU, true);
-        linear(w.depth_linear, dep_tok, B, dS * dC, xh + c.rgb_out, ldx, ACT_RELU, true);
+        linear(w.depth_linear, hb.dep_tok, B, dS * dC, xh + c.rgb_out, ldx, ACT_RELU, true);
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
@@ -336,58 +361,112 @@ struct Fwd {
         tap("hi.rnn_in", xh, false, {B, ldx});
     }
 
-    // ---------------------------------------------------------------- Seq2Seq_LowLevel.forward
-    void low(const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
-             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out) {
+    // ---------------------------------------------------------------- stages of Seq2Seq_LowLevel.forward
+    void lo_depth(const float* depth, int B, LoBufs& lb) {
+        const LowW& w = ctx->lo;
+        use(ctx->dt_depth);
+        if (w.depth_simple) {
+            simple_cnn(w.depth_s, depth, DT_F32, 1.0f, B, lb.xh, lb.ldx);
+        } else {
+            Act o = depth_trunk(w.depth, depth, B, "lo.depth");
+            linear(w.depth_fc, o.p, B, o.H * o.W * o.C, lb.xh, lb.ldx, ACT_RELU, true);     // visual_fc
+        }
+    }
+    void lo_rgb(const void* rgb, int rgb_dt, int B, LoBufs& lb) {
+        const LowW& w = ctx->lo;
+        const hcm_config& c = ctx->cfg;
+        use(ctx->dt_rgb);
+        if (w.rgb_simple) {
+            simple_cnn(w.rgb_s, rgb, rgb_dt, 1.0f / 255.0f, B, lb.xh + c.depth_out, lb.ldx);
+        } else {
+            Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "lo.rgb");
+            void* pooled = alloc_t((size_t)B * o.C);
+            if (!dry) ck(launch_adaptive_avgpool(o.p, pooled, dt, B, o.H, o.W, o.C, 1, 1, o.C, s), "global avgpool");
+            linear(w.rgb_fc, pooled, B, o.C, lb.xh + c.depth_out, lb.ldx, ACT_RELU, true);
+        }
+    }
+    void lo_tail(int B, LoBufs& lb, const float* h_in, const float* mask, const int64_t* subtask, float* vel, int ld_vel,
+                 float* stop, int ld_stop, float* h_out) {
         const hcm_config& c = ctx->cfg;
         const LowW& w = ctx->lo;
-        const int H = c.hidden, in = w.rnn.in, ldx = in + H;
-        ar.reset();
-        float* xh = alloc_f((size_t)B * ldx);                    // [depth | rgb | subtask | h*mask]  (seq2seq_lowlevel.py:143)
-        {
-            const size_t m = ar.mark();
-            use(ctx->dt_depth);
-            if (w.depth_simple) {
-                simple_cnn(w.depth_s, depth, DT_F32, 1.0f, B, xh, ldx);
-            } else {
-                Act o = depth_trunk(w.depth, depth, B, "lo.depth");
-                linear(w.depth_fc, o.p, B, o.H * o.W * o.C, xh, ldx, ACT_RELU, true);     // visual_fc
-            }
-            ar.release(m);
-        }
-        {
-            const size_t m = ar.mark();
-            use(ctx->dt_rgb);
-            if (w.rgb_simple) {
-                simple_cnn(w.rgb_s, rgb, rgb_dt, 1.0f / 255.0f, B, xh + c.depth_out, ldx);
-            } else {
-                Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "lo.rgb");
-                void* pooled = alloc_t((size_t)B * o.C);
-                if (!dry) ck(launch_adaptive_avgpool(o.p, pooled, dt, B, o.H, o.W, o.C, 1, 1, o.C, s), "global avgpool");
-                linear(w.rgb_fc, pooled, B, o.C, xh + c.depth_out, ldx, ACT_RELU, true);
-            }
-            ar.release(m);
-        }
         use(ctx->dt_vla);
-        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, xh, B, 32, ldx, c.depth_out + c.rgb_out, c.num_sub_tasks + 1, s), "subtask emb");
+        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, lb.xh, B, 32, lb.ldx, c.depth_out + c.rgb_out, c.num_sub_tasks + 1, s), "subtask emb");
         Heads hd;
         hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;
         hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = ld_stop;
-        rnn_step(w.rnn, xh, ldx, B, h_in, mask, h_out, hd);
-        tap("lo.rnn_in", xh, false, {B, ldx});
+        rnn_step(w.rnn, lb.xh, lb.ldx, B, h_in, mask, h_out, hd);
+        tap("lo.rnn_in", lb.xh, false, {B, lb.ldx});
+    }
+
+    // ---------------------------------------------------------------- one step: independent encoder chains run on
+    // separate HIP streams (fork/join by events, capturable into a hipGraph): the two RGB ResNet-50s, the two depth
+    // trunks and BERT have no data dependence until the cross-modal block / the recurrent cells.  Each chain owns a
+    // disjoint arena region; nothing is released until the step is fully enqueued.
+    void fork_join_begin(int n_aux) {
+        if (dry || n_aux == 0) return;
+        ck(hipEventRecord(ctx->ev_fork, ctx->stream), "fork record");
+        for (int i = 0; i < n_aux; ++i) ck(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0), "fork wait");
+    }
+    void fork_join_end(int n_aux) {
+        if (dry || n_aux == 0) return;
+        for (int i = 0; i < n_aux; ++i) {
+            ck(hipEventRecord(ctx->ev_join[i], ctx->aux[i]), "join record");
+            ck(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0), "join wait");
+        }
+    }
+    void on(hipStream_t st) { s = st; }
+
+    void step(bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
+              const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask,
+              float* logits, int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out) {
+        ar.reset();
+        HiBufs hb;
+        LoBufs lb;
+        if (do_hi) hb = hi_alloc(B);
+        if (do_lo) lb = lo_alloc(B);
+        const bool multi = ctx->concurrent && !ctx->taps_on;    // taps allocate/synchronise: keep them single-stream
+        hipStream_t main_s = ctx->stream;
+        hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s, a2 = multi ? ctx->aux[2] : main_s;
+        if (multi) fork_join_begin(3);
+        // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
+        on(main_s);
+        if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb);
+        // chain 1: the low-level RGB trunk
+        on(a0);
+        if (do_hi && do_lo) lo_rgb(rgb, rgb_dt, B, lb);
+        // chain 2: both depth trunks back to back (small, latency-bound kernels that fill the gaps of the RGB chains)
+        on(a1);
+        {
+            const size_t m = ar.mark();
+            size_t top = m;
+            if (do_hi) { hi_depth(depth, B, hb); top = ar.mark(); ar.release(m); }
+            if (do_lo) { lo_depth(depth, B, lb); if (ar.mark() > top) top = ar.mark(); }
+            ar.release(m);
+            ar.alloc(top - m);                                  // keep the chain's whole region reserved
+        }
+        // chain 3: BERT
+        on(a2);
+        if (do_hi) hi_bert(ids, ids_dt, B, hb);
+        on(main_s);
+        if (multi) fork_join_end(3);
+        if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);
+        const int64_t* st_ids = subtask;
+        if (do_hi && do_lo) {
+            // pred = argmax(output, dim=1)  (hierarchical_trainer.py:1098)
+            if (!dry) ck(launch_argmax(logits, ctx->pred_buf, B, ctx->cfg.num_actions, ld_logits, s), "argmax");
+            st_ids = ctx->pred_buf;
+        }
+        if (do_lo) lo_tail(B, lb, lo_h_in, mask, st_ids, vel, ld_vel, stop, ld_stop, lo_h_out);
     }
 };
 
-// entry points used by api.cpp
-void run_high(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
-              const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
+// entry point used by api.cpp
+void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
+              int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
+              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out) {
     Fwd f(ctx);
-    f.high(rgb, rgb_dt, depth, ids, ids_dt, B, h_in, mask, logits, ld_logits, h_out);
-}
-void run_low(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, int B, const float* h_in, const float* mask,
-             const int64_t* subtask, float* vel, int ld_vel, float* stop, int ld_stop, float* h_out) {
-    Fwd f(ctx);
-    f.low(rgb, rgb_dt, depth, B, h_in, mask, subtask, vel, ld_vel, stop, ld_stop, h_out);
+    f.step(do_hi, do_lo, rgb, rgb_dt, depth, ids, ids_dt, B, hi_h_in, lo_h_in, mask, subtask, logits, ld_logits, vel, ld_vel,
+           stop, ld_stop, hi_h_out, lo_h_out);
 }
 
 }  // namespace hcm
