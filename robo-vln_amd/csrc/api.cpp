@@ -152,6 +152,50 @@ int hcm_finalize(hcm_handle h) {
         }
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
+        // one tuning step at max_batch on scratch inputs: every conv / linear shape of the plan picks its fastest
+        // tile + staging variant (igemm.hip); steady-state calls then never synchronise the host
+        // (opt-in: HCM_TUNE=1.  Isolated per-kernel timings rank variants differently from the concurrent multi-stream
+        //  schedule, where the built-in heuristic measured faster end to end)
+        const char* nt = getenv("HCM_TUNE");
+        if (nt && atoi(nt)) {
+            const hcm_config& c = h->cfg;
+            const size_t B = c.max_batch, R = c.rnn_type == HCM_LSTM ? 2 : 1;
+            const size_t n_rgb = B * c.rgb_h * c.rgb_w * 3 * 4, n_dep = B * c.depth_h * c.depth_w * 4, n_ids = B * c.instr_len * 8;
+            const size_t n_hid = R * B * c.hidden * 4, n_misc = B * 16 * 4;
+            char* tmp = nullptr;
+            const size_t total = n_rgb + n_dep + n_ids + 4 * n_hid + 2 * n_misc + 4096;
+            if (hipMalloc((void**)&tmp, total) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc of tuning scratch failed");
+            (void)hipMemset(tmp, 0, total);
+            (void)hipMemset(tmp, 0x3C, n_rgb + n_dep);                  // small positive f32 pattern for the frames
+            char* p = tmp;
+            void* rgb = p; p += n_rgb;
+            float* dep = (float*)p; p += n_dep;
+            void* ids = p; p += n_ids;
+            float* hh = (float*)p; p += n_hid;
+            float* lh = (float*)p; p += n_hid;
+            float* hh2 = (float*)p; p += n_hid;
+            float* lh2 = (float*)p; p += n_hid;
+            float* mask = (float*)p; p += n_misc;
+            float* rec = (float*)p;
+            const bool conc = h->concurrent;
+            h->concurrent = false;
+            h->stream = nullptr;
+            igemm_set_tuning(true);
+            std::string terr;
+            try {
+                if (c.build_high && c.build_low)
+                    run_step(h, true, true, rgb, DT_F32, dep, ids, DT_I64, (int)B, hh, lh, mask, nullptr, rec, 7, rec + 4, 7, rec + 6, 7, hh2, lh2);
+                else if (c.build_high)
+                    run_step(h, true, false, rgb, DT_F32, dep, ids, DT_I64, (int)B, hh, nullptr, mask, nullptr, rec, c.num_actions, nullptr, 0, nullptr, 0, hh2, nullptr);
+                else
+                    run_step(h, false, true, rgb, DT_F32, dep, nullptr, DT_I64, (int)B, nullptr, lh, mask, (const int64_t*)ids, nullptr, 0, rec, c.lo_actions, rec + 8, 1, nullptr, lh2);
+            } catch (const std::exception& e) { terr = e.what(); }
+            igemm_set_tuning(false);
+            h->concurrent = conc;
+            (void)hipDeviceSynchronize();
+            (void)hipFree(tmp);
+            if (!terr.empty()) return fail(h, HCM_ERR_HIP, "tuning step failed: " + terr);
+        }
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, std::string("hcm_finalize: ") + e.what());
     }

@@ -19,7 +19,11 @@
 //
 // Reference ops replaced: cuDNN conv fwd + BatchNorm(eval) + ReLU of torchvision resnet50, the GN-ResNet
 // convs, and every nn.Linear / Conv1d(k=1) on the path.
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include "kernels.h"
 #include "dev.h"
 
@@ -33,6 +37,7 @@ struct IGemmDev {
     int B, H, W, Cin, xC, Ho, Wo, KH, KW, stride, pad;
     int M, N, K, Kp, ldy, ldr, act, out_f32;
     int cin_shift, kw_rcp, tilesM, tilesN;
+    unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
 };
 
 template <typename T> struct Mma;
@@ -54,6 +59,115 @@ template <> struct Mma<float> {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
 };
+
+// Shared epilogue of both kernel variants (see the comment at its top).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / 32][BM / 32], char* smem, int m0, int n0,
+                                               int tid, int wm, int wn, int fr, int fg) {
+    constexpr int TM = BM / 32;
+    constexpr int TN = BN / 32;
+    // ---- epilogue ----
+    // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
+    // output tile (the A/B tiles are dead: the K loop ended with a barrier).  Phase 2: each thread takes 8
+    // consecutive channels of a row, applies bias + residual + activation in f32, rounds once, and stores 16 B --
+    // a row of the tile leaves as one contiguous BN*sizeof(T)-byte run (the accumulator layout alone would store
+    // 32-byte fragments).  Row stride BN+4 floats keeps the ds_write_b128 of phase 1 conflict free.
+    constexpr int LDC = BN + 4;
+    float* sc = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int r = wm * (BM / 2) + j * 16 + fr;
+            const int cc = wn * (BN / 2) + i * 16 + fg * 4;
+            *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 8;            // threads per tile row
+    constexpr int RPP = 256 / TPR;         // rows per pass
+    const int c8 = (tid % TPR) * 8;
+    const int n = n0 + c8;
+    if (n >= p.N) return;
+    const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        if (hi_ok) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+    }
+    const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
+    const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
+#pragma unroll
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int r = pass * RPP + tid / TPR;
+        const int m = m0 + r;
+        if (m >= p.M) continue;
+        float v[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(sc + r * LDC + c8);
+            const float4 a1 = *reinterpret_cast<const float4*>(sc + r * LDC + c8 + 4);
+            v[0] = a0.x + bias8[0]; v[1] = a0.y + bias8[1]; v[2] = a0.z + bias8[2]; v[3] = a0.w + bias8[3];
+            v[4] = a1.x + bias8[4]; v[5] = a1.y + bias8[5]; v[6] = a1.z + bias8[6]; v[7] = a1.w + bias8[7];
+        }
+        if (p.res) {
+            const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
+            if constexpr (sizeof(T) == 2) {
+                if (wide16r) {
+                    float rr[8];
+                    ld_chunk(rp, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Tr<T>::ld(rp + e);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 4; e < 8; ++e) v[e] += Tr<T>::ld(rp + e);
+                    }
+                }
+            } else {
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (hi_ok) {
+                    const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+            }
+        }
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.out_f32 || sizeof(T) == 4) {
+            float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (hi_ok) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            if constexpr (sizeof(T) == 2) {
+                T* yp = reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n;
+                if (wide16) {
+                    st_chunk(yp, v);
+                } else {
+                    T o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<const uint2*>(o4);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[4 + e]);
+                        *reinterpret_cast<uint2*>(yp + 4) = *reinterpret_cast<const uint2*>(o4);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
@@ -192,160 +306,289 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
         __syncthreads();
     }
 
-    // ---- epilogue ----
-    // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
-    // output tile (the A/B tiles are dead: the K loop ended with a barrier).  Phase 2: each thread takes 8
-    // consecutive channels of a row, applies bias + residual + activation in f32, rounds once, and stores 16 B --
-    // a row of the tile leaves as one contiguous BN*sizeof(T)-byte run (the accumulator layout alone would store
-    // 32-byte fragments).  Row stride BN+4 floats keeps the ds_write_b128 of phase 1 conflict free.
-    constexpr int LDC = BN + 4;
-    float* sc = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int r = wm * (BM / 2) + j * 16 + fr;
-            const int cc = wn * (BN / 2) + i * 16 + fg * 4;
-            *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-    __syncthreads();
-    constexpr int TPR = BN / 8;            // threads per tile row
-    constexpr int RPP = 256 / TPR;         // rows per pass
-    const int c8 = (tid % TPR) * 8;
-    const int n = n0 + c8;
-    if (n >= p.N) return;
-    const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-        if (hi_ok) {
-            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-        }
-    }
-    const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
-    const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
-#pragma unroll
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-        const int r = pass * RPP + tid / TPR;
-        const int m = m0 + r;
-        if (m >= p.M) continue;
-        float v[8];
-        {
-            const float4 a0 = *reinterpret_cast<const float4*>(sc + r * LDC + c8);
-            const float4 a1 = *reinterpret_cast<const float4*>(sc + r * LDC + c8 + 4);
-            v[0] = a0.x + bias8[0]; v[1] = a0.y + bias8[1]; v[2] = a0.z + bias8[2]; v[3] = a0.w + bias8[3];
-            v[4] = a1.x + bias8[4]; v[5] = a1.y + bias8[5]; v[6] = a1.z + bias8[6]; v[7] = a1.w + bias8[7];
-        }
-        if (p.res) {
-            const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
-            if constexpr (sizeof(T) == 2) {
-                if (wide16r) {
-                    float rr[8];
-                    ld_chunk(rp, rr);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += Tr<T>::ld(rp + e);
-                    if (hi_ok) {
-#pragma unroll
-                        for (int e = 4; e < 8; ++e) v[e] += Tr<T>::ld(rp + e);
-                    }
-                }
-            } else {
-                const float4 r0 = *reinterpret_cast<const float4*>(rp);
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                if (hi_ok) {
-                    const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
-                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                }
-            }
-        }
-        if (p.act == ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if (p.out_f32 || sizeof(T) == 4) {
-            float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
-            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-            if (hi_ok) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-            if constexpr (sizeof(T) == 2) {
-                T* yp = reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n;
-                if (wide16) {
-                    st_chunk(yp, v);
-                } else {
-                    T o4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
-                    *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<const uint2*>(o4);
-                    if (hi_ok) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[4 + e]);
-                        *reinterpret_cast<uint2*>(yp + 4) = *reinterpret_cast<const uint2*>(o4);
-                    }
-                }
-            }
-        }
-    }
+    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Main variant: LDS-DMA staging, 3-deep ring, counted waits.
+//   * both tiles go L2/HBM -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write pass).  The DMA
+//     destination is lane-linear (wave base + lane*16 B): one wave instruction fills 8 tile rows x 128 B, so the XOR
+//     swizzle moves to the SOURCE address: lane (row r, slot c') fetches chunk c' ^ (r & 7) (rule 21 of the guide).
+//   * buffer resources with range checking: a lane whose im2col tap is outside the image (or past M / N / K) presents
+//     offset 0xFFFFFFFF and the hardware deposits zeros -- branch-free zero fill.
+//   * the DMA is issued from inline asm: hipcc models an LDS-DMA builtin as an LDS store and would put
+//     `s_waitcnt vmcnt(0)` in front of every ds_read of the loop, exposing the whole load latency.  Hidden from the
+//     compiler, tile t+2 is requested before tile t is consumed and only `vmcnt(<loads of one tile>)` is waited for at
+//     the end of an iteration (cdna_hip_programming.md T3/T4): two tiles of loads stay in flight across the barrier.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, v4i_t rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+__device__ __forceinline__ v4i_t make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    v4i_t r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu);     // stride 0
+    r[2] = (int)bytes;                               // num_records (bytes for raw buffers)
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <typename T, int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
+    constexpr int CH = Tr<T>::CH;
+    constexpr int BK = 8 * CH;
+    constexpr int TM = BM / 32;
+    constexpr int TN = BN / 32;
+    constexpr int A_IT = BM / 32;          // wave-level DMA instructions per tile (8 rows each)
+    constexpr int B_IT = BN / 32;
+    constexpr int LPT = A_IT + B_IT;       // DMA instructions per wave per K tile
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int local = bid >> 3;
+    const int tile_n = local % p.tilesN;
+    const int tile_m = (local / p.tilesN) * 8 + xcd;
+    if (tile_m >= p.tilesM) return;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rin = lane >> 3;                 // row inside the 8-row DMA group
+    const int c = (lane & 7) ^ rin;            // source chunk this lane fetches (swizzle on the source side)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (wave + 4 * i) * 8 + rin;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_pix[i] = b * p.H * p.W;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+        } else {
+            a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+        }
+    }
+    const bool spatial = (p.KH * p.KW) > 1;
+    const v4i_t rx = make_rsrc(p.x, p.x_bytes);
+    const v4i_t rw = make_rsrc(p.w, p.w_bytes);
+
+    auto stage = [&](int kt, int buf) {
+        const unsigned sa = lds_base + buf * TILE_BYTES;
+        const unsigned sb = sa + BM * 128;
+        const int k = kt * BK + c * CH;
+        int kh = 0, kw = 0, ci = k;
+        if (spatial) {
+            const int khw = k >> p.cin_shift;
+            ci = k & (p.Cin - 1);
+            kh = (khw * p.kw_rcp) >> 16;
+            kw = khw - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * (unsigned)sizeof(T);
+            dma16(sa + (wave + 4 * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + (wave + 4 * i) * 8 + rin;
+            const bool ok = (k < p.Kp) & (n < p.N);
+            const unsigned off = (unsigned)(n * p.Kp + k) * (unsigned)sizeof(T);
+            dma16(sb + (wave + 4 * i) * 1024, ok ? off : 0xFFFFFFFFu, rw);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    // prologue: NBUF-1 tiles in flight; tile 0 must have landed (for every wave) before the first fragment read
+    stage(0, 0);
+    if (NBUF == 3 && nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + (NBUF - 1) < nk;
+        // ring slot of tile kt+NBUF-1: it was last read in iteration kt-1, which every wave has left (barrier)
+        if (more) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[TM], wb[TN];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / 2) + j * 16 + fr;
+                xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * (BN / 2) + i * 16 + fr;
+                wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], wb[i], xa[j]);
+        }
+        // tile kt+1 must be complete before the next iteration reads it; with the 3-deep ring the tile requested in this
+        // iteration may stay in flight across the barrier
+        if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == NBUF - 1 ? 0 : cur + 1;
+    }
+    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+}
+
+// variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring
 template <typename T, int BM, int BN>
-static hipError_t launch_cfg(IGemmDev d, hipStream_t s) {
+static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesM = (d.M + BM - 1) / BM;
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
     const int grid = tm8 * 8 * d.tilesN;
-    size_t lds = 2 * (size_t)(BM + BN) * 128;
+    size_t lds = (variant == 2 ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
     if (lds_c > lds) lds = lds_c;
-    if (lds > 64 * 1024) {
-        static bool attr_done = false;                        // one flag per template instantiation
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_done = false;                            // one flag per template instantiation
+    if (!attr_done) {
+        const void* fns[3] = {reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
+                              reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2>),
+                              reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
         }
+        attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
+    else if (variant == 1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, s, d);
+    else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, s, d);
     return hipGetLastError();
 }
 
-template <typename T>
-static hipError_t launch_forced(const IGemmDev& d, int cfg, hipStream_t s) {
-    switch (cfg) {
-        case 0: return launch_cfg<T, 128, 128>(d, s);
-        case 1: return launch_cfg<T, 128, 64>(d, s);
-        case 2: return launch_cfg<T, 64, 64>(d, s);
-        case 3: return launch_cfg<T, 64, 32>(d, s);
-        case 4: return launch_cfg<T, 128, 32>(d, s);
-        case 5: return launch_cfg<T, 64, 128>(d, s);
-        default: return hipErrorInvalidValue;
-    }
-}
+static const int kTiles[6][2] = {{128, 128}, {128, 64}, {64, 64}, {64, 32}, {128, 32}, {64, 128}};
 
 template <typename T>
-static hipError_t launch_t(const IGemmDev& d, hipStream_t s) {
-    static const char* force = getenv("HCM_IGEMM_FORCE");
-    if (force) return launch_forced<T>(d, atoi(force), s);
-    // tile choice: largest tile that still gives the 256 CUs at least ~2 workgroups each
-    const long blocks128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-    const long blocks12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
-    const long blocks64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-    if (d.N >= 128 && blocks128 >= 512) return launch_cfg<T, 128, 128>(d, s);
-    if (d.N >= 64 && blocks12864 >= 512) return launch_cfg<T, 128, 64>(d, s);
-    if (d.N <= 32) {
-        if ((long)((d.M + 127) / 128) >= 512) return launch_cfg<T, 128, 32>(d, s);
-        return launch_cfg<T, 64, 32>(d, s);
+static hipError_t launch_choice(const IGemmDev& d, int choice, hipStream_t s) {
+    const int variant = choice / 6;
+    switch (choice % 6) {
+        case 0: return launch_cfg<T, 128, 128>(d, variant, s);
+        case 1: return launch_cfg<T, 128, 64>(d, variant, s);
+        case 2: return launch_cfg<T, 64, 64>(d, variant, s);
+        case 3: return launch_cfg<T, 64, 32>(d, variant, s);
+        case 4: return launch_cfg<T, 128, 32>(d, variant, s);
+        default: return launch_cfg<T, 64, 128>(d, variant, s);
     }
-    if (blocks64 >= 256 || d.N <= 64) return launch_cfg<T, 64, 64>(d, s);
-    return launch_cfg<T, 64, 32>(d, s);
+}
+static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s) {
+    if (dt == DT_BF16) return launch_choice<bf16>(d, choice, s);
+    if (dt == DT_F16) return launch_choice<f16>(d, choice, s);
+    if (dt == DT_F32) return launch_choice<float>(d, choice, s);
+    return hipErrorInvalidValue;
+}
+
+// Default (tile, staging variant) per shape, distilled from the per-shape sweep in profiles/igemm_sweep_r1.md:
+// LDS-DMA with 2 buffers nearly everywhere (2 workgroups per CU); the 3-deep ring only for long K loops on small
+// tiles (few workgroups, latency bound); 64-row pixel tiles whenever 128x128 would leave CUs idle or K is so short
+// that the kernel is a streaming copy with a matmul attached.
+static int heuristic_choice(const IGemmDev& d, int dt) {
+    auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
+    const long b64128 = cdiv(d.M, 64) * cdiv(d.N, 128);
+    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
+    int tile;       // index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
+    if (d.N <= 32) tile = 3;
+    else if (d.N <= 64) tile = (d.K >= 512 && d.M >= 65536) ? 1 : (b64 >= 256 ? 2 : 3);
+    else if (d.K <= 256) tile = b64128 >= 512 ? 5 : (b64 >= 256 ? 2 : 3);
+    else if (b128 >= 512) tile = 0;
+    else if (b64128 >= 384) tile = 5;
+    else if (b64 >= 256) tile = 2;
+    else tile = 3;
+    const int variant = (d.K >= 2048 && (tile == 2 || tile == 3) && d.M > 64) ? 2 : 1;
+    (void)dt;
+    return variant * 6 + tile;
+}
+
+// ---- per-shape autotuner (run once per handle at hcm_finalize on the real layer shapes) ----
+static bool g_tuning = false;
+static std::unordered_map<std::string, int> g_choice;
+static std::mutex g_choice_mu;
+
+void igemm_set_tuning(bool on) { g_tuning = on; }
+size_t igemm_tuned_shapes() { std::lock_guard<std::mutex> l(g_choice_mu); return g_choice.size(); }
+
+static std::string shape_key(const IGemmDev& d, int dt) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "%d|%d,%d,%d|%d,%d,%d,%d|%d,%d,%d,%d|%d,%d", dt, d.M, d.N, d.K, d.H, d.W, d.Cin, d.xC, d.KH, d.KW, d.stride,
+             d.pad, d.res != nullptr, d.out_f32);
+    return buf;
+}
+
+static bool candidate_ok(const IGemmDev& d, int choice) {
+    const int bm = kTiles[choice % 6][0], bn = kTiles[choice % 6][1];
+    if (bn >= 64 && d.N <= bn / 2) return false;            // mostly-empty channel tile
+    if (bm == 128 && d.M <= 64) return false;
+    return true;
+}
+
+static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best_out) {
+    hipEvent_t e0, e1;
+    hipError_t rc = hipEventCreate(&e0);
+    if (rc != hipSuccess) return rc;
+    rc = hipEventCreate(&e1);
+    if (rc != hipSuccess) return rc;
+    float best = 1e30f;
+    int best_c = heuristic_choice(d, dt);
+    for (int c = 0; c < 18; ++c) {
+        if (!candidate_ok(d, c)) continue;
+        if ((rc = launch_dt(d, dt, c, s)) != hipSuccess) break;         // warm-up (also sets the LDS attribute)
+        float tmin = 1e30f;
+        for (int rep = 0; rep < 3 && rc == hipSuccess; ++rep) {
+            (void)hipEventRecord(e0, s);
+            rc = launch_dt(d, dt, c, s);
+            (void)hipEventRecord(e1, s);
+            if (rc != hipSuccess) break;
+            if ((rc = hipEventSynchronize(e1)) != hipSuccess) break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < tmin) tmin = ms;
+        }
+        if (rc != hipSuccess) break;
+        if (tmin < best) { best = tmin; best_c = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *best_out = best_c;
+    return rc;
 }
 
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
@@ -363,12 +606,37 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         while ((1 << d.cin_shift) < g.Cin) ++d.cin_shift;
     }
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
+    {
+        const size_t esz = dt_size(dt);
+        const size_t xb = (((size_t)d.B * d.H * d.W - 1) * d.xC + d.Cin) * esz;
+        const size_t wb = (size_t)d.N * d.Kp * esz;
+        if (xb >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
+        d.x_bytes = (unsigned)xb;
+        d.w_bytes = (unsigned)wb;
+    }
     if ((g.Cin % CH) || (d.xC % CH) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
         return hipErrorInvalidValue;
-    if (dt == DT_BF16) return launch_t<bf16>(d, s);
-    if (dt == DT_F16) return launch_t<f16>(d, s);
-    if (dt == DT_F32) return launch_t<float>(d, s);
-    return hipErrorInvalidValue;
+    if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
+    static const char* force = getenv("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
+    if (force) return launch_dt(d, dt, atoi(force), s);
+    const std::string key = shape_key(d, dt);
+    int choice = -1;
+    {
+        std::lock_guard<std::mutex> l(g_choice_mu);
+        auto it = g_choice.find(key);
+        if (it != g_choice.end()) choice = it->second;
+    }
+    if (choice < 0) {
+        if (g_tuning) {
+            hipError_t rc = tune_shape(d, dt, s, &choice);
+            if (rc != hipSuccess) return rc;
+            std::lock_guard<std::mutex> l(g_choice_mu);
+            g_choice[key] = choice;
+        } else {
+            choice = heuristic_choice(d, dt);
+        }
+    }
+    return launch_dt(d, dt, choice, s);
 }
 
 }  // namespace hcm

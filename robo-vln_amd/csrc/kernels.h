@@ -30,6 +30,10 @@ struct IGemm {
     int out_f32 = 0;
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
+// While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real
+// operands and caches the fastest (process-wide); hcm_finalize() runs one tuning step at max_batch.
+void igemm_set_tuning(bool on);
+size_t igemm_tuned_shapes();
 
 // First-layer im2col (Cin = 1 or 3): x [B,H,W,C] (src_dt: f32 / u8 / T) * scale -> A [B*Ho*Wo][Kp] (T), zero-padded K..Kp
 hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C,
