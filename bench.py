@@ -92,7 +92,7 @@ def dominant_kernel_probe(batch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * B * H * W * Cout * 9 * Cin
-    return {"kernel": "igemm_kernel<bf16,128,64> conv3x3 64->64 @64x64", "us_per_launch": round(ms * 1e3, 2),
+    return {"kernel": "igemm_dma_kernel<bf16,128,64,2> conv3x3 64->64 @64x64 (M=B*4096, N=64, K=576)", "us_per_launch": round(ms * 1e3, 2),
             "tflops": round(flops / ms / 1e9, 1)}
 
 
@@ -177,7 +177,7 @@ def main():
             "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr",
             "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic (random-init weights, random RGB-D frames and token ids, resident in HBM)",
+            "dtype": "bf16+fp16 (16-bit MFMA, fp32 accumulate; DESIGN.md section 5)" if args.precision == "bf16" else "fp32", "data": "synthetic (random-init weights, random RGB-D frames and token ids, resident in HBM)",
             "config": {"workload": "BASELINE.json configs[1]: full HCM act() (hi->argmax->lo), 256x256 RGB-D, L=80, VLA N=1, LSTM-512",
                        "per_gpu_batch": B, "global_batch": global_B,
                        "parallelism": f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step" if world > 1 else "single GPU"},
