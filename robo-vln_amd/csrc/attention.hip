@@ -5,6 +5,7 @@
 // v1: one workgroup per (batch, head); K and V staged once in LDS as f32; four lanes share a query row (16 of the
 // 64 dims each), online softmax in registers.  Scores are tiny here (<= 160 x 160 per head, 1.7 % of BERT's
 // FLOPs) so this kernel is LDS-bandwidth bound, not MFMA bound.
+#include <cstdlib>
 #include "kernels.h"
 #include "dev.h"
 
@@ -95,6 +96,155 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// MFMA variant for the 16-bit storage types (Lk <= 160).  One workgroup per (batch, head), 4 waves, each wave owns
+// 16-query tiles.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand = K rows from LDS, B operand = Q rows
+// straight from global), so that in the accumulator layout a lane holds 4 keys of ONE query per key tile: the
+// softmax row reduction is in-register plus two cross-lane steps (xor 16, 32), and the exponentiated scores are
+// already in A-operand position for P.V -- no LDS round trip for P.  The key order inside a 32-key MFMA step is
+// permuted (slots 0-3: keys 4g..4g+3 of the even tile, 4-7: the same of the odd tile); V is staged transposed
+// ([d][key], padded rows) and read with the same permutation, which a dot product is invariant to.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename T> struct AttMma;
+template <> struct AttMma<bf16> {
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct AttMma<f16> {
+    static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    }
+};
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    T t[2];
+    Tr<T>::st(&t[0], a);
+    Tr<T>::st(&t[1], b);
+    return (uint32_t)t[0].v | ((uint32_t)t[1].v << 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                             T* __restrict__ out, int heads, int Lq, int Lk, int ldq, int ldk,
+                                                             int ldv, int ldo, int q_batch_mod) {
+    constexpr int D = 64;
+    constexpr int MAXKT = 10;                 // Lk <= 160
+    extern __shared__ __attribute__((aligned(16))) char smem_att[];
+    const int KT2 = (Lk + 31) / 32;           // 32-key MFMA steps
+    const int Lkp = KT2 * 32;
+    const int vstride = Lkp + 4;              // elements per V^T row (pad keeps the 8-byte reads spread over banks)
+    char* Ks = smem_att;                      // [Lkp][64] T, 128-B rows, chunk index ^ (row & 7)
+    T* Vt = reinterpret_cast<T*>(smem_att + (size_t)Lkp * 128);   // [64][vstride] T
+
+    const int b = blockIdx.x / heads;
+    const int h = blockIdx.x % heads;
+    const int bq = b % q_batch_mod;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // stage K (swizzled rows) and V^T; rows >= Lk are zero
+    for (int e = tid; e < Lkp * 8; e += 256) {
+        const int row = e >> 3, c = e & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < Lk) {
+            kv = *reinterpret_cast<const uint4*>(k + ((size_t)b * Lk + row) * ldk + h * D + c * 8);
+            vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Lk + row) * ldv + h * D + c * 8);
+        }
+        *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T t;
+            t.v = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+            Vt[(size_t)(c * 8 + j) * vstride + row] = t;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int QT = (Lq + 15) / 16;
+    for (int qt = wave; qt < QT; qt += 4) {
+        // B operand: Q rows of this tile (clamped: rows past Lq compute garbage that is never stored)
+        int qrow = qt * 16 + fr;
+        if (qrow >= Lq) qrow = Lq - 1;
+        const T* qp = q + ((size_t)bq * Lq + qrow) * ldq + h * D;
+        const uint4 q0 = *reinterpret_cast<const uint4*>(qp + fg * 8);
+        const uint4 q1 = *reinterpret_cast<const uint4*>(qp + 32 + fg * 8);
+
+        f32x4_t sc[MAXKT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < MAXKT; ++t) {
+            sc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (t < 2 * KT2) {
+                const int r = t * 16 + fr;
+                const uint4 k0 = *reinterpret_cast<const uint4*>(Ks + r * 128 + (((0 + fg) ^ (r & 7)) << 4));
+                const uint4 k1 = *reinterpret_cast<const uint4*>(Ks + r * 128 + (((4 + fg) ^ (r & 7)) << 4));
+                sc[t] = AttMma<T>::run(k0, q0, sc[t]);
+                sc[t] = AttMma<T>::run(k1, q1, sc[t]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + fg * 4 + e;
+                    const float sv = key < Lk ? sc[t][e] * 0.125f : -3.0e38f;     // 1/sqrt(64); padded keys masked
+                    sc[t][e] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXKT; ++t)
+            if (t < 2 * KT2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __expf(sc[t][e] - mx);
+                    sc[t][e] = pv;
+                    sum += pv;
+                }
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+
+        f32x4_t o[4];
+#pragma unroll
+        for (int dtile = 0; dtile < 4; ++dtile) o[dtile] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c2 = 0; c2 < MAXKT / 2; ++c2)
+            if (c2 < KT2) {
+                uint4 pa;
+                pa.x = pack2<T>(sc[2 * c2][0], sc[2 * c2][1]);
+                pa.y = pack2<T>(sc[2 * c2][2], sc[2 * c2][3]);
+                pa.z = pack2<T>(sc[2 * c2 + 1][0], sc[2 * c2 + 1][1]);
+                pa.w = pack2<T>(sc[2 * c2 + 1][2], sc[2 * c2 + 1][3]);
+#pragma unroll
+                for (int dtile = 0; dtile < 4; ++dtile) {
+                    const T* vr = Vt + (size_t)(dtile * 16 + fr) * vstride + c2 * 32 + fg * 4;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+                    const uint4 vb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    o[dtile] = AttMma<T>::run(pa, vb, o[dtile]);
+                }
+            }
+        const float inv = 1.0f / sum;           // per query = per (lane & 15); rows of o are queries (fg*4 + e)
+        // o[dtile][e] belongs to query qt*16 + fg*4 + e, column dtile*16 + fr; its normaliser lives in lane (fg*4+e)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv_q = __shfl(inv, fg * 4 + e, 64);
+            const int qi = qt * 16 + fg * 4 + e;
+            if (qi < Lq) {
+                T* op = out + ((size_t)b * Lq + qi) * ldo + h * D + fr;
+#pragma unroll
+                for (int dtile = 0; dtile < 4; ++dtile) Tr<T>::st(op + dtile * 16, o[dtile][e] * inv_q);
+            }
+        }
+    }
+}
+
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads, int Lq,
                             int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s) {
     const size_t lds = (size_t)Lk * 64 * sizeof(float) * 2;
@@ -108,6 +258,15 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
+    }
+    static const char* valu = getenv("HCM_ATT_VALU");
+    if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 160 && !(valu && atoi(valu))) {
+        const int Lkp = (Lk + 31) / 32 * 32;
+        const size_t lds2 = (size_t)Lkp * 128 + (size_t)64 * (Lkp + 4) * 2;
+#define LM(T) hipLaunchKernelGGL(attention_mfma_kernel<T>, dim3(B * heads), dim3(256), lds2, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod)
+        if (dt == DT_BF16) LM(bf16); else LM(f16);
+#undef LM
+        return hipGetLastError();
     }
 #define LA(T) hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), lds, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod)
     if (dt == DT_BF16) LA(bf16); else if (dt == DT_F16) LA(f16); else if (dt == DT_F32) LA(float); else return hipErrorInvalidValue;

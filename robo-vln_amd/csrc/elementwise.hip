@@ -360,14 +360,75 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
         }
 }
 
+// Vectorised variant: 32 lanes per row, 16-byte chunks (D/CH chunks per row, D/CH/32 per lane), two rows per wave.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ post, int post_rows,
+                                                             T* __restrict__ y, int rows, float eps) {
+    constexpr int CH = Tr<T>::CH;
+    constexpr int CPL = D / CH / 32;         // chunks per lane
+    static_assert(CPL >= 1 && D % (CH * 32) == 0, "row must split into 32 x 16-byte chunks");
+    const int sub = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * D;
+    const T* rr = res ? res + (size_t)row * D : nullptr;
+    float v[CPL][CH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 32 + sub) * CH;
+        ld_chunk(xr + c, v[i]);
+        if (rr) {
+            float r[CH];
+            ld_chunk(rr + c, r);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[i][j] += r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) sum += v[i][j];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq * (1.0f / D) + eps);
+    const float* pp = post ? post + (size_t)(row % post_rows) * D : nullptr;
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 32 + sub) * CH;
+        float o[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            float t = (v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j];
+            if (pp) t += pp[c + j];
+            o[j] = t;
+        }
+        st_chunk(yr + c, o);
+    }
+}
+
 hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, const float* beta, const float* post,
                             int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s) {
+    const int pr = post_rows > 0 ? post_rows : 1;
+    if (D == 768 || D == 256 || D == 512) {
+        const dim3 grid((rows + 7) / 8), block(256);
+#define LV(DD) hipLaunchKernelGGL((layernorm_vec_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, pr, (T*)y, rows, eps)
+        HCM_DISPATCH_T(dt, { if (D == 768) LV(768); else if (D == 256) LV(256); else LV(512); });
+#undef LV
+        return hipGetLastError();
+    }
     const int wpb = 4;
     const dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
-#define L(DD) hipLaunchKernelGGL((layernorm_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, post_rows > 0 ? post_rows : 1, (T*)y, rows, eps)
-    HCM_DISPATCH_T(dt, {
-        if (D == 768) L(768); else if (D == 256) L(256); else if (D == 512) L(512); else if (D == 128) L(128); else return hipErrorInvalidValue;
-    });
+#define L(DD) hipLaunchKernelGGL((layernorm_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, pr, (T*)y, rows, eps)
+    HCM_DISPATCH_T(dt, { if (D == 128) L(128); else return hipErrorInvalidValue; });
 #undef L
     return hipGetLastError();
 }
