@@ -84,17 +84,27 @@ struct Fwd {
     // ---------------------------------------------------------------- ResNet-50 trunks
     // torchvision resnet50 conv1..layer4 with BN folded (RGB), or habitat GN-ResNet50 (+compression) (depth).
     // `first` is the im2col'ed input [B*Ho*Wo][Kp]; returns the trunk output living in arena memory.
-    Act trunk(const TrunkW& t, const void* first, int B, int Ho, int Wo, const std::string& tapname) {
+    struct Stem { const void* x; int x_dt; float scale; int H, W, Cin; };   // raw frame feeding the 7x7/2 stem conv
+
+    void stem_conv(const ConvW& w, const Stem& st, int B, int k, int stride, int pad, void* out, int Ho, int Wo, int act) {
+        if (dry) return;
+        IGemm g;
+        g.x = st.x; g.w = w.w; g.bias = w.bias; g.y = out;
+        g.B = B; g.H = st.H; g.W = st.W; g.Cin = st.Cin; g.xC = st.Cin;
+        g.Ho = Ho; g.Wo = Wo; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad;
+        g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
+        g.x_src_dt = st.x_dt; g.x_scale = st.scale;
+        ck(launch_igemm(g, w.dt, s), "stem conv");
+    }
+
+    Act trunk(const TrunkW& t, const Stem& st, int B, int Ho, int Wo, const std::string& tapname) {
         const int c1 = t.conv1.Cout;
         const size_t max_elems = (size_t)B * Ho * Wo * c1;      // conv1 output == layer1 output == largest activation
         void* slot[4];
         for (auto& p : slot) p = alloc_t(max_elems);
-        // conv1 as a plain GEMM over the im2col matrix
-        {
-            LinW l; l.w = t.conv1.w; l.bias = t.conv1.bias; l.N = c1; l.K = t.conv1.Kp; l.Kp = t.conv1.Kp; l.dt = dt;
-            linear(l, first, B * Ho * Wo, t.conv1.Kp, slot[0], c1, t.gn ? ACT_NONE : ACT_RELU, false);
-            if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, t.groups, true);
-        }
+        // 7x7/2 stem: implicit GEMM gathering straight from the raw frame (permute, /255, dtype conversion fused)
+        stem_conv(t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
+        if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, t.groups, true);
         tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
         if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
@@ -142,30 +152,23 @@ struct Fwd {
     Act rgb_trunk(const TrunkW& t, const void* rgb, int rgb_dt, int B, const std::string& tapname) {
         const int H = ctx->cfg.rgb_h, W = ctx->cfg.rgb_w;
         const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-        void* a = alloc_t((size_t)B * Ho * Wo * t.conv1.Kp);
-        // permute(0,3,1,2) + `/ 255.0` (resnet_encoders.py:211-213) folded into the im2col gather
-        if (!dry) ck(launch_im2col(rgb, rgb_dt, a, dt, B, H, W, 3, 7, 7, 2, 3, Ho, Wo, t.conv1.Kp, 1.0f / 255.0f, s), "im2col rgb");
-        return trunk(t, a, B, Ho, Wo, tapname);
+        // permute(0,3,1,2) + `/ 255.0` (resnet_encoders.py:211-213) are folded into the stem conv's gather
+        return trunk(t, Stem{rgb, rgb_dt, 1.0f / 255.0f, H, W, 3}, B, Ho, Wo, tapname);
     }
     Act depth_trunk(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
         const int H = ctx->cfg.depth_h / 2, W = ctx->cfg.depth_w / 2;
         void* pooled = alloc_t((size_t)B * H * W);
         if (!dry) ck(launch_avgpool2_f32(depth, pooled, dt, B, ctx->cfg.depth_h, ctx->cfg.depth_w, s), "avgpool2");
         const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-        void* a = alloc_t((size_t)B * Ho * Wo * t.conv1.Kp);
-        if (!dry) ck(launch_im2col(pooled, dt, a, dt, B, H, W, 1, 7, 7, 2, 3, Ho, Wo, t.conv1.Kp, 1.0f, s), "im2col depth");
-        return trunk(t, a, B, Ho, Wo, tapname);
+        return trunk(t, Stem{pooled, dt, 1.0f, H, W, 1}, B, Ho, Wo, tapname);
     }
 
     // SimpleAllCNN.cnn (simple_cnns.py:76-100) -> f32 features into out[b*ld + col0 ..]
     void simple_cnn(const SimpleCnnW& w, const void* x, int x_dt, float scale, int B, float* out, int ld) {
         const int H = w.hw;
         const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
-        void* a = alloc_t((size_t)B * h1 * h1 * w.c0.Kp);
-        if (!dry) ck(launch_im2col(x, x_dt, a, dt, B, H, H, w.cin, 8, 8, 4, 0, h1, h1, w.c0.Kp, scale, s), "im2col simple");
         void* y0 = alloc_t((size_t)B * h1 * h1 * 32);
-        LinW l; l.w = w.c0.w; l.bias = w.c0.bias; l.N = 32; l.K = w.c0.Kp; l.Kp = w.c0.Kp; l.dt = dt;
-        linear(l, a, B * h1 * h1, w.c0.Kp, y0, 32, ACT_RELU, false);
+        stem_conv(w.c0, Stem{x, x_dt, scale, H, H, w.cin}, B, 8, 4, 0, y0, h1, h1, ACT_RELU);
         void* y1 = alloc_t((size_t)B * h2 * h2 * 64);
         conv(w.c1, Act{y0, B, h1, h1, 32}, y1, 2, 0, nullptr, ACT_RELU, h2, h2);
         void* y2 = alloc_t((size_t)B * h3 * h3 * 32);

@@ -21,6 +21,7 @@
 // convs, and every nn.Linear / Conv1d(k=1) on the path.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -38,6 +39,7 @@ struct IGemmDev {
     int M, N, K, Kp, ldy, ldr, act, out_f32;
     int cin_shift, kw_rcp, tilesM, tilesN;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
+    float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
 };
 
 template <typename T> struct Mma;
@@ -169,7 +171,14 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
     }
 }
 
-template <typename T, int BM, int BN>
+// S = void: activations are T with Cin a multiple of the 16-byte chunk (the general path).
+// S = float / uint8_t / T: narrow-channel FIRST layers (Cin = 1 or 3: the 7x7/2 stems, SimpleCNN's 8x8/4): the im2col row
+// is gathered element-wise straight from the raw frame (`permute`, `/255`, dtype conversion fused; no im2col matrix).
+template <typename S> __device__ __forceinline__ float ld_src_elem(const S* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ld_src_elem<bf16>(const bf16* p) { return bf2f(p->v); }
+template <> __device__ __forceinline__ float ld_src_elem<f16>(const f16* p) { return Tr<f16>::ld(p); }
+
+template <typename T, int BM, int BN, typename S = void>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
     constexpr int CH = Tr<T>::CH;          // elements per 16-byte chunk
     constexpr int BK = 8 * CH;             // elements per 128-byte tile row
@@ -224,21 +233,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
     uint4 ra[A_IT], rb[B_IT];
     auto load_tiles = [&](int kt) {
         const int k = kt * BK + c * CH;
-        const bool kvalid = k < p.K;
-        int kh = 0, kw = 0, ci = k;
-        if (spatial) {
-            const int khw = k >> p.cin_shift;
-            ci = k & (p.Cin - 1);
-            kh = (khw * p.kw_rcp) >> 16;
-            kw = khw - kh * p.KW;
-        }
+        if constexpr (std::is_void<S>::value) {
+            const bool kvalid = k < p.K;
+            int kh = 0, kw = 0, ci = k;
+            if (spatial) {
+                const int khw = k >> p.cin_shift;
+                ci = k & (p.Cin - 1);
+                kh = (khw * p.kw_rcp) >> 16;
+                kw = khw - kh * p.KW;
+            }
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-            const bool ok = kvalid && a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(xg + (size_t)(a_pix[i] + iy * p.W + ix) * p.xC + ci);
-            ra[i] = v;
+            for (int i = 0; i < A_IT; ++i) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool ok = kvalid && a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *reinterpret_cast<const uint4*>(xg + (size_t)(a_pix[i] + iy * p.W + ix) * p.xC + ci);
+                ra[i] = v;
+            }
+        } else {
+            const S* xs = reinterpret_cast<const S*>(p.x);
+            int dkh[CH], dkw[CH], dci[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int kk = k + j;
+                const int khw = p.Cin == 1 ? kk : (p.Cin == 3 ? (kk * 21846) >> 16 : kk / p.Cin);
+                dci[j] = kk - khw * p.Cin;
+                dkh[j] = kk < p.K ? (khw * p.kw_rcp) >> 16 : -100000;          // k tail: always out of the image
+                dkw[j] = khw - ((khw * p.kw_rcp) >> 16) * p.KW;
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                float v[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int iy = a_iy0[i] + dkh[j], ix = a_ix0[i] + dkw[j];
+                    const bool ok = a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    v[j] = ok ? ld_src_elem<S>(xs + (size_t)(a_pix[i] + iy * p.W + ix) * p.xC + dci[j]) * p.x_scale : 0.f;
+                }
+                T packed[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) Tr<T>::st(&packed[j], v[j]);
+                ra[i] = *reinterpret_cast<const uint4*>(packed);
+            }
         }
         const bool kvalid_w = k < p.Kp;
 #pragma unroll
@@ -495,6 +531,31 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     return hipGetLastError();
 }
 
+// first-layer (narrow-channel) launch: register-staged variant with the element-wise gather; N is 32 or 64
+template <typename T, typename S>
+static hipError_t launch_narrow(IGemmDev d, hipStream_t s) {
+    constexpr int BM = 128;
+    d.tilesM = (d.M + BM - 1) / BM;
+    const int tm8 = (d.tilesM + 7) / 8;
+    if (d.N <= 32) {
+        d.tilesN = 1;
+        const size_t lds = 2 * (size_t)(BM + 32) * 128;
+        hipLaunchKernelGGL((igemm_kernel<T, BM, 32, S>), dim3(tm8 * 8), dim3(256), lds, s, d);
+    } else {
+        d.tilesN = (d.N + 63) / 64;
+        const size_t lds = 2 * (size_t)(BM + 64) * 128;
+        hipLaunchKernelGGL((igemm_kernel<T, BM, 64, S>), dim3(tm8 * 8 * d.tilesN), dim3(256), lds, s, d);
+    }
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_narrow_src(const IGemmDev& d, int src_dt, int dt, hipStream_t s) {
+    if (src_dt == DT_F32) return launch_narrow<T, float>(d, s);
+    if (src_dt == DT_U8) return launch_narrow<T, uint8_t>(d, s);
+    if (src_dt == dt) return launch_narrow<T, T>(d, s);
+    return hipErrorInvalidValue;
+}
+
 static const int kTiles[6][2] = {{128, 128}, {128, 64}, {64, 64}, {64, 32}, {128, 32}, {64, 128}};
 
 template <typename T>
@@ -601,11 +662,21 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     const int CH = dt_chunk(dt);
     d.cin_shift = 0;
     d.kw_rcp = (65536 + g.KW - 1) / g.KW;
-    if (g.KH * g.KW > 1) {
+    if (g.KH * g.KW > 1 && g.x_src_dt < 0) {
         if (g.Cin & (g.Cin - 1)) return hipErrorInvalidValue;     // spatial kernels need power-of-two Cin
         while ((1 << d.cin_shift) < g.Cin) ++d.cin_shift;
     }
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
+    d.x_scale = g.x_scale;
+    if (g.x_src_dt >= 0) {
+        // narrow-channel first layer: element-wise gather from the raw frame
+        if ((d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || d.res || d.KH * d.KW * d.Cin != d.K) return hipErrorInvalidValue;
+        d.x_bytes = d.w_bytes = 0;
+        if (dt == DT_BF16) return launch_narrow_src<bf16>(d, g.x_src_dt, dt, s);
+        if (dt == DT_F16) return launch_narrow_src<f16>(d, g.x_src_dt, dt, s);
+        if (dt == DT_F32) return launch_narrow_src<float>(d, g.x_src_dt, dt, s);
+        return hipErrorInvalidValue;
+    }
     {
         const size_t esz = dt_size(dt);
         const size_t xb = (((size_t)d.B * d.H * d.W - 1) * d.xC + d.Cin) * esz;

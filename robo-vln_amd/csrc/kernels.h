@@ -28,6 +28,10 @@ struct IGemm {
     int ldy = 0, ldr = 0;
     int act = ACT_NONE;
     int out_f32 = 0;
+    // narrow-channel first layers (Cin = 1 or 3): x is the RAW frame of dtype x_src_dt (DT_F32 / DT_U8 / the storage
+    // type), gathered element-wise and multiplied by x_scale; -1 = x is an ordinary T activation
+    int x_src_dt = -1;
+    float x_scale = 1.0f;
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real
