@@ -146,7 +146,7 @@ int hcm_finalize(hcm_handle h) {
         if (hipMalloc((void**)&h->pred_buf, (size_t)h->cfg.max_batch * sizeof(int64_t)) != hipSuccess)
             return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
         h->arena.dry = false;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         }
@@ -293,7 +293,7 @@ void hcm_destroy(hcm_handle h) {
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }

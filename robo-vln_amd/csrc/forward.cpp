@@ -2,6 +2,7 @@
 // No allocation and no host synchronisation inside a step: every intermediate lives in the per-handle
 // workspace arena, whose size is found by running this same code once in "dry" mode at hcm_finalize().
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "model.h"
@@ -430,28 +431,28 @@ struct Fwd {
         const bool multi = ctx->concurrent && !ctx->taps_on;    // taps allocate/synchronise: keep them single-stream
         hipStream_t main_s = ctx->stream;
         hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s, a2 = multi ? ctx->aux[2] : main_s;
-        if (multi) fork_join_begin(3);
-        // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
-        on(main_s);
-        if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb);
-        // chain 1: the low-level RGB trunk
-        on(a0);
-        if (do_hi && do_lo) lo_rgb(rgb, rgb_dt, B, lb);
-        // chain 2: both depth trunks back to back (small, latency-bound kernels that fill the gaps of the RGB chains)
-        on(a1);
-        {
-            const size_t m = ar.mark();
-            size_t top = m;
-            if (do_hi) { hi_depth(depth, B, hb); top = ar.mark(); ar.release(m); }
-            if (do_lo) { lo_depth(depth, B, lb); if (ar.mark() > top) top = ar.mark(); }
-            ar.release(m);
-            ar.alloc(top - m);                                  // keep the chain's whole region reserved
-        }
+        hipStream_t a3 = multi ? ctx->aux[3] : main_s;
+        static const int skip = getenv("HCM_SKIP") ? atoi(getenv("HCM_SKIP")) : 0;   // profiling aid: drop chains (bitmask)
+        if (multi) fork_join_begin(4);
+        // Host enqueue order = start order on the GPU: the chains made of many small dependent launches go first (BERT,
+        // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
         // chain 3: BERT
         on(a2);
-        if (do_hi) hi_bert(ids, ids_dt, B, hb);
+        if (do_hi && !(skip & 8)) hi_bert(ids, ids_dt, B, hb);
+        // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
+        on(a1);
+        if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
+        static const int dsplit = getenv("HCM_DEPTH_SPLIT") ? atoi(getenv("HCM_DEPTH_SPLIT")) : 0;
+        on((do_hi && dsplit) ? a3 : a1);
+        if (do_lo && !(skip & 4)) lo_depth(depth, B, lb);
+        // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
-        if (multi) fork_join_end(3);
+        if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
+        // chain 1: the low-level RGB trunk
+        on(a0);
+        if (do_hi && do_lo && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
+        on(main_s);
+        if (multi) fork_join_end(4);
         if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);
         const int64_t* st_ids = subtask;
         if (do_hi && do_lo) {

@@ -40,6 +40,7 @@ struct IGemmDev {
     int cin_shift, kw_rcp, tilesM, tilesN;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
+    int debug;                     // ablation knobs (HCM_IGEMM_DEBUG): 1 = no loads after the prologue, 2 = no MFMA, 4 = no stores
 };
 
 template <typename T> struct Mma;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
     constexpr int RPP = 256 / TPR;         // rows per pass
     const int c8 = (tid % TPR) * 8;
     const int n = n0 + c8;
-    if (n >= p.N) return;
+    if (n >= p.N || (p.debug & 4)) return;
     const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -178,8 +179,8 @@ template <typename S> __device__ __forceinline__ float ld_src_elem(const S* p) {
 template <> __device__ __forceinline__ float ld_src_elem<bf16>(const bf16* p) { return bf2f(p->v); }
 template <> __device__ __forceinline__ float ld_src_elem<f16>(const f16* p) { return Tr<f16>::ld(p); }
 
-template <typename T, int BM, int BN, typename S = void>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
+template <typename T, int BM, int BN, typename S = void, int PF = 1>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
     constexpr int CH = Tr<T>::CH;          // elements per 16-byte chunk
     constexpr int BK = 8 * CH;             // elements per 128-byte tile row
     constexpr int TM = BM / 32;            // 16-wide pixel tiles per wave
@@ -230,8 +231,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
     const T* wg = reinterpret_cast<const T*>(p.w);
     const bool spatial = (p.KH * p.KW) > 1;
 
-    uint4 ra[A_IT], rb[B_IT];
-    auto load_tiles = [&](int kt) {
+    // PF register sets: with PF = 2 the loads of tile t+2 are issued while tile t+1 is still in flight (two tiles of
+    // loads outstanding per workgroup: in-flight bytes, not LDS capacity, bound the latency-limited shapes)
+    uint4 rsa[PF][A_IT], rsb[PF][B_IT];
+    auto load_tiles = [&](int kt, auto SET) {
+        uint4 (&ra)[A_IT] = rsa[decltype(SET)::value];
+        uint4 (&rb)[B_IT] = rsb[decltype(SET)::value];
         const int k = kt * BK + c * CH;
         if constexpr (std::is_void<S>::value) {
             const bool kvalid = k < p.K;
@@ -285,7 +290,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
             rb[i] = v;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto SET) {
+        uint4 (&ra)[A_IT] = rsa[decltype(SET)::value];
+        uint4 (&rb)[B_IT] = rsb[decltype(SET)::value];
         char* sa = smem + buf * TILE_BYTES;
         char* sb = sa + BM * 128;
 #pragma unroll
@@ -307,16 +314,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
     const int fr = lane & 15;      // fragment row (pixel for A-tile, channel for W-tile)
     const int fg = lane >> 4;      // 16-byte chunk within the 64-byte half row
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    auto compute = [&](int cur) {
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -338,8 +341,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmDev p) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], wb[i], xa[j]);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+    };
+
+    load_tiles(0, S0{});
+    store_tiles(0, S0{});
+    if constexpr (PF == 1) {
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tiles(kt + 1, S0{});
+            compute(cur);
+            if (kt + 1 < nk) store_tiles(cur ^ 1, S0{});
+            __syncthreads();
+        }
+    } else {
+        if (nk > 1) load_tiles(1, S1{});
+        __syncthreads();
+        // iteration kt: request tile kt+2 into the set tile kt just vacated, compute tile kt, park tile kt+1 in LDS
+        auto iter = [&](int kt, auto LOADSET, auto STORESET) {
+            if (kt + 2 < nk) load_tiles(kt + 2, LOADSET);
+            compute(kt & 1);
+            if (kt + 1 < nk) store_tiles((kt + 1) & 1, STORESET);
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            iter(kt, S0{}, S1{});
+            if (kt + 1 < nk) iter(kt + 1, S1{}, S0{});
+        }
     }
 
     igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
@@ -472,7 +500,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + (NBUF - 1) < nk;
         // ring slot of tile kt+NBUF-1: it was last read in iteration kt-1, which every wave has left (barrier)
-        if (more) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
+        if (more && !(p.debug & 1)) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -492,11 +520,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], wb[i], xa[j]);
+                for (int j = 0; j < TM; ++j) { if (!(p.debug & 2)) Mma<T>::run(acc[i][j], wb[i], xa[j]); else { acc[i][j][0] += __uint_as_float(wb[i].x ^ xa[j].x); } }
         }
         // tile kt+1 must be complete before the next iteration reads it; with the 3-deep ring the tile requested in this
         // iteration may stay in flight across the barrier
-        if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        if (NBUF == 3 && more && !(p.debug & 1)) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur == NBUF - 1 ? 0 : cur + 1;
@@ -504,7 +532,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
     igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
 }
 
-// variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring
+// variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring, 3 = register-staged with two
+// register sets (prefetch distance 2)
 template <typename T, int BM, int BN>
 static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesM = (d.M + BM - 1) / BM;
@@ -516,9 +545,10 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     if (lds_c > lds) lds = lds_c;
     static bool attr_done = false;                            // one flag per template instantiation
     if (!attr_done) {
-        const void* fns[3] = {reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
+        const void* fns[4] = {reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
                               reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2>),
-                              reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3>)};
+                              reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3>),
+                              reinterpret_cast<const void*>(igemm_kernel<T, BM, BN, void, 2>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -526,6 +556,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         attr_done = true;
     }
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
+    else if (variant == 3) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, void, 2>), dim3(grid), dim3(256), lds, s, d);
     else if (variant == 1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, s, d);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, s, d);
     return hipGetLastError();
@@ -629,7 +660,7 @@ static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best
     if (rc != hipSuccess) return rc;
     float best = 1e30f;
     int best_c = heuristic_choice(d, dt);
-    for (int c = 0; c < 18; ++c) {
+    for (int c = 0; c < 24; ++c) {
         if (!candidate_ok(d, c)) continue;
         if ((rc = launch_dt(d, dt, c, s)) != hipSuccess) break;         // warm-up (also sets the LDS attribute)
         float tmin = 1e30f;
@@ -668,6 +699,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     }
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
     d.x_scale = g.x_scale;
+    static const int dbg = getenv("HCM_IGEMM_DEBUG") ? atoi(getenv("HCM_IGEMM_DEBUG")) : 0;
+    d.debug = dbg;
     if (g.x_src_dt >= 0) {
         // narrow-channel first layer: element-wise gather from the raw frame
         if ((d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || d.res || d.KH * d.KW * d.Cin != d.K) return hipErrorInvalidValue;

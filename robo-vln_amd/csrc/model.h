@@ -134,8 +134,8 @@ struct hcm_ctx {
     bool taps_on = false;
     std::map<std::string, hcm::Tap> taps;
     hipStream_t stream = nullptr;   // the caller's stream of the current call
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams of the encoder chains (forward.cpp step())
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the encoder chains (forward.cpp step())
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool concurrent = true;
     bool failed = false;            // a launch failed during the current forward
 };
