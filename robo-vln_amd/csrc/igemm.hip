@@ -40,7 +40,6 @@ struct IGemmDev {
     int cin_shift, kw_rcp, tilesM, tilesN;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
-    int debug;                     // ablation knobs (HCM_IGEMM_DEBUG): 1 = no loads after the prologue, 2 = no MFMA, 4 = no stores
 };
 
 template <typename T> struct Mma;
@@ -90,7 +89,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
     constexpr int RPP = 256 / TPR;         // rows per pass
     const int c8 = (tid % TPR) * 8;
     const int n = n0 + c8;
-    if (n >= p.N || (p.debug & 4)) return;
+    if (n >= p.N) return;
     const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + (NBUF - 1) < nk;
         // ring slot of tile kt+NBUF-1: it was last read in iteration kt-1, which every wave has left (barrier)
-        if (more && !(p.debug & 1)) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
+        if (more) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -520,11 +519,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) { if (!(p.debug & 2)) Mma<T>::run(acc[i][j], wb[i], xa[j]); else { acc[i][j][0] += __uint_as_float(wb[i].x ^ xa[j].x); } }
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], wb[i], xa[j]);
         }
         // tile kt+1 must be complete before the next iteration reads it; with the 3-deep ring the tile requested in this
         // iteration may stay in flight across the barrier
-        if (NBUF == 3 && more && !(p.debug & 1)) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur == NBUF - 1 ? 0 : cur + 1;
@@ -699,8 +698,6 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     }
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
     d.x_scale = g.x_scale;
-    static const int dbg = getenv("HCM_IGEMM_DEBUG") ? atoi(getenv("HCM_IGEMM_DEBUG")) : 0;
-    d.debug = dbg;
     if (g.x_src_dt >= 0) {
         // narrow-channel first layer: element-wise gather from the raw frame
         if ((d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || d.res || d.KH * d.KW * d.Cin != d.K) return hipErrorInvalidValue;
