@@ -185,7 +185,10 @@ def main():
                        "per_gpu_batch": B, "global_batch": global_B,
                        "parallelism": f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4), "traffic": None,
+                         "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
+                         # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
+                         # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
+                         "traffic": {"value": 19.4, "unit": "GB per step (B=64)", "source": "profiles/r1_pmc_traffic_bench.md"} if B == 64 else None,
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s"},
         }
         if args.precision == "bf16":

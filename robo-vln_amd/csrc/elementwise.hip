@@ -1,6 +1,7 @@
 // Memory-bound kernels of the HCM step: first-layer im2col, pooling, GroupNorm, LayerNorm, BERT
 // embeddings, recurrent cells + heads, small glue.  All are HBM/L2-bound: 16-byte vector accesses,
 // grid-stride loops, wave64 reductions.
+#include <cstdlib>
 #include "kernels.h"
 #include "dev.h"
 
@@ -299,6 +300,11 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
     }
 }
 
+static long gn_slab_limit() {
+    static const long v = getenv("HCM_GN_SLAB") ? atol(getenv("HCM_GN_SLAB")) : 32768;
+    return v;
+}
+
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* /*stats*/, int dt, int B,
                             int HW, int C, int G, float eps, int relu, hipStream_t s) {
     const int CH = dt_chunk(dt);
@@ -308,7 +314,7 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
     int unit = Cg > CH ? Cg : CH;
     if (unit % Cg || unit % CH) return hipErrorInvalidValue;
     int CS = unit;
-    while (CS * 2 <= C && CS * 2 <= 256 && (CS * 2) / CH <= 32 && (long)HW * CS * 2 <= 32768 && C % (CS * 2) == 0) CS *= 2;
+    while (CS * 2 <= C && CS * 2 <= 256 && (CS * 2) / CH <= 32 && (long)HW * CS * 2 <= gn_slab_limit() && C % (CS * 2) == 0) CS *= 2;
     const int cpr = CS / CH;
     if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) return hipErrorInvalidValue;
     const int grid = B * (C / CS);

@@ -37,7 +37,7 @@ struct IGemmDev {
     const char* x; const char* w; const float* bias; const char* res; char* y;
     int B, H, W, Cin, xC, Ho, Wo, KH, KW, stride, pad;
     int M, N, K, Kp, ldy, ldr, act, out_f32;
-    int cin_shift, kw_rcp, tilesM, tilesN;
+    int cin_shift, kw_rcp, tilesM, tilesN, map;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
 };
@@ -61,6 +61,27 @@ template <> struct Mma<float> {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
 };
+
+// XCD-aware tile order (block b runs on XCD b % 8, each XCD has a private 4 MB L2).
+//   map 0: the XCD owns whole pixel-tiles (tile_m = 8j + xcd) and walks all channel tiles of one before the next: the
+//          gathered activation rows are re-read from that XCD's L2, the (small) weight matrix is resident everywhere.
+//   map 1: for big weight matrices (> ~2 MB: the BERT GEMMs) the XCD owns a contiguous slice of the CHANNEL tiles
+//          instead, so its slice of the weights stays L2-resident while the activations stream through once per XCD.
+__device__ __forceinline__ bool tile_of_block(const IGemmDev& p, int bid, int& tile_m, int& tile_n) {
+    const int xcd = bid & 7;
+    const int local = bid >> 3;
+    if (p.map == 0) {
+        tile_n = local % p.tilesN;
+        tile_m = (local / p.tilesN) * 8 + xcd;
+        return tile_m < p.tilesM;
+    }
+    const int n_lo = (xcd * p.tilesN) >> 3, n_hi = ((xcd + 1) * p.tilesN) >> 3;   // this XCD's channel tiles
+    const int nn = n_hi - n_lo;
+    if (nn <= 0) return false;
+    tile_m = local / nn;
+    tile_n = n_lo + local % nn;
+    return tile_m < p.tilesM;
+}
 
 // Shared epilogue of both kernel variants (see the comment at its top).
 template <typename T, int BM, int BN>
@@ -192,12 +213,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
 
     // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole pixel-tiles (all channel tiles of
     // one pixel tile back to back) so the gathered activation rows are re-read from that XCD's L2.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int local = bid >> 3;
-    const int tile_n = local % p.tilesN;
-    const int tile_m = (local / p.tilesN) * 8 + xcd;
-    if (tile_m >= p.tilesM) return;
+    int tile_m, tile_n;
+    if (!tile_of_block(p, blockIdx.x, tile_m, tile_n)) return;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -416,12 +433,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int local = bid >> 3;
-    const int tile_n = local % p.tilesN;
-    const int tile_m = (local / p.tilesN) * 8 + xcd;
-    if (tile_m >= p.tilesM) return;
+    int tile_m, tile_n;
+    if (!tile_of_block(p, blockIdx.x, tile_m, tile_n)) return;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -538,7 +551,13 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesM = (d.M + BM - 1) / BM;
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
-    const int grid = tm8 * 8 * d.tilesN;
+    int grid = tm8 * 8 * d.tilesN;
+    static const char* fmap = getenv("HCM_IGEMM_MAP");
+    d.map = fmap ? atoi(fmap) : (((size_t)d.N * d.Kp * sizeof(T) > (2u << 20)) && d.tilesN >= 8 ? 1 : 0);
+    if (d.map == 1) {
+        if (d.tilesN < 8) d.map = 0;
+        else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);       // every XCD gets ceil(tilesN/8) slots per pixel tile
+    }
     size_t lds = (variant == 2 ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
     if (lds_c > lds) lds = lds_c;
@@ -566,6 +585,7 @@ template <typename T, typename S>
 static hipError_t launch_narrow(IGemmDev d, hipStream_t s) {
     constexpr int BM = 128;
     d.tilesM = (d.M + BM - 1) / BM;
+    d.map = 0;
     const int tm8 = (d.tilesM + 7) / 8;
     if (d.N <= 32) {
         d.tilesN = 1;
