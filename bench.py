@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="environments per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +134,7 @@ def main():
     B = args.batch
     global_B = B * world
     hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank
-    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=args.precision)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=args.precision, graph=not args.no_graph)
     # this rank's contiguous block of environments e -> rank e // B
     lo_e, hi_e = shard_range(global_B, world, rank)
     obs_np = synth.make_observations(cfg, B, step=rank, seed=0)    # distinct frames per rank, same shapes
@@ -149,9 +150,11 @@ def main():
 
     def step(mask):
         nonlocal hh, lh
-        _, hh, lh = eng.act(obs, hh, lh, mask, out=rec)
+        r, hh, lh = eng.act(obs, hh, lh, mask)
         if use_dist:
-            gather_records(rec, all_rec)            # ONE RCCL all-gather of the (B,7) records per step
+            gather_records(r, all_rec)              # ONE RCCL all-gather of the (B,7) records per step
+        else:
+            rec.copy_(r)
 
     step(mask0)
     for _ in range(max(0, args.warmup - 1)):
@@ -191,6 +194,7 @@ def main():
                          "traffic": {"value": 19.4, "unit": "GB per step (B=64)", "source": "profiles/r1_pmc_traffic_bench.md"} if B == 64 else None,
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s"},
         }
+        out["config"]["hipgraph"] = {"enabled": not args.no_graph, "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
         if args.precision == "bf16":
             try:
                 out["roofline"]["dominant_kernel"] = dominant_kernel_probe(B)

@@ -48,7 +48,9 @@ enum hcm_query_what {
     HCM_RECORD_WIDTH = 3,          /* 7 = 4 logits + (v, w) + stop logit */
     HCM_WORKSPACE_BYTES = 4,
     HCM_WEIGHT_BYTES = 5,
-    HCM_MAX_BATCH = 6
+    HCM_MAX_BATCH = 6,
+    HCM_GRAPH_LAUNCHES = 7,        /* hcm_act calls served by a captured hipGraph replay */
+    HCM_EAGER_LAUNCHES = 8
 };
 
 /* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,
@@ -114,7 +116,9 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
                     float* vel, float* stop, float* h_out, void* stream);
 
 /* The caller-side step of the eval loop, hierarchical_trainer.py:1095-1101: high -> argmax(dim=1) -> low.
- *   record (B,7) f32 out: [4 sub-task logits, lin_vel, ang_vel, stop logit]. */
+ *   record (B,7) f32 out: [4 sub-task logits, lin_vel, ang_vel, stop logit].
+ * When called repeatedly with the same pointers on a non-default stream, the step (all forked encoder streams
+ * included) is captured into a hipGraph on the second call and replayed afterwards (HCM_GRAPH=0 disables). */
 int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
             const void* ids, int ids_dtype, int B,
             const float* hi_h_in, const float* lo_h_in, const float* mask,

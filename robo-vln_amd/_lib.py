@@ -11,7 +11,7 @@ HCM_HIGH, HCM_LOW = 0, 1
 HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
- HCM_WEIGHT_BYTES, HCM_MAX_BATCH) = range(7)
+ HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES) = range(9)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: KeyError, -4: ValueError, -5: RuntimeError, -6: ValueError,

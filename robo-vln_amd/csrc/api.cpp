@@ -152,6 +152,7 @@ int hcm_finalize(hcm_handle h) {
         }
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
+        if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
         // one tuning step at max_batch on scratch inputs: every conv / linear shape of the plan picks its fastest
         // tile + staging variant (igemm.hip); steady-state calls then never synchronise the host
         // (opt-in: HCM_TUNE=1.  Isolated per-kernel timings rank variants differently from the concurrent multi-stream
@@ -260,13 +261,60 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, co
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     REQUIRE(h->cfg.num_actions + h->cfg.lo_actions + 1 == 7, HCM_ERR_UNSUPPORTED, "record layout assumes 4 + 2 + 1 outputs");
     h->stream = (hipStream_t)stream;
+    const int ld = 7;
+    auto eager = [&]() -> int {
+        try {
+            run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
+                     record + 6, ld, hi_h_out, lo_h_out);
+        } catch (const std::exception& e) {
+            return fail(h, HCM_ERR_HIP, e.what());
+        }
+        ++h->eager_launches;
+        return HCM_OK;
+    };
+    // the legacy default stream cannot be captured; taps allocate and synchronise
+    if (!h->use_graph || h->taps_on || stream == nullptr) return eager();
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
+                                       (uint64_t)hi_h_in, (uint64_t)lo_h_in, (uint64_t)mask, (uint64_t)record, (uint64_t)hi_h_out,
+                                       (uint64_t)lo_h_out, (uint64_t)stream};
+    for (auto& g : h->graphs)
+        if (g.key == key) {
+            if (hipGraphLaunch(g.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
+            ++h->graph_launches;
+            return HCM_OK;
+        }
+    bool seen = false;
+    for (auto& k : h->seen_keys) seen = seen || k == key;
+    if (!seen) {                                   // first sight: eager (also performs one-time kernel attribute setup)
+        if (h->seen_keys.size() >= 16) h->seen_keys.erase(h->seen_keys.begin());
+        h->seen_keys.push_back(key);
+        return eager();
+    }
+    // second sight: capture the whole step (the forked side streams join the capture through their events)
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(); }
+    std::string cap_err;
     try {
-        const int ld = 7;
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
-    } catch (const std::exception& e) {
-        return fail(h, HCM_ERR_HIP, e.what());
+    } catch (const std::exception& e) { cap_err = e.what(); }
+    hipGraph_t graph = nullptr;
+    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (!cap_err.empty() || ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        h->use_graph = false;                      // do not retry on this handle
+        if (!cap_err.empty()) return fail(h, HCM_ERR_HIP, "graph capture failed: " + cap_err);
+        return eager();
     }
+    hcm_ctx::GraphEntry ge;
+    ge.key = key;
+    ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ce != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return eager(); }
+    if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+    h->graphs.push_back(ge);
+    if (hipGraphLaunch(ge.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
+    ++h->graph_launches;
     return HCM_OK;
 }
 
@@ -280,6 +328,8 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_WORKSPACE_BYTES: *out = (int64_t)h->arena.cap; break;
         case HCM_WEIGHT_BYTES: *out = (int64_t)h->weight_bytes; break;
         case HCM_MAX_BATCH: *out = h->cfg.max_batch; break;
+        case HCM_GRAPH_LAUNCHES: *out = h->graph_launches; break;
+        case HCM_EAGER_LAUNCHES: *out = h->eager_launches; break;
         default: return fail(h, HCM_ERR_ARG, "hcm_query: unknown selector");
     }
     return HCM_OK;
@@ -293,6 +343,7 @@ void hcm_destroy(hcm_handle h) {
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 4; ++i) {
         if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);

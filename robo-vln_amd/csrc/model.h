@@ -137,5 +137,12 @@ struct hcm_ctx {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the encoder chains (forward.cpp step())
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool concurrent = true;
+    // hipGraph cache of the fused step (hcm_act): keyed by (B, dtypes, every pointer argument).  A key is run eagerly the
+    // first time it is seen and captured (all forked streams included) the second time; replays cost one graph launch.
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; };
+    std::vector<GraphEntry> graphs;
+    std::vector<std::vector<uint64_t>> seen_keys;
+    bool use_graph = true;
+    int64_t graph_launches = 0, eager_launches = 0;
     bool failed = false;            // a launch failed during the current forward
 };

@@ -60,10 +60,16 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="bf16", device=None, sub_precision=None):
+                 precision="bf16", device=None, sub_precision=None, graph=False):
         """precision: "bf16" (16-bit storage + MFMA with fp32 accumulate; by default the GroupNorm depth trunk uses
         fp16 tiles and everything else bf16, recurrent cells/heads fp32) or "fp32".  `sub_precision` overrides the
-        storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb)."""
+        storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
+        graph=True: act() runs on an engine-owned stream with engine-owned static I/O buffers, so that libhcm replays
+        one captured hipGraph per step; the returned record / hidden tensors then alias those buffers and stay valid
+        until the second-next act() call (ping-pong), which is what a rollout loop that rebinds them every step needs."""
+        self._graph = bool(graph)
+        self._gstream = None
+        self._static = None
         cfg.validate()
         self.cfg = cfg
         self.max_batch = max_batch
@@ -180,7 +186,42 @@ class HCMEngine:
                                                  stop.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
+    def _act_graph(self, observations, hi_hidden, lo_hidden, masks):
+        with torch.cuda.device(self.device):
+            rgb, depth, ids, B = self._obs(observations, True)
+            hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
+            if self._gstream is None:
+                self._gstream = torch.cuda.Stream(device=self.device)
+            st = self._static
+            if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype:
+                st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth), "ids": torch.empty_like(ids),
+                      "mask": torch.empty_like(m), "rec": [torch.empty(B, 7, device=self.device) for _ in range(2)],
+                      "hh": [torch.zeros_like(hh) for _ in range(2)], "lh": [torch.zeros_like(lh) for _ in range(2)]}
+                self._static = st
+            cur = torch.cuda.current_stream()
+            gs = self._gstream
+            gs.wait_stream(cur)
+            with torch.cuda.stream(gs):
+                i = st["tick"] & 1
+                for dst, src in ((st["rgb"], rgb), (st["depth"], depth), (st["ids"], ids), (st["mask"], m),
+                                 (st["hh"][1 - i], hh), (st["lh"][1 - i], lh)):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src, non_blocking=True)
+                _lib.check(self._lib.hcm_act(self._h, st["rgb"].data_ptr(), _TORCH_DT[rgb.dtype], st["depth"].data_ptr(),
+                                             st["ids"].data_ptr(), _TORCH_DT[ids.dtype], B, st["hh"][1 - i].data_ptr(),
+                                             st["lh"][1 - i].data_ptr(), st["mask"].data_ptr(), st["rec"][i].data_ptr(),
+                                             st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), C.c_void_p(gs.cuda_stream)), self._h)
+                st["tick"] += 1
+            cur.wait_stream(gs)
+        return st["rec"][i], st["hh"][i], st["lh"][i]
+
     def act(self, observations, hi_hidden, lo_hidden, masks, out=None):
+        if self._graph:
+            rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks)
+            if out is not None:
+                out.copy_(rec)
+                rec = out
+            return rec, hh2, lh2
         with torch.cuda.device(self.device):
             rgb, depth, ids, B = self._obs(observations, True)
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)

@@ -61,3 +61,33 @@ def test_uint8_rgb_equals_float_rgb():
     a = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=False)
     b = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=True)
     assert np.array_equal(a["records"], b["records"])
+
+
+def test_hipgraph_replay_equals_eager():
+    """act() served by the captured hipGraph (engine-owned stream + static I/O) must equal the eager multi-stream path
+    bit for bit over a multi-step rollout with an episode reset."""
+    import torch
+    from oracle import cases
+    from robo_vln_amd import synth
+    from robo_vln_amd.policy import HCMEngine
+    cfg, B, T, which = cases.case_config("cfg0_128_L20_N2")
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=cases.SEED)
+    outs = []
+    for graph in (False, True):
+        eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
+        R = cfg.num_recurrent_layers
+        hh = torch.zeros(R, B, cfg.hidden, device="cuda")
+        lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+        recs = []
+        for t in range(6):
+            obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, step=t % 3, seed=cases.SEED).items()}
+            m = torch.from_numpy(cases.step_masks(B, t % 3)).cuda()
+            rec, hh, lh = eng.act(obs, hh, lh, m)
+            recs.append(rec.clone().cpu())
+        torch.cuda.synchronize()
+        if graph:
+            assert eng.query(7) >= 3, "the hipGraph path was not taken"
+        outs.append((torch.stack(recs), hh.clone().cpu(), lh.clone().cpu()))
+        eng.close()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
