@@ -84,11 +84,12 @@ __device__ __forceinline__ bool tile_of_block(const IGemmDev& p, int bid, int& t
 }
 
 // Shared epilogue of both kernel variants (see the comment at its top).
-template <typename T, int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / 32][BM / 32], char* smem, int m0, int n0,
+template <typename T, int BM, int BN, int NW = 4>
+__device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / (NW / 2) / 16][BM / 32], char* smem, int m0, int n0,
                                                int tid, int wm, int wn, int fr, int fg) {
+    constexpr int WNc = NW / 2;            // waves along the channel axis (2 along the pixel axis)
     constexpr int TM = BM / 32;
-    constexpr int TN = BN / 32;
+    constexpr int TN = BN / WNc / 16;
     // ---- epilogue ----
     // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
     // output tile (the A/B tiles are dead: the K loop ended with a barrier).  Phase 2: each thread takes 8
@@ -102,12 +103,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int r = wm * (BM / 2) + j * 16 + fr;
-            const int cc = wn * (BN / 2) + i * 16 + fg * 4;
+            const int cc = wn * (BN / WNc) + i * 16 + fg * 4;
             *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
     __syncthreads();
     constexpr int TPR = BN / 8;            // threads per tile row
-    constexpr int RPP = 256 / TPR;         // rows per pass
+    constexpr int RPP = 64 * NW / TPR;     // rows per pass
     const int c8 = (tid % TPR) * 8;
     const int n = n0 + c8;
     if (n >= p.N) return;
@@ -419,14 +420,18 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
-template <typename T, int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
+// NW = 4 (2x2 waves, wave tile BM/2 x BN/2) or 8 (2x4 waves, wave tile BM/2 x BN/4: twice the waves per SIMD on the same
+// LDS footprint -- more thread-level parallelism to cover ds_read / DMA-issue latency)
+template <typename T, int BM, int BN, int NBUF, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     constexpr int CH = Tr<T>::CH;
     constexpr int BK = 8 * CH;
+    constexpr int WNc = NW / 2;
     constexpr int TM = BM / 32;
-    constexpr int TN = BN / 32;
-    constexpr int A_IT = BM / 32;          // wave-level DMA instructions per tile (8 rows each)
-    constexpr int B_IT = BN / 32;
+    constexpr int TN = BN / WNc / 16;
+    constexpr int A_IT = BM / 8 / NW;      // wave-level DMA instructions per tile (8 rows each)
+    constexpr int B_IT = BN / 8 / NW;
+    static_assert(A_IT >= 1 && B_IT >= 1 && TN >= 1, "tile too small for this wave count");
     constexpr int LPT = A_IT + B_IT;       // DMA instructions per wave per K tile
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNc, wn = wave % WNc;
     const int rin = lane >> 3;                 // row inside the 8-row DMA group
     const int c = (lane & 7) ^ rin;            // source chunk this lane fetches (swizzle on the source side)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave + 4 * i) * 8 + rin;
+        const int m = m0 + (wave + NW * i) * 8 + rin;
         if (m < p.M) {
             const int b = m / HoWo;
             const int rem = m - b * HoWo;
@@ -483,14 +488,14 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
             const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
             const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * (unsigned)sizeof(T);
-            dma16(sa + (wave + 4 * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+            dma16(sa + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + (wave + 4 * i) * 8 + rin;
+            const int n = n0 + (wave + NW * i) * 8 + rin;
             const bool ok = (k < p.Kp) & (n < p.N);
             const unsigned off = (unsigned)(n * p.Kp + k) * (unsigned)sizeof(T);
-            dma16(sb + (wave + 4 * i) * 1024, ok ? off : 0xFFFFFFFFu, rw);
+            dma16(sb + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rw);
         }
     };
 
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const int r = wn * (BN / 2) + i * 16 + fr;
+                const int r = wn * (BN / WNc) + i * 16 + fr;
                 wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
             }
 #pragma unroll
@@ -541,11 +546,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(IGemmDev p) {
         __builtin_amdgcn_s_barrier();
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
-    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    igemm_epilogue<T, BM, BN, NW>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
 }
 
 // variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring, 3 = register-staged with two
-// register sets (prefetch distance 2)
+// register sets (prefetch distance 2), 4 / 5 = variants 1 / 2 with 8 waves per workgroup
 template <typename T, int BM, int BN>
 static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesM = (d.M + BM - 1) / BM;
@@ -558,7 +563,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         if (d.tilesN < 8) d.map = 0;
         else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);       // every XCD gets ceil(tilesN/8) slots per pixel tile
     }
-    size_t lds = (variant == 2 ? 3 : 2) * (size_t)(BM + BN) * 128;
+    size_t lds = ((variant == 2 || variant == 5) ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
     if (lds_c > lds) lds = lds_c;
     static bool attr_done = false;                            // one flag per template instantiation
@@ -571,7 +576,21 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
+        if constexpr (BN >= 64) {
+            const void* f8[2] = {reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2, 8>),
+                                 reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8>)};
+            for (const void* f : f8) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
+        }
         attr_done = true;
+    }
+    if constexpr (BN >= 64) {
+        if (variant == 4) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8>), dim3(grid), dim3(512), lds, s, d); return hipGetLastError(); }
+        if (variant == 5) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8>), dim3(grid), dim3(512), lds, s, d); return hipGetLastError(); }
+    } else {
+        if (variant >= 4) variant -= 3;             // no 8-wave instantiation for 32-wide channel tiles
     }
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
     else if (variant == 3) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, void, 2>), dim3(grid), dim3(256), lds, s, d);
@@ -636,15 +655,19 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
     const long b64128 = cdiv(d.M, 64) * cdiv(d.N, 128);
     const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
-    int tile;       // index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
-    if (d.N <= 32) tile = 3;
-    else if (d.N <= 64) tile = (d.K >= 512 && d.M >= 65536) ? 1 : (b64 >= 256 ? 2 : 3);
-    else if (d.K <= 256) tile = b64128 >= 512 ? 5 : (b64 >= 256 ? 2 : 3);
-    else if (b128 >= 512) tile = 0;
-    else if (b64128 >= 384) tile = 5;
-    else if (b64 >= 256) tile = 2;
-    else tile = 3;
-    const int variant = (d.K >= 2048 && (tile == 2 || tile == 3) && d.M > 64) ? 2 : 1;
+    // tile index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
+    // variant: 1 dma2, 2 dma3 (4 waves); 4 dma2, 5 dma3 (8 waves)
+    int tile, variant;
+    const bool longk = d.K >= 1024;
+    if (d.N <= 32) { tile = 3; variant = d.K >= 2048 ? 2 : 1; }
+    else if (d.N <= 64) {
+        tile = d.M >= 65536 ? 1 : (b64 >= 256 ? 2 : 3);
+        variant = tile == 3 ? (d.K >= 2048 ? 2 : 1) : 4;
+    }
+    else if (d.M <= 64) { tile = 3; variant = 1; }
+    else if (b128 >= 512) { tile = 0; variant = 4; }
+    else if (b64128 >= 128) { tile = 5; variant = longk ? 5 : 4; }
+    else { tile = b64 >= 256 ? 2 : 3; variant = d.K >= 2048 ? 2 : 1; }
     (void)dt;
     return variant * 6 + tile;
 }
@@ -679,7 +702,7 @@ static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best
     if (rc != hipSuccess) return rc;
     float best = 1e30f;
     int best_c = heuristic_choice(d, dt);
-    for (int c = 0; c < 24; ++c) {
+    for (int c = 0; c < 36; ++c) {
         if (!candidate_ok(d, c)) continue;
         if ((rc = launch_dt(d, dt, c, s)) != hipSuccess) break;         // warm-up (also sets the LDS attribute)
         float tmin = 1e30f;
