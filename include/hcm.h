@@ -115,6 +115,17 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
                     const float* h_in, const float* mask, const int64_t* subtask,
                     float* vel, float* stop, float* h_out, void* stream);
 
+/* Training / validation path: the models are called on T*N frames at once
+ * (hierarchical_trainer.py:505-506,:539 and :575-576,:613) and RNNStateEncoder.forward takes the seq_forward branch
+ * (models/decoder/state_encoder.py:83-133): encoders on all T*N frames, then a T-step masked recurrent scan.
+ *   rgb/depth/ids/subtask: T*N rows, time-major (row t*N + n);  masks (T*N,) f32;  h_in/h_out (R,N,hidden);
+ *   logits (T*N,num_actions) / vel (T*N,2) / stop (T*N,1).  T*N must not exceed max_batch.  Inference only (no autograd). */
+int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
+                         int T, int N, const float* h_in, const float* masks, float* logits, float* h_out, void* stream);
+int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, int T, int N,
+                        const float* h_in, const float* masks, const int64_t* subtask,
+                        float* vel, float* stop, float* h_out, void* stream);
+
 /* The caller-side step of the eval loop, hierarchical_trainer.py:1095-1101: high -> argmax(dim=1) -> low.
  *   record (B,7) f32 out: [4 sub-task logits, lin_vel, ang_vel, stop logit].
  * When called repeatedly with the same pointers on a non-default stream, the step (all forked encoder streams

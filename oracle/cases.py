@@ -54,3 +54,33 @@ def subsample(a):
 def fixed_subtask(batch, step):
     """For low-level-only cases the sub-task ids are scripted instead of coming from a high-level argmax."""
     return ((np.arange(batch) + step) % 4).astype(np.int64)
+
+
+# Training-path (seq_forward) cases: name -> (config kwargs, T, N)
+# The reference's in-tree RNNStateEncoder.seq_forward calls `.detach()` on the unpacked hidden state
+# (models/decoder/state_encoder.py:131), which is a tuple for LSTM -> AttributeError: with the in-tree copy the sequence
+# path only runs for GRU, so only the GRU case has a golden; the LSTM case is checked HIP-vs-oracle (the oracle's LSTM
+# cell is pinned by the single-step goldens, its scan logic by the GRU sequence golden).
+SEQ_CASES = {
+    "seq_T4_N2_gru": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2, rnn_type="GRU"), 4, 2),
+}
+SEQ_CASES_ORACLE_ONLY = {
+    "seq_T4_N2_lstm": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2), 4, 2),
+}
+
+
+def seq_masks(T, N):
+    """(T*N,) time-major masks: every env starts at t=0; env 1 is reset at t=2 (a segment boundary for seq_forward)."""
+    m = np.ones((T, N), dtype=np.float32)
+    m[0, :] = 0
+    if T > 2:
+        m[2, 1 % N] = 0
+    return m.reshape(-1)
+
+
+def seq_observations(cfg, T, N):
+    """T*N frames, time-major (row t*N + n); the instruction of env n repeated at every step (as the trainer's collate does)."""
+    obs = synth.make_observations(cfg, T * N, step=7, seed=SEED)
+    ids = synth.make_observations(cfg, N, step=0, seed=SEED)["instruction"]
+    obs["instruction"] = np.tile(ids, (T, 1))
+    return obs

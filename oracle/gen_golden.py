@@ -138,10 +138,45 @@ def compare_oracle(name, gold, hi_sd, lo_sd):
     return worst
 
 
+def run_seq_case(name):
+    """Reference models called on T*N frames with an (R,N,H) hidden state: RNNStateEncoder.seq_forward path."""
+    kw, T, N = cases.SEQ_CASES[name]
+    cfg = cases.HCMConfig(**kw).validate()
+    hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
+    hi, lo = ref_shims.build_models(cfg, hi_sd, lo_sd)
+    obs_np = cases.seq_observations(cfg, T, N)
+    obs = {k: torch.from_numpy(v.astype(np.float32)) for k, v in obs_np.items()}
+    m = cases.seq_masks(T, N)
+    masks = torch.from_numpy(m).view(-1, 1).expand(-1, 2).contiguous()
+    R = cfg.num_recurrent_layers
+    g = torch.Generator().manual_seed(3)
+    h0 = (torch.rand(R, N, cfg.hidden, generator=g) - 0.5)
+    st = torch.from_numpy(cases.fixed_subtask(T * N, 1))
+    prev = torch.zeros(T * N, 2, dtype=torch.long)
+    with torch.no_grad():
+        logits, hi_h = hi((dict(obs), h0.clone(), prev, masks))
+        vel, stop, lo_h = lo((dict(obs), h0.clone(), prev, masks, st))
+    out = {"logits": logits.numpy(), "vel": vel.numpy(), "stop": stop.numpy(), "hi_hidden": hi_h.numpy(), "lo_hidden": lo_h.numpy(),
+           "h0": h0.numpy(),
+           "meta": np.array(repr(dict(case=name, T=T, N=N, config=repr(cfg.to_dict()),
+                                      note="reference hi/lo forward with T*N frames and an (R,N,H) hidden state -> seq_forward")))}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    # oracle cross-check
+    ho = hcm_oracle.HighLevelOracle(cfg, hi_sd)
+    lo_o = hcm_oracle.LowLevelOracle(cfg, lo_sd)
+    l2, h2 = ho.forward(obs_np, h0.clone(), m)
+    v2, s2, lh2 = lo_o.forward(obs_np, h0.clone(), m, st)
+    worst = max(np.abs(l2.numpy() - out["logits"]).max(), np.abs(h2.numpy() - out["hi_hidden"]).max(),
+                np.abs(v2.numpy() - out["vel"]).max(), np.abs(s2.numpy() - out["stop"]).max(), np.abs(lh2.numpy() - out["lo_hidden"]).max())
+    print(f"[{name}] seq_forward T={T} N={N}: oracle-vs-reference worst max-abs {worst:.3e}")
+    return worst
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(cases.CASES)
+    names = sys.argv[1:] or (list(cases.CASES) + list(cases.SEQ_CASES))
     bad = 0
     for n in names:
-        w = run_case(n)
+        w = run_seq_case(n) if n in cases.SEQ_CASES else run_case(n)
         bad |= (w > 1e-4)
     sys.exit(1 if bad else 0)

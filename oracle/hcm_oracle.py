@@ -268,6 +268,36 @@ def rnn_single_forward(x, hidden, mask, w, rnn_type):
     return h2, h2[None]
 
 
+def rnn_seq_forward(x, hidden, masks, w, rnn_type):
+    """RNNStateEncoder.seq_forward (models/decoder/state_encoder.py:83-133): x is (T*N, F) time-major, hidden (R,N,H),
+    masks (T*N,).  Steps are grouped into segments that start at t=0 and at every t where ANY environment has mask 0;
+    the hidden state is multiplied by masks[start] at each segment start and the RNN runs over the segment."""
+    n = hidden.shape[1]
+    t = x.shape[0] // n
+    x = x.view(t, n, -1)
+    masks = masks.view(t, n)
+    has_zeros = (masks[1:] == 0.0).any(dim=-1).nonzero().squeeze(-1)
+    starts = [0] + (has_zeros + 1).tolist() + [t]
+    outs = []
+    for i in range(len(starts) - 1):
+        a, b = starts[i], starts[i + 1]
+        if a == b:
+            continue
+        m = masks[a]
+        for step in range(a, b):
+            # inside a segment every later mask is all-ones by construction, so only the first step is masked
+            h, hidden = rnn_single_forward(x[step], hidden, m if step == a else torch.ones(n), w, rnn_type)
+            outs.append(h)
+    return torch.cat(outs, 0), hidden
+
+
+def rnn_forward(x, hidden, masks, w, rnn_type):
+    """RNNStateEncoder.forward (state_encoder.py:135-137)."""
+    if x.shape[0] == hidden.shape[1]:
+        return rnn_single_forward(x, hidden, masks, w, rnn_type)
+    return rnn_seq_forward(x, hidden, masks, w, rnn_type)
+
+
 # ------------------------------------------------------------------ the two models
 class HighLevelOracle:
     """Seq2Seq_HighLevel_CMA.forward (models/seq2seq_highlevel_cma.py:170-233)."""
@@ -283,8 +313,8 @@ class HighLevelOracle:
         depth = torch.as_tensor(obs["depth"]).float()
         ids = torch.as_tensor(obs["instruction"]).long()
         hidden = torch.as_tensor(hidden).float()
-        mask = torch.as_tensor(mask).float().reshape(hidden.shape[1], -1)[:, 0]   # masks[:,0] (:208)
         B = rgb.shape[0]
+        mask = torch.as_tensor(mask).float().reshape(B, -1)[:, 0]   # masks[:,0] (:208)
         dep = depth_resnet_spatial(depth, w.sub("depth_encoder."), cfg.depth_baseplanes // 2).flatten(2)  # :178-179
         rg = rgb_resnet_spatial(rgb, w.sub("rgb_encoder.")).flatten(2)                                     # :180-181
         ids = ids.expand(B, ids.shape[1])                                                                  # :189-190
@@ -299,7 +329,7 @@ class HighLevelOracle:
         rgb_in = F.relu(F.linear(rg.mean(2), w("rgb_linear.2.weight"), w("rgb_linear.2.bias")))            # :213
         dep_in = F.relu(F.linear(dep.flatten(1), w("depth_linear.1.weight"), w("depth_linear.1.bias")))    # :214
         x = torch.cat((rgb_in, dep_in, p_rgb, p_dep), dim=1)                                               # :215
-        h, hid = rnn_single_forward(x, hidden, mask, w.sub("state_encoder."), cfg.rnn_type)                # :219
+        h, hid = rnn_forward(x, hidden, mask, w.sub("state_encoder."), cfg.rnn_type)                       # :219
         logits = F.linear(h, w("linear.weight"), w("linear.bias"))                                         # :232
         if taps is not None:
             taps.update(depth_spatial=dep, rgb_spatial=rg, bert=emb, rgb_kv=rgb_sp, depth_kv=dep_sp,
@@ -320,7 +350,7 @@ class LowLevelOracle:
         rgb = torch.as_tensor(obs["rgb"]).float()
         depth = torch.as_tensor(obs["depth"]).float()
         hidden = torch.as_tensor(hidden).float()
-        mask = torch.as_tensor(mask).float().reshape(hidden.shape[1], -1)[:, 0]    # :145
+        mask = torch.as_tensor(mask).float().reshape(rgb.shape[0], -1)[:, 0]       # :145
         subtask = torch.as_tensor(subtask).long()
         if cfg.depth_encoder == "VlnResnetDepthEncoder":
             d = depth_resnet_flat(depth, w.sub("depth_encoder."), cfg.depth_baseplanes // 2)               # :128
@@ -332,7 +362,7 @@ class LowLevelOracle:
             r = simple_rgb_cnn(rgb, w.sub("rgb_encoder."))
         st = w("sub_task_embedding.weight")[subtask]                                                       # :141
         x = torch.cat([d, r, st], dim=1)                                                                   # :143
-        h, hid = rnn_single_forward(x, hidden, mask, w.sub("state_encoder."), cfg.rnn_type)                # :147
+        h, hid = rnn_forward(x, hidden, mask, w.sub("state_encoder."), cfg.rnn_type)                       # :147
         out = F.linear(h, w("linear.weight"), w("linear.bias"))                                            # :160
         stop = F.linear(h, w("stop_linear.weight"), w("stop_linear.bias"))                                 # :161
         if taps is not None:

@@ -13,7 +13,7 @@ void prepare_high(hcm_ctx* ctx);
 void prepare_low(hcm_ctx* ctx);
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
               int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
-              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out);
+              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out, int T = 1);
 }  // namespace hcm
 
 using namespace hcm;
@@ -245,6 +245,44 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
     try {
         run_step(h, false, true, rgb, rgb_dtype, depth, nullptr, DT_I64, B, nullptr, h_in, mask, subtask, nullptr, 0, vel,
                  h->cfg.lo_actions, stop, 1, nullptr, h_out);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int T, int N,
+                         const float* h_in, const float* masks, float* logits, float* h_out, void* stream) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    REQUIRE(T >= 1 && N >= 1, HCM_ERR_ARG, "T and N must be >= 1");
+    int rc = check_fwd(h, T * N);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
+    REQUIRE(rgb && depth && ids && h_in && masks && logits && h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
+    h->stream = (hipStream_t)stream;
+    try {
+        run_step(h, true, false, rgb, rgb_dtype, depth, ids, ids_dtype, T * N, h_in, nullptr, masks, nullptr, logits, h->cfg.num_actions,
+                 nullptr, 0, nullptr, 0, h_out, nullptr, T);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, int T, int N, const float* h_in,
+                        const float* masks, const int64_t* subtask, float* vel, float* stop, float* h_out, void* stream) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
+    REQUIRE(T >= 1 && N >= 1, HCM_ERR_ARG, "T and N must be >= 1");
+    int rc = check_fwd(h, T * N);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_low, HCM_ERR_STATE, "handle holds no low-level model");
+    REQUIRE(rgb && depth && h_in && masks && subtask && vel && stop && h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype), HCM_ERR_ARG, "unsupported rgb dtype");
+    h->stream = (hipStream_t)stream;
+    try {
+        run_step(h, false, true, rgb, rgb_dtype, depth, nullptr, DT_I64, T * N, nullptr, h_in, masks, subtask, nullptr, 0, vel,
+                 h->cfg.lo_actions, stop, 1, nullptr, h_out, T);
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, e.what());
     }

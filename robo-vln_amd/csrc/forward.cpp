@@ -219,6 +219,26 @@ struct Fwd {
         }
     }
 
+    // RNNStateEncoder.forward (models/decoder/state_encoder.py:135-137): single_forward when the feature batch equals
+    // the hidden batch, else seq_forward (:83-133) -- T steps over (T*N) feature rows with per-step masking (the
+    // reference masks at segment starts only; inside a segment every mask is 1, so per-step masking is identical).
+    void rnn_scan(const RnnW& w, float* xh, int ld, int T, int N, const float* h_in, const float* mask, float* h_out, const Heads& heads) {
+        if (T == 1) { rnn_step(w, xh, ld, N, h_in, mask, h_out, heads); return; }
+        const int R = ctx->cfg.rnn_type == HCM_LSTM ? 2 : 1;
+        float* pp[2] = {alloc_f((size_t)R * N * ctx->cfg.hidden), alloc_f((size_t)R * N * ctx->cfg.hidden)};
+        const float* cur = h_in;
+        for (int t = 0; t < T; ++t) {
+            float* dst = t == T - 1 ? h_out : pp[t & 1];
+            Heads hd = heads;
+            if (hd.out0) hd.out0 += (size_t)t * N * hd.ld0;
+            if (hd.out1) hd.out1 += (size_t)t * N * hd.ld1;
+            rnn_step(w, xh + (size_t)t * N * ld, ld, N, cur, mask + (size_t)t * N, dst, hd);
+            cur = dst;
+        }
+    }
+
+    int T = 1;      // time steps packed in the batch (training / validation path); 1 = the per-step rollout call
+
     // ---------------------------------------------------------------- stages of Seq2Seq_HighLevel_CMA.forward
     struct HiBufs {
         void* rgb_tok = nullptr;   // (B,2112,16) of the reference, token-major [B][16][2112]      (dt_vla)
@@ -361,7 +381,7 @@ struct Fwd {
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
-        rnn_step(w.rnn, xh, ldx, B, h_in, mask, h_out, hd);
+        rnn_scan(w.rnn, xh, ldx, T, B / T, h_in, mask, h_out, hd);
         tap("hi.rnn_in", xh, false, {B, ldx});
     }
 
@@ -398,7 +418,7 @@ struct Fwd {
         Heads hd;
         hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;
         hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = ld_stop;
-        rnn_step(w.rnn, lb.xh, lb.ldx, B, h_in, mask, h_out, hd);
+        rnn_scan(w.rnn, lb.xh, lb.ldx, T, B / T, h_in, mask, h_out, hd);
         tap("lo.rnn_in", lb.xh, false, {B, lb.ldx});
     }
 
@@ -467,8 +487,9 @@ struct Fwd {
 // entry point used by api.cpp
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
               int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
-              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out) {
+              int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out, int T) {
     Fwd f(ctx);
+    f.T = T;
     f.step(do_hi, do_lo, rgb, rgb_dt, depth, ids, ids_dt, B, hi_h_in, lo_h_in, mask, subtask, logits, ld_logits, vel, ld_vel,
            stop, ld_stop, hi_h_out, lo_h_out);
 }

@@ -150,11 +150,11 @@ class HCMEngine:
         m = m.reshape(B, -1)[:, 0].contiguous()
         return m
 
-    def _hidden(self, h, B):
+    def _hidden(self, h, B=None):
         h = self._dev(h, (torch.float32,))
         R = self.num_recurrent_layers
-        if tuple(h.shape) != (R, B, self.cfg.hidden):
-            raise ValueError(f"hidden state must be ({R},{B},{self.cfg.hidden}), got {tuple(h.shape)}")
+        if h.dim() != 3 or h.shape[0] != R or h.shape[2] != self.cfg.hidden or (B is not None and h.shape[1] != B):
+            raise ValueError(f"hidden state must be ({R},{B if B is not None else 'N'},{self.cfg.hidden}), got {tuple(h.shape)}")
         return h
 
     @staticmethod
@@ -214,6 +214,39 @@ class HCMEngine:
                 st["tick"] += 1
             cur.wait_stream(gs)
         return st["rec"][i], st["hh"][i], st["lh"][i]
+
+    # ---- training / validation path: T*N frames per call, RNNStateEncoder.seq_forward (state_encoder.py:83-133)
+    def high_forward_seq(self, observations, hidden, masks):
+        with torch.cuda.device(self.device):
+            rgb, depth, ids, TN = self._obs(observations, True)
+            h_in = self._hidden(hidden)
+            N = h_in.shape[1]
+            if TN % N:
+                raise ValueError(f"{TN} frames is not a multiple of the hidden batch {N}")
+            m = self._mask(masks, TN)
+            logits = torch.empty(TN, self.cfg.num_actions, device=self.device, dtype=torch.float32)
+            h_out = torch.empty_like(h_in)
+            _lib.check(self._lib.hcm_high_forward_seq(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
+                                                      _TORCH_DT[ids.dtype], TN // N, N, h_in.data_ptr(), m.data_ptr(), logits.data_ptr(),
+                                                      h_out.data_ptr(), self._stream()), self._h)
+        return logits, h_out
+
+    def low_forward_seq(self, observations, hidden, masks, subtask):
+        with torch.cuda.device(self.device):
+            rgb, depth, _, TN = self._obs(observations, False)
+            h_in = self._hidden(hidden)
+            N = h_in.shape[1]
+            if TN % N:
+                raise ValueError(f"{TN} frames is not a multiple of the hidden batch {N}")
+            m = self._mask(masks, TN)
+            st = self._dev(subtask, (torch.int64,)).reshape(TN)
+            vel = torch.empty(TN, self.cfg.lo_actions, device=self.device, dtype=torch.float32)
+            stop = torch.empty(TN, 1, device=self.device, dtype=torch.float32)
+            h_out = torch.empty_like(h_in)
+            _lib.check(self._lib.hcm_low_forward_seq(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), TN // N, N,
+                                                     h_in.data_ptr(), m.data_ptr(), st.data_ptr(), vel.data_ptr(), stop.data_ptr(),
+                                                     h_out.data_ptr(), self._stream()), self._h)
+        return vel, stop, h_out
 
     def act(self, observations, hi_hidden, lo_hidden, masks, out=None):
         if self._graph:
@@ -278,7 +311,11 @@ class Seq2Seq_HighLevel_CMA(_ModelBase):
 
     def forward(self, batch):
         observations, rnn_hidden_states, prev_actions, masks = batch   # prev_actions unused (use_prev_action=False)
-        logits, hidden = self.engine.high_forward(observations, rnn_hidden_states, masks)
+        # RNNStateEncoder.forward dispatch (state_encoder.py:135-137): frames == hidden batch -> single step, else sequence
+        if observations["rgb"].shape[0] == rnn_hidden_states.shape[1]:
+            logits, hidden = self.engine.high_forward(observations, rnn_hidden_states, masks)
+        else:
+            logits, hidden = self.engine.high_forward_seq(observations, rnn_hidden_states, masks)
         # the reference mutates the caller's dict (seq2seq_highlevel_cma.py:196)
         if isinstance(observations, dict) and "instruction" in observations:
             del observations["instruction"]
@@ -290,7 +327,9 @@ class Seq2Seq_LowLevel(_ModelBase):
 
     def forward(self, batch):
         observations, rnn_hidden_states, prev_actions, masks, discrete_actions = batch
-        return self.engine.low_forward(observations, rnn_hidden_states, masks, discrete_actions)
+        if observations["rgb"].shape[0] == rnn_hidden_states.shape[1]:
+            return self.engine.low_forward(observations, rnn_hidden_states, masks, discrete_actions)
+        return self.engine.low_forward_seq(observations, rnn_hidden_states, masks, discrete_actions)
 
 
 class Policy:

@@ -76,3 +76,23 @@ def test_synth_is_deterministic():
     assert (synth.uniform01("k2", 1000, 3) != a).any()
     # known-answer: first values are a pure function of (key, seed)
     assert a.dtype == np.float32
+
+
+def test_oracle_seq_forward_matches_reference_golden():
+    """Training-path call (T*N frames, (R,N,H) hidden): RNNStateEncoder.seq_forward, golden from the imported reference."""
+    name = "seq_T4_N2_gru"
+    kw, T, N = cases.SEQ_CASES[name]
+    cfg = cases.HCMConfig(**kw).validate()
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    hi = hcm_oracle.HighLevelOracle(cfg, synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED))
+    lo = hcm_oracle.LowLevelOracle(cfg, synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED))
+    obs = cases.seq_observations(cfg, T, N)
+    m = cases.seq_masks(T, N)
+    h0 = torch.from_numpy(gold["h0"])
+    logits, hh = hi.forward(obs, h0.clone(), m)
+    vel, stop, lh = lo.forward(obs, h0.clone(), m, torch.from_numpy(cases.fixed_subtask(T * N, 1)))
+    for got, key in ((logits, "logits"), (hh, "hi_hidden"), (vel, "vel"), (stop, "stop"), (lh, "lo_hidden")):
+        np.testing.assert_allclose(got.numpy(), gold[key], atol=TOL, rtol=0)
+    # the scan must differ from treating the rows as independent first steps (state is carried, reset at t=2 for env 1)
+    l1, _ = hi.forward({k: v[N:2 * N] for k, v in obs.items()}, torch.zeros_like(h0), np.zeros(N, np.float32))
+    assert np.abs(l1.numpy() - gold["logits"][N:2 * N]).max() > 1e-4

@@ -91,3 +91,40 @@ def test_hipgraph_replay_equals_eager():
         eng.close()
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("name", ["seq_T4_N2_gru", "seq_T4_N2_lstm"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_seq_forward_matches_oracle(name, precision):
+    """the training/validation-path call -- T*N frames at once, masked T-step recurrent scan
+    (RNNStateEncoder.seq_forward) -- through the reference-shaped model wrappers."""
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    from robo_vln_amd.policy import HCMEngine, Seq2Seq_HighLevel_CMA, Seq2Seq_LowLevel
+    kw, T, N = {**cases.SEQ_CASES, **cases.SEQ_CASES_ORACLE_ONLY}[name]
+    cfg = cases.HCMConfig(**kw).validate()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=cases.SEED)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=T * N, precision=precision)
+    obs_np = cases.seq_observations(cfg, T, N)
+    m = cases.seq_masks(T, N)
+    R = cfg.num_recurrent_layers
+    h0 = (torch.rand(R, N, cfg.hidden, generator=torch.Generator().manual_seed(3)) - 0.5)
+    st = torch.from_numpy(cases.fixed_subtask(T * N, 1))
+    obs = {k: torch.from_numpy(v).cuda() for k, v in obs_np.items()}
+    masks = torch.from_numpy(m).view(-1, 1).expand(-1, 2).contiguous().cuda()       # reference-shaped (T*N, 2)
+    logits, hh = Seq2Seq_HighLevel_CMA(eng)((dict(obs), h0.cuda(), None, masks))
+    vel, stop, lh = Seq2Seq_LowLevel(eng)((dict(obs), h0.cuda(), None, masks, st.cuda()))
+    assert logits.shape == (T * N, 4) and hh.shape == (R, N, cfg.hidden) and vel.shape == (T * N, 2) and stop.shape == (T * N, 1)
+    o_l, o_hh = hcm_oracle.HighLevelOracle(cfg, hi_sd).forward(obs_np, h0.clone(), m)
+    o_v, o_s, o_lh = hcm_oracle.LowLevelOracle(cfg, lo_sd).forward(obs_np, h0.clone(), m, st)
+    tol = TOL[precision]
+    for got, ref in ((logits, o_l), (vel, o_v), (stop, o_s)):
+        assert (got.cpu() - ref).abs().max().item() <= tol
+    for got, ref in ((hh, o_hh), (lh, o_lh)):
+        assert (torch.linalg.norm(got.cpu() - ref) / torch.linalg.norm(ref)).item() <= 1e-2
+    if name in cases.SEQ_CASES:
+        gold = np.load(os.path.join(GOLD, name + ".npz"))
+        assert np.abs(logits.cpu().numpy() - gold["logits"]).max() <= tol
+        assert np.abs(vel.cpu().numpy() - gold["vel"]).max() <= tol
+    eng.close()
