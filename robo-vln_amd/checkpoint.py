@@ -1,0 +1,70 @@
+"""Reader for the reference's checkpoint format.
+
+`RoboDaggerTrainer.save_checkpoint` writes `torch.save({"high_level_state_dict", "low_level_state_dict", "config"})`
+(robo_vln_baselines/hierarchical_trainer.py:349-363); `_setup_actor_critic_agent` loads the two state_dicts with
+`load_state_dict` (:343-345).  The pickled `config` is a yacs `CfgNode`; yacs is not needed here: unknown classes
+un-pickle as plain dict/object stand-ins.
+"""
+import io
+import pickle
+
+import torch
+
+# buffers that some `transformers` versions register inside BertEmbeddings and older checkpoints therefore carry;
+# they are not parameters of the model and are ignored (everything else stays strict)
+IGNORED_SUFFIXES = ("embeddings.position_ids", "embeddings.token_type_ids")
+
+
+class _Stub(dict):
+    """Stand-in for classes whose module is not installed (e.g. yacs.config.CfgNode)."""
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+
+    def __reduce_ex__(self, protocol):
+        return (dict, (dict(self),))
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            return type(name, (_Stub,), {"__module__": module})
+
+
+class _TolerantPickle:
+    Unpickler = _TolerantUnpickler
+    __name__ = "tolerant_pickle"
+
+    @staticmethod
+    def load(f, **kw):
+        return _TolerantUnpickler(f, **kw).load()
+
+
+def load_checkpoint(path_or_file, map_location="cpu"):
+    """-> (high_level_state_dict, low_level_state_dict, config) from a reference checkpoint file."""
+    ckpt = torch.load(path_or_file, map_location=map_location, pickle_module=_TolerantPickle, weights_only=False)
+    for k in ("high_level_state_dict", "low_level_state_dict"):
+        if k not in ckpt:
+            raise KeyError(f"checkpoint has no '{k}' (keys: {list(ckpt)})")
+    clean = []
+    for sd in (ckpt["high_level_state_dict"], ckpt["low_level_state_dict"]):
+        clean.append({k: v for k, v in sd.items() if not k.endswith(IGNORED_SUFFIXES)})
+    return clean[0], clean[1], ckpt.get("config")
+
+
+def save_checkpoint(path_or_file, high_level_state_dict, low_level_state_dict, config=None):
+    """Write the same three-key dict the reference trainer writes (tensors, not numpy)."""
+    def as_t(sd):
+        return {k: torch.as_tensor(v) for k, v in sd.items()}
+    torch.save({"high_level_state_dict": as_t(high_level_state_dict), "low_level_state_dict": as_t(low_level_state_dict),
+                "config": config}, path_or_file)
+
+
+def engine_from_checkpoint(path, cfg, **engine_kwargs):
+    """Build an HCMEngine from a reference checkpoint (strict key/shape check inside libhcm)."""
+    from .policy import HCMEngine
+    hi_sd, lo_sd, _ = load_checkpoint(path)
+    return HCMEngine(cfg, hi_sd, lo_sd, **engine_kwargs)

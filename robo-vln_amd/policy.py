@@ -88,6 +88,8 @@ class HCMEngine:
                     if sd is None:
                         continue
                     for k, v in sd.items():
+                        if k.endswith(("embeddings.position_ids", "embeddings.token_type_ids")):
+                            continue        # BertEmbeddings buffers of some transformers versions, not parameters
                         a, dt = _np32(v)
                         shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
                         _lib.check(self._lib.hcm_load_tensor(self._h, model, k.encode(), a.ctypes.data_as(C.c_void_p), dt,
