@@ -95,6 +95,7 @@ struct Fwd {
         g.Ho = Ho; g.Wo = Wo; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad;
         g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
         g.x_src_dt = st.x_dt; g.x_scale = st.scale;
+        g.x_rowrun = (w.K == w.KH * 24 && st.Cin == 3) ? 1 : 0;
         ck(launch_igemm(g, w.dt, s), "stem conv");
     }
 
@@ -104,7 +105,9 @@ struct Fwd {
         void* slot[4];
         for (auto& p : slot) p = alloc_t(max_elems);
         // 7x7/2 stem: implicit GEMM gathering straight from the raw frame (permute, /255, dtype conversion fused)
-        stem_conv(t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
+        // f32 RGB frames take the row-run fast gather; uint8 frames and the 1-channel depth stem the element-wise one
+        const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
+        stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
         if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, t.groups, true);
         tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
@@ -469,7 +472,8 @@ struct Fwd {
         on(main_s);
         if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
-        on(a0);
+        static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
+        on(rgb_serial ? main_s : a0);
         if (do_hi && do_lo && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);

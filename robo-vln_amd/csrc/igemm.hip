@@ -40,6 +40,7 @@ struct IGemmDev {
     int cin_shift, kw_rcp, tilesM, tilesN, map;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
+    int rowrun;                    // RGB f32 stem: K laid out as KH runs of 24 (see igemm_kernel)
 };
 
 template <typename T> struct Mma;
@@ -274,6 +275,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
             }
         } else {
             const S* xs = reinterpret_cast<const S*>(p.x);
+            if constexpr (std::is_same<S, float>::value) {
+                if (p.rowrun) {
+                    // RGB f32 stem fast path.  K is laid out as KH runs of 24 (= KW*3 = 21 taps + 3 zero-weight pads): for a
+                    // fixed kernel row the 21 taps of a pixel are 21 CONSECUTIVE floats of the NHWC frame, so a chunk of CH
+                    // k-values is CH consecutive floats: CH/4 bounds-checked 16-byte buffer loads (4-byte aligned) instead
+                    // of CH scalar gathers; taps left/right of the image are masked per element afterwards.
+                    const int kh = k / 24, j0 = k - kh * 24;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) {
+                        const int iy = a_iy0[i] + kh;
+                        const bool rowok = kh < p.KH && a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H;
+                        const int off = (a_pix[i] + iy * p.W + a_ix0[i]) * 3 + j0;           // floats; may be negative (-> OOB -> 0)
+                        float v[CH];
+#pragma unroll
+                        for (int q = 0; q < CH / 4; ++q) {
+                            const f32x4 ld = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rs, rowok ? (off + 4 * q) * 4 : -1, 0, 0));
+                            v[4 * q] = ld[0]; v[4 * q + 1] = ld[1]; v[4 * q + 2] = ld[2]; v[4 * q + 3] = ld[3];
+                        }
+                        T packed[CH];
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) {
+                            const int ix = a_ix0[i] + (j0 + e) / 3;
+                            const bool ok = rowok && (unsigned)ix < (unsigned)p.W;
+                            Tr<T>::st(&packed[e], ok ? v[e] * p.x_scale : 0.f);
+                        }
+                        ra[i] = *reinterpret_cast<const uint4*>(packed);
+                    }
+                    goto weights;
+                }
+            }
             int dkh[CH], dkw[CH], dci[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -298,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
                 ra[i] = *reinterpret_cast<const uint4*>(packed);
             }
         }
+    weights:
         const bool kvalid_w = k < p.Kp;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -741,10 +775,19 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     }
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
     d.x_scale = g.x_scale;
+    d.rowrun = 0;
     if (g.x_src_dt >= 0) {
         // narrow-channel first layer: element-wise gather from the raw frame
-        if ((d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || d.res || d.KH * d.KW * d.Cin != d.K) return hipErrorInvalidValue;
-        d.x_bytes = d.w_bytes = 0;
+        d.rowrun = g.x_rowrun;
+        if ((d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || d.res) return hipErrorInvalidValue;
+        if (d.rowrun ? (d.K != d.KH * 24 || d.Cin != 3 || d.KW * 3 > 24 || g.x_src_dt != DT_F32) : (d.KH * d.KW * d.Cin != d.K))
+            return hipErrorInvalidValue;
+        d.w_bytes = 0;
+        {
+            const size_t xb = (size_t)d.B * d.H * d.W * d.xC * (g.x_src_dt == DT_F32 ? 4 : g.x_src_dt == DT_U8 ? 1 : dt_size(dt));
+            if (xb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+            d.x_bytes = (unsigned)xb;
+        }
         if (dt == DT_BF16) return launch_narrow_src<bf16>(d, g.x_src_dt, dt, s);
         if (dt == DT_F16) return launch_narrow_src<f16>(d, g.x_src_dt, dt, s);
         if (dt == DT_F32) return launch_narrow_src<float>(d, g.x_src_dt, dt, s);

@@ -32,6 +32,7 @@ struct IGemm {
     // type), gathered element-wise and multiplied by x_scale; -1 = x is an ordinary T activation
     int x_src_dt = -1;
     float x_scale = 1.0f;
+    int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real

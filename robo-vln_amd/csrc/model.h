@@ -41,7 +41,8 @@ struct BottleneckW {
 struct TrunkW {
     bool gn = false;           // false: BN folded into conv (torchvision); true: GroupNorm (habitat)
     int groups = 0;
-    ConvW conv1;               // first conv, applied to the im2col matrix (KH=KW=1 from the kernel's view)
+    ConvW conv1;               // 7x7/2 stem, K = (kh,kw,ci) order (element-wise gather path: uint8 / 16-bit frames)
+    ConvW conv1_rowrun;        // same stem in the row-run K layout of the f32 RGB fast gather (torchvision trunk only)
     int k1 = 7, s1 = 2, p1 = 3, cin1 = 3;
     NormW n_conv1;
     std::vector<BottleneckW> blocks;

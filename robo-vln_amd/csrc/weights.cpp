@@ -264,12 +264,39 @@ static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, 
     return l;
 }
 
+// 7x7x3 stem weights in the "row-run" K layout of the f32 fast gather (igemm.hip): k = kh*24 + kw*3 + ci, the three
+// slots 21..23 of every run are zero; K = 7*24 = 168, rows padded to 192.  BN folded as usual.
+static ConvW make_stem_rowrun(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
+    const HostTensor& w = T_(ctx, model, wkey);
+    const HostTensor& g = T_(ctx, model, bn + ".weight");
+    const HostTensor& b = T_(ctx, model, bn + ".bias");
+    const HostTensor& m = T_(ctx, model, bn + ".running_mean");
+    const HostTensor& v = T_(ctx, model, bn + ".running_var");
+    ConvW c;
+    c.dt = dt;
+    c.Cout = (int)w.shape[0]; c.Cin = 3; c.KH = 7; c.KW = 7;
+    c.K = 7 * 24; c.Kp = 192;
+    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f), bias(c.Cout);
+    for (int o = 0; o < c.Cout; ++o) {
+        const float sc = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
+        bias[o] = b.f[o] - m.f[o] * sc;
+        for (int ci = 0; ci < 3; ++ci)
+            for (int kh = 0; kh < 7; ++kh)
+                for (int kw = 0; kw < 7; ++kw)
+                    r[(size_t)o * c.Kp + kh * 24 + kw * 3 + ci] = w.f[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * sc;
+    }
+    c.w = up.typed(r, dt);
+    c.bias = up.f32(bias);
+    return c;
+}
+
 static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
     const int dt = ctx->dt_rgb;
     t.gn = false;
     t.cin1 = 3;
     t.conv1 = make_conv_bn(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
+    t.conv1_rowrun = make_stem_rowrun(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
             const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";

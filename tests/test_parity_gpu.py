@@ -60,7 +60,11 @@ def test_uint8_rgb_equals_float_rgb():
     from tests import parity_util
     a = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=False)
     b = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=True)
-    assert np.array_equal(a["records"], b["records"])
+    # same values, different stem gather (f32 frames: row-run vector gather; uint8: element-wise) -> only the fp32
+    # summation order inside the 7x7 stem differs
+    assert np.abs(a["records"] - b["records"]).max() <= 2e-3
+    for s in b["steps"]:
+        assert s["max_abs"] <= 1e-2
 
 
 def test_hipgraph_replay_equals_eager():
