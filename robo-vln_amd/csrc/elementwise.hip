@@ -367,7 +367,7 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
 }
 
 // Vectorised variant: 32 lanes per row, 16-byte chunks (D/CH chunks per row, D/CH/32 per lane), two rows per wave.
-template <typename T, int D>
+template <typename T, int D, bool HAS_RES, bool HAS_POST>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ post, int post_rows,
                                                              T* __restrict__ y, int rows, float eps) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
     for (int i = 0; i < CPL; ++i) {
         const int c = (i * 32 + sub) * CH;
         ld_chunk(xr + c, v[i]);
-        if (rr) {
+        if constexpr (HAS_RES) {
             float r[CH];
             ld_chunk(rr + c, r);
 #pragma unroll
@@ -410,13 +410,21 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int c = (i * 32 + sub) * CH;
-        float o[CH];
+        float o[CH], gm[CH], bt[CH];
+        // gamma / beta / post as 16-byte vector loads (c is a multiple of CH), no per-element branches
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            float t = (v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j];
-            if (pp) t += pp[c + j];
-            o[j] = t;
+        for (int q = 0; q < CH / 4; ++q) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c + 4 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(beta + c + 4 * q);
+            gm[4 * q] = g4.x; gm[4 * q + 1] = g4.y; gm[4 * q + 2] = g4.z; gm[4 * q + 3] = g4.w;
+            bt[4 * q] = b4.x; bt[4 * q + 1] = b4.y; bt[4 * q + 2] = b4.z; bt[4 * q + 3] = b4.w;
+            if constexpr (HAS_POST) {
+                const float4 p4 = *reinterpret_cast<const float4*>(pp + c + 4 * q);
+                bt[4 * q] += p4.x; bt[4 * q + 1] += p4.y; bt[4 * q + 2] += p4.z; bt[4 * q + 3] += p4.w;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o[j] = (v[i][j] - mean) * rstd * gm[j] + bt[j];
         st_chunk(yr + c, o);
     }
 }
@@ -426,9 +434,11 @@ hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, 
     const int pr = post_rows > 0 ? post_rows : 1;
     if (D == 768 || D == 256 || D == 512) {
         const dim3 grid((rows + 7) / 8), block(256);
-#define LV(DD) hipLaunchKernelGGL((layernorm_vec_kernel<T, DD>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, pr, (T*)y, rows, eps)
+#define LV2(DD, R_, P_) hipLaunchKernelGGL((layernorm_vec_kernel<T, DD, R_, P_>), grid, block, 0, s, (const T*)x, (const T*)res, gamma, beta, post, pr, (T*)y, rows, eps)
+#define LV(DD) do { if (res) { if (post) LV2(DD, true, true); else LV2(DD, true, false); } else { if (post) LV2(DD, false, true); else LV2(DD, false, false); } } while (0)
         HCM_DISPATCH_T(dt, { if (D == 768) LV(768); else if (D == 256) LV(256); else LV(512); });
 #undef LV
+#undef LV2
         return hipGetLastError();
     }
     const int wpb = 4;
