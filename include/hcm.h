@@ -156,6 +156,10 @@ int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t c
 int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y,
                   int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                   int act, void* stream);
+/* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
+ * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
+int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,
+                     int Cout, int KH, int KW, int stride, int pad, int K, int Kp, int rowrun, float scale, int act, void* stream);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
 int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype,

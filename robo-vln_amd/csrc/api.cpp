@@ -429,6 +429,18 @@ int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const vo
     g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = act;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C, int Cout,
+                     int KH, int KW, int stride, int pad, int K, int Kp, int rowrun, float scale, int act, void* stream) {
+    IGemm g;
+    g.x = x; g.w = w; g.bias = bias; g.y = y;
+    g.B = B; g.H = H; g.W = W; g.Cin = C; g.xC = C;
+    g.Ho = (H + 2 * pad - KH) / stride + 1; g.Wo = (W + 2 * pad - KW) / stride + 1;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = K; g.Kp = Kp; g.ldy = Cout; g.ldr = Cout; g.act = act;
+    g.x_src_dt = x_dtype == HCM_U8 ? DT_U8 : x_dtype == HCM_F32 ? DT_F32 : op_dt(x_dtype);
+    g.x_scale = scale; g.x_rowrun = rowrun;
+    return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y, int dtype, int M, int N, int K,
                   int act, int out_f32, void* stream) {
     IGemm g;
@@ -446,12 +458,7 @@ int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, co
 }
 int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta, int dtype, int B, int HW, int C,
                      int groups, float eps, int relu, void* stream) {
-    float* stats = nullptr;
-    if (hipMalloc((void**)&stats, (size_t)B * groups * 2 * sizeof(float)) != hipSuccess) return HCM_ERR_NOMEM;
-    int rc = op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, stats, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(stats);
-    return rc;
+    return op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, nullptr, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
 }
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

@@ -145,7 +145,7 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int
 // ------------------------------------------------------------------------------------------ adaptive_avg_pool2d NHWC
 // F.adaptive_avg_pool2d(x,(OH,OW)) (resnet_encoders.py:160-166) / AdaptiveAvgPool2d(1): window [floor(i*H/OH), ceil((i+1)*H/OH)).
 template <typename T>
-__global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH, int OW, int ldy) {
+__global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int OH, int OW, int ldy, int ldx) {
     constexpr int CH = Tr<T>::CH;
     const int cv = C / CH;
     const size_t total = (size_t)B * OH * OW * cv;
@@ -163,7 +163,7 @@ __global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y,
         for (int iy = y0; iy < y1; ++iy)
             for (int ix = x0; ix < x1; ++ix) {
                 float v[CH];
-                ld_chunk(x + ((size_t)(b * H + iy) * W + ix) * C + c, v);
+                ld_chunk(x + ((size_t)(b * H + iy) * W + ix) * ldx + c, v);
 #pragma unroll
                 for (int j = 0; j < CH; ++j) acc[j] += v[j];
             }
@@ -173,11 +173,12 @@ __global__ void adaptive_pool_kernel(const T* __restrict__ x, T* __restrict__ y,
         st_chunk(y + pix * ldy + c, acc);
     }
 }
-hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s) {
+hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s, int ldx) {
     const int CH = dt_chunk(dt);
-    if (C % CH || ldy % CH) return hipErrorInvalidValue;
+    if (ldx <= 0) ldx = C;
+    if (C % CH || ldy % CH || ldx % CH) return hipErrorInvalidValue;
     const size_t total = (size_t)B * OH * OW * (C / CH);
-    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(adaptive_pool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, B, H, W, C, OH, OW, ldy));
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(adaptive_pool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, B, H, W, C, OH, OW, ldy, ldx));
     return hipGetLastError();
 }
 

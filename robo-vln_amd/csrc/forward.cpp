@@ -60,6 +60,10 @@ struct Fwd {
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
         g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
         g.M = in.B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
+        if (w.groups > 1) {     // hi|lo pair: group g reads channels [g*Cin, (g+1)*Cin) and writes [g*Cout, (g+1)*Cout)
+            g.Cin = w.Cin; g.xC = in.C; g.ldy = g.ldr = w.groups * w.Cout;
+            g.groups = w.groups; g.g_x = w.Cin; g.g_w = (long long)w.Cout * w.Kp; g.g_b = w.Cout; g.g_y = w.Cout;
+        }
         ck(launch_igemm(g, w.dt, s), "conv igemm");
     }
     // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
@@ -101,6 +105,8 @@ struct Fwd {
 
     Act trunk(const TrunkW& t, const Stem& st, int B, int Ho, int Wo, const std::string& tapname) {
         const int c1 = t.conv1.Cout;
+        const int G = t.groups * (t.pair ? 2 : 1);                 // GroupNorm groups over the (possibly paired) channels
+        auto CO = [](const ConvW& w) { return w.groups * w.Cout; };   // total output channels of a (grouped) conv
         const size_t max_elems = (size_t)B * Ho * Wo * c1;      // conv1 output == layer1 output == largest activation
         void* slot[4];
         for (auto& p : slot) p = alloc_t(max_elems);
@@ -108,7 +114,7 @@ struct Fwd {
         // f32 RGB frames take the row-run fast gather; uint8 frames and the 1-channel depth stem the element-wise one
         const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
         stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
-        if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, t.groups, true);
+        if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
         tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
         if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
@@ -120,25 +126,25 @@ struct Fwd {
             for (int i = 0; i < 4; ++i) if (i != xi) fr[nf++] = i;
             void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
             const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
-            Act o1{sa, B, x.H, x.W, b.c1.Cout};
+            Act o1{sa, B, x.H, x.W, CO(b.c1)};
             conv(b.c1, x, sa, 1, 0, nullptr, t.gn ? ACT_NONE : ACT_RELU, x.H, x.W);
-            if (t.gn) gn(sa, nullptr, b.n1, B, x.H * x.W, b.c1.Cout, t.groups, true);
-            Act o2{sb, B, Ho2, Wo2, b.c2.Cout};
+            if (t.gn) gn(sa, nullptr, b.n1, B, x.H * x.W, CO(b.c1), G, true);
+            Act o2{sb, B, Ho2, Wo2, CO(b.c2)};
             conv(b.c2, o1, sb, b.stride, 1, nullptr, t.gn ? ACT_NONE : ACT_RELU, Ho2, Wo2);
-            if (t.gn) gn(sb, nullptr, b.n2, B, Ho2 * Wo2, b.c2.Cout, t.groups, true);
+            if (t.gn) gn(sb, nullptr, b.n2, B, Ho2 * Wo2, CO(b.c2), G, true);
             const void* idt = x.p;
             if (b.has_ds) {
                 conv(b.ds, x, sa, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);       // o1 is dead: reuse its slot
-                if (t.gn) gn(sa, nullptr, b.nds, B, Ho2 * Wo2, b.ds.Cout, t.groups, false);
+                if (t.gn) gn(sa, nullptr, b.nds, B, Ho2 * Wo2, CO(b.ds), G, false);
                 idt = sa;
             }
             if (t.gn) {
                 conv(b.c3, o2, sc, 1, 0, nullptr, ACT_NONE, Ho2, Wo2);
-                gn(sc, idt, b.n3, B, Ho2 * Wo2, b.c3.Cout, t.groups, true);        // relu(GN(conv) + identity)
+                gn(sc, idt, b.n3, B, Ho2 * Wo2, CO(b.c3), G, true);                // relu(GN(conv) + identity)
             } else {
                 conv(b.c3, o2, sc, 1, 0, idt, ACT_RELU, Ho2, Wo2);                  // relu(bn(conv) + identity), fused
             }
-            x = Act{sc, B, Ho2, Wo2, b.c3.Cout};
+            x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
             xi = fr[2];
             ++bidx;
             if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16)
@@ -147,8 +153,8 @@ struct Fwd {
         if (t.gn) {
             int fr = (xi + 1) & 3;
             conv(t.compress, x, slot[fr], 1, 1, nullptr, ACT_NONE, x.H, x.W);
-            gn(slot[fr], nullptr, t.n_compress, B, x.H * x.W, t.compress.Cout, 1, true);
-            x = Act{slot[fr], B, x.H, x.W, t.compress.Cout};
+            gn(slot[fr], nullptr, t.n_compress, B, x.H * x.W, CO(t.compress), t.pair ? 2 : 1, true);
+            x = Act{slot[fr], B, x.H, x.W, CO(t.compress)};
         }
         return x;
     }
@@ -284,6 +290,26 @@ struct Fwd {
             ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
             if (tok != hb.dep_tok) ck(launch_convert(tok, ctx->dt_depth, hb.dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
         }
+        use(ctx->dt_vla);
+        tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
+    }
+    // Both depth encoders in one pass over the shared frame (hcm_act): channel-concatenated pair trunk, then the hi half
+    // becomes dep_tok (+ pos-emb) and the lo half goes through visual_fc (resnet_encoders.py:56-62,:108) into the lo RNN input.
+    void depth_pair(const float* depth, int B, HiBufs& hb, LoBufs& lb) {
+        const HighW& w = ctx->hi;
+        const int dS = w.depth_S, dC = w.depth_C;
+        use(ctx->dt_depth);
+        Act o = depth_trunk(w.depth_pair, depth, B, "pair.depth");        // [B, fs, fs, 2*cc]
+        const int cc = o.C / 2;
+        void* tok = ctx->dt_depth == ctx->dt_vla ? hb.dep_tok : alloc_t((size_t)B * dS * dC);
+        void* lo_feat = alloc_t((size_t)B * dS * cc);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, cc, o.H, o.W, dC, s, o.C), "depth tokens (hi half)");
+            ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)cc * esz, dt, B, dS, 64, dC, s), "depth pe");
+            if (tok != hb.dep_tok) ck(launch_convert(tok, ctx->dt_depth, hb.dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
+            ck(launch_adaptive_avgpool((char*)o.p + (size_t)cc * esz, lo_feat, dt, B, o.H, o.W, cc, o.H, o.W, cc, s, o.C), "depth lo half");
+        }
+        linear(ctx->lo.depth_fc, lo_feat, B, dS * cc, lb.xh, lb.ldx, ACT_RELU, true);     // visual_fc
         use(ctx->dt_vla);
         tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
     }
@@ -464,10 +490,13 @@ struct Fwd {
         if (do_hi && !(skip & 8)) hi_bert(ids, ids_dt, B, hb);
         // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
         on(a1);
-        if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
+        const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;
+        if (pair) {
+            if (!(skip & 4)) depth_pair(depth, B, hb, lb);
+        } else if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
         static const int dsplit = getenv("HCM_DEPTH_SPLIT") ? atoi(getenv("HCM_DEPTH_SPLIT")) : 0;
         on((do_hi && dsplit) ? a3 : a1);
-        if (do_lo && !(skip & 4)) lo_depth(depth, B, lb);
+        if (do_lo && !pair && !(skip & 4)) lo_depth(depth, B, lb);
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
         if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }

@@ -41,6 +41,8 @@ struct IGemmDev {
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
     int rowrun;                    // RGB f32 stem: K laid out as KH runs of 24 (see igemm_kernel)
+    // grouped launch (blockIdx.y = group): element offsets added to x / w / bias / y+res per group
+    int groups; long long g_x, g_w, g_b, g_y;
 };
 
 template <typename T> struct Mma;
@@ -212,6 +214,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
     constexpr int TILE_BYTES = (BM + BN) * 128;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.groups > 1) {
+        const long long g = blockIdx.y;
+        p.x += g * p.g_x * (long long)sizeof(T);
+        p.w += g * p.g_w * (long long)sizeof(T);
+        if (p.bias) p.bias += g * p.g_b;
+        if (p.res) p.res += g * p.g_y * (long long)sizeof(T);
+        p.y += g * p.g_y * (long long)(p.out_f32 ? 4 : sizeof(T));
+    }
 
     // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole pixel-tiles (all channel tiles of
     // one pixel tile back to back) so the gathered activation rows are re-read from that XCD's L2.
@@ -289,11 +299,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
                         const bool rowok = kh < p.KH && a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H;
                         const int off = (a_pix[i] + iy * p.W + a_ix0[i]) * 3 + j0;           // floats; may be negative (-> OOB -> 0)
                         float v[CH];
+                        // the run may start before the first / end after the last float of the tensor (first and last image
+                        // rows only): do not rely on partial range checking of a 16-byte access there, gather those element-wise
+                        const bool inside = off >= 0 && (unsigned)(off + CH) * 4u <= p.x_bytes;
+                        if (inside || !rowok) {
 #pragma unroll
-                        for (int q = 0; q < CH / 4; ++q) {
-                            const f32x4 ld = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                rs, rowok ? (off + 4 * q) * 4 : -1, 0, 0));
-                            v[4 * q] = ld[0]; v[4 * q + 1] = ld[1]; v[4 * q + 2] = ld[2]; v[4 * q + 3] = ld[3];
+                            for (int q = 0; q < CH / 4; ++q) {
+                                const f32x4 ld = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, rowok ? (off + 4 * q) * 4 : -1, 0, 0));
+                                v[4 * q] = ld[0]; v[4 * q + 1] = ld[1]; v[4 * q + 2] = ld[2]; v[4 * q + 3] = ld[3];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) {
+                                const int o1 = off + e;
+                                v[e] = (o1 >= 0 && (unsigned)(o1 + 1) * 4u <= p.x_bytes) ? xs[o1] : 0.f;
+                            }
                         }
                         T packed[CH];
 #pragma unroll
@@ -471,6 +492,14 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     static_assert(NBUF == 2 || NBUF == 3, "ring depth");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.groups > 1) {
+        const long long g = blockIdx.y;
+        p.x += g * p.g_x * (long long)sizeof(T);
+        p.w += g * p.g_w * (long long)sizeof(T);
+        if (p.bias) p.bias += g * p.g_b;
+        if (p.res) p.res += g * p.g_y * (long long)sizeof(T);
+        p.y += g * p.g_y * (long long)(p.out_f32 ? 4 : sizeof(T));
+    }
 
     int tile_m, tile_n;
     if (!tile_of_block(p, blockIdx.x, tile_m, tile_n)) return;
@@ -621,15 +650,15 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         attr_done = true;
     }
     if constexpr (BN >= 64) {
-        if (variant == 4) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8>), dim3(grid), dim3(512), lds, s, d); return hipGetLastError(); }
-        if (variant == 5) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8>), dim3(grid), dim3(512), lds, s, d); return hipGetLastError(); }
+        if (variant == 4) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8>), dim3(grid, d.groups), dim3(512), lds, s, d); return hipGetLastError(); }
+        if (variant == 5) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8>), dim3(grid, d.groups), dim3(512), lds, s, d); return hipGetLastError(); }
     } else {
         if (variant >= 4) variant -= 3;             // no 8-wave instantiation for 32-wide channel tiles
     }
-    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, s, d);
-    else if (variant == 3) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, void, 2>), dim3(grid), dim3(256), lds, s, d);
-    else if (variant == 1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, s, d);
-    else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, s, d);
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid, d.groups), dim3(256), lds, s, d);
+    else if (variant == 3) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, void, 2>), dim3(grid, d.groups), dim3(256), lds, s, d);
+    else if (variant == 1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), dim3(grid, d.groups), dim3(256), lds, s, d);
+    else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3>), dim3(grid, d.groups), dim3(256), lds, s, d);
     return hipGetLastError();
 }
 
@@ -686,9 +715,9 @@ static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s
 // that the kernel is a streaming copy with a matmul attached.
 static int heuristic_choice(const IGemmDev& d, int dt) {
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
-    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
-    const long b64128 = cdiv(d.M, 64) * cdiv(d.N, 128);
-    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
+    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128) * d.groups;
+    const long b64128 = cdiv(d.M, 64) * cdiv(d.N, 128) * d.groups;
+    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64) * d.groups;
     // tile index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
     // variant: 1 dma2, 2 dma3 (4 waves); 4 dma2, 5 dma3 (8 waves)
     int tile, variant;
@@ -776,6 +805,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
     d.x_scale = g.x_scale;
     d.rowrun = 0;
+    d.groups = g.groups > 1 ? g.groups : 1;
+    d.g_x = g.g_x; d.g_w = g.g_w; d.g_b = g.g_b; d.g_y = g.g_y;
     if (g.x_src_dt >= 0) {
         // narrow-channel first layer: element-wise gather from the raw frame
         d.rowrun = g.x_rowrun;

@@ -32,6 +32,8 @@ struct IGemm {
     // type), gathered element-wise and multiplied by x_scale; -1 = x is an ordinary T activation
     int x_src_dt = -1;
     float x_scale = 1.0f;
+    int groups = 1;              // grouped launch: group g adds g*g_x / g*g_w / g*g_b / g*g_y ELEMENTS to x / w / bias / (y, res)
+    long long g_x = 0, g_w = 0, g_b = 0, g_y = 0;
     int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
@@ -47,7 +49,8 @@ hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int 
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel
-hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s);
+hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s,
+                                   int ldx = 0 /* input pixel stride in elements, 0 = C */);
 // mean over S rows: x [B,S,ldx(>=C)] (T) -> y [B, ldy] (T or f32 when out_f32) columns [0,C)
 hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s);
 // write a constant f32 table tab[S][C] into columns of y [B,S,ldy] (T)

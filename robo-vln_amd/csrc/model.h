@@ -24,6 +24,7 @@ struct ConvW {                 // [Cout][Kp] in the sub-network's storage dtype,
     int dt = 0;
     float* bias = nullptr;     // f32 [Cout] or null
     int Cout = 0, Cin = 0, KH = 1, KW = 1, K = 0, Kp = 0;
+    int groups = 1;            // 2: hi|lo pair trunk -- w holds [2][Cout][Kp], bias [2][Cout]; Cout / Cin are per group
 };
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct LinW {                  // [N][Kp]; dt = compute dtype or f32 (recurrent weights)
@@ -40,6 +41,7 @@ struct BottleneckW {
 };
 struct TrunkW {
     bool gn = false;           // false: BN folded into conv (torchvision); true: GroupNorm (habitat)
+    bool pair = false;         // hi|lo channel-concatenated pair (grouped convs, 2x GroupNorm groups)
     int groups = 0;
     ConvW conv1;               // 7x7/2 stem, K = (kh,kw,ci) order (element-wise gather path: uint8 / 16-bit frames)
     ConvW conv1_rowrun;        // same stem in the row-run K layout of the f32 RGB fast gather (torchvision trunk only)
@@ -81,6 +83,10 @@ struct HighW {
     float* rgb_pe = nullptr;   // [16][64] transposed view of spatial_embeddings (the `.view` quirk)
     float* depth_pe = nullptr; // [S][64]
     int depth_S = 0, depth_C = 0;
+    // hi + lo GroupNorm depth trunks fused into ONE channel-concatenated network (hcm_act only): same input frame, same
+    // layer shapes, different weights -> grouped convs (2 groups), GroupNorm over 2C channels with 2G groups
+    TrunkW depth_pair;
+    bool has_depth_pair = false;
     BertW bert;
     LinW rgb_kv, depth_kv, rgb_linear, depth_linear;
     VlaW vla;

@@ -2,6 +2,7 @@
 // BatchNorm folding, OIHW -> OHWI re-layout for the NHWC implicit GEMM, flatten-order permutations,
 // fused QKV / KV / recurrent weight concatenation, conversion to the compute dtype, upload.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -342,6 +343,71 @@ static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     return t;
 }
 
+// ---- hi|lo pair of the GroupNorm depth trunk (see HighW::depth_pair)
+static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const HostTensor& b, bool concat_n) {
+    ConvW c;
+    c.dt = dt;
+    c.Cout = (int)a.shape[0]; c.Cin = (int)a.shape[1]; c.KH = (int)a.shape[2]; c.KW = (int)a.shape[3];
+    c.K = c.KH * c.KW * c.Cin;
+    c.Kp = round_up(c.K, 32);
+    std::vector<float> r((size_t)2 * c.Cout * c.Kp, 0.f);
+    const HostTensor* ws[2] = {&a, &b};
+    for (int g = 0; g < 2; ++g)
+        for (int o = 0; o < c.Cout; ++o)
+            for (int i = 0; i < c.Cin; ++i)
+                for (int kh = 0; kh < c.KH; ++kh)
+                    for (int kw = 0; kw < c.KW; ++kw)
+                        r[((size_t)g * c.Cout + o) * c.Kp + (size_t)(kh * c.KW + kw) * c.Cin + i] =
+                            ws[g]->f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw];
+    c.w = up.typed(r, dt);
+    if (concat_n) c.Cout *= 2;          // shared input (stem): one ordinary conv with the output channels concatenated
+    else c.groups = 2;
+    return c;
+}
+static NormW make_norm_pair(hcm_ctx* ctx, Uploader& up, const std::string& p) {
+    NormW n;
+    std::vector<float> g = T_(ctx, HCM_HIGH, p + ".weight").f, b = T_(ctx, HCM_HIGH, p + ".bias").f;
+    const HostTensor& g2 = T_(ctx, HCM_LOW, p + ".weight");
+    const HostTensor& b2 = T_(ctx, HCM_LOW, p + ".bias");
+    g.insert(g.end(), g2.f.begin(), g2.f.end());
+    b.insert(b.end(), b2.f.begin(), b2.f.end());
+    n.C = (int)g.size();
+    n.gamma = up.f32(g);
+    n.beta = up.f32(b);
+    return n;
+}
+static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& pre) {
+    TrunkW t;
+    const int dt = ctx->dt_depth;
+    t.gn = true;
+    t.pair = true;
+    t.groups = ctx->cfg.depth_baseplanes / 2;
+    t.cin1 = 1;
+    auto W2 = [&](const std::string& k, bool cat) { return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat); };
+    const std::string bb = pre + "backbone.";
+    t.conv1 = W2(bb + "conv1.0.weight", true);
+    t.n_conv1 = make_norm_pair(ctx, up, bb + "conv1.1");
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            BottleneckW b;
+            b.stride = (li > 0 && bi == 0) ? 2 : 1;
+            b.c1 = W2(p + "convs.0.weight", false); b.n1 = make_norm_pair(ctx, up, p + "convs.1");
+            b.c2 = W2(p + "convs.3.weight", false); b.n2 = make_norm_pair(ctx, up, p + "convs.4");
+            b.c3 = W2(p + "convs.6.weight", false); b.n3 = make_norm_pair(ctx, up, p + "convs.7");
+            if (bi == 0) {
+                b.has_ds = true;
+                b.ds = W2(p + "downsample.0.weight", false);
+                b.nds = make_norm_pair(ctx, up, p + "downsample.1");
+            }
+            t.blocks.push_back(b);
+        }
+    t.compress = W2(pre + "compression.0.weight", false);
+    t.n_compress = make_norm_pair(ctx, up, pre + "compression.1");
+    t.out_c = t.compress.Cout;      // per model
+    return t;
+}
+
 static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& pre, int cin, int hw) {
     SimpleCnnW s;
     s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
@@ -471,6 +537,10 @@ void prepare_high(hcm_ctx* ctx) {
                 pe[(size_t)p * d + 2 * i + 1] = std::cos(ang);
             }
         v.pe = up.f32(pe);
+    }
+    if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !(getenv("HCM_NO_DEPTH_PAIR") && atoi(getenv("HCM_NO_DEPTH_PAIR")))) {
+        h.depth_pair = make_gn_trunk_pair(ctx, up, "depth_encoder.visual_encoder.");
+        h.has_depth_pair = true;
     }
     h.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
     h.head_w = up.f32(T_(ctx, M, "linear.weight").f);

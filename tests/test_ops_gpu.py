@@ -171,3 +171,52 @@ def test_maxpool(prec):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, C, Cout, K, stride, pad, src ("f32" | "u8" | "same"), rowrun
+    (2, 32, 32, 3, 64, 7, 2, 3, "f32", 0), (2, 32, 32, 3, 64, 7, 2, 3, "f32", 1), (3, 37, 29, 3, 64, 7, 2, 3, "f32", 1),
+    (1, 16, 16, 3, 64, 7, 2, 3, "f32", 1), (2, 32, 32, 3, 64, 7, 2, 3, "u8", 0), (2, 32, 32, 1, 32, 7, 2, 3, "same", 0),
+    (2, 36, 36, 1, 32, 8, 4, 0, "f32", 0), (2, 36, 36, 3, 32, 8, 4, 0, "u8", 0),
+])
+def test_stem_conv(prec, cfg):
+    """First-layer convs gathered straight from the raw frame (element-wise and f32 row-run paths), incl. image borders
+    and the very first / last rows of the tensor."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cc, Cout, K, stride, pad, src, rowrun = cfg
+    x_int = torch.randint(0, 256, (B, H, W, Cc), generator=torch.Generator().manual_seed(1))
+    scale = 1.0 / 255.0
+    if src == "u8":
+        xd, xcode, xf = x_int.to(torch.uint8).cuda(), L.HCM_U8, x_int.float()
+    elif src == "f32":
+        xd, xcode, xf = x_int.float().cuda(), L.HCM_F32, x_int.float()
+    else:
+        xf = (x_int.float() * scale).to(tdt).float()
+        xd, xcode, scale = xf.to(tdt).cuda(), code, 1.0
+    w = (_rnd(Cout, Cc, K, K, seed=2) * (3.0 / (Cc * K * K)) ** 0.5).to(tdt).float()
+    bias = _rnd(Cout, seed=3)
+    xin = (xf * scale).to(tdt).float() if src != "same" else xf         # the kernel rounds the scaled pixel to the storage type
+    ref = F.relu(F.conv2d(xin.permute(0, 3, 1, 2), w, bias, stride=stride, padding=pad))
+    if rowrun:
+        Kk, Kp = K * 24, 192
+        wl = torch.zeros(Cout, Kp)
+        for kh in range(K):
+            for kw in range(K):
+                for ci in range(Cc):
+                    wl[:, kh * 24 + kw * 3 + ci] = w[:, ci, kh, kw]
+    else:
+        Kk = K * K * Cc
+        Kp = (Kk + 31) // 32 * 32
+        wl = torch.zeros(Cout, Kp)
+        wl[:, :Kk] = w.permute(0, 2, 3, 1).reshape(Cout, Kk)
+    wd, bd = wl.to(tdt).cuda(), bias.cuda()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=tdt)
+    rc = lib.hcm_op_stem_conv(_p(xd), xcode, _p(wd), _p(bd), _p(y), code, B, H, W, Cc, Cout, K, K, stride, pad, Kk, Kp, rowrun,
+                              scale, L.ACT_RELU, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
