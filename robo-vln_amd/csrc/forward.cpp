@@ -313,6 +313,27 @@ struct Fwd {
         use(ctx->dt_vla);
         tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
     }
+    // Both RGB encoders in one pass (hcm_act): hi half -> adaptive_avg_pool2d(4,4) + pos-emb -> rgb_tok; lo half -> global
+    // average pool -> fc -> ReLU (resnet_encoders.py:234-237) into the lo RNN input.
+    void rgb_pair(const void* rgb, int rgb_dt, int B, HiBufs& hb, LoBufs& lb) {
+        const HighW& w = ctx->hi;
+        const hcm_config& c = ctx->cfg;
+        const int rC = 2048 + 64;
+        use(ctx->dt_rgb);
+        Act o = rgb_trunk(w.rgb_pair, rgb, rgb_dt, B, "pair.rgb");            // [B, h, w, 2*2048]
+        const int C1 = o.C / 2;
+        void* tok = ctx->dt_rgb == ctx->dt_vla ? hb.rgb_tok : alloc_t((size_t)B * 16 * rC);
+        void* pooled = alloc_t((size_t)B * C1);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, C1, 4, 4, rC, s, o.C), "rgb tokens (hi half)");
+            ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)C1 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+            if (tok != hb.rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, hb.rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
+            ck(launch_adaptive_avgpool((char*)o.p + (size_t)C1 * esz, pooled, dt, B, o.H, o.W, C1, 1, 1, C1, s, o.C), "global avgpool (lo half)");
+        }
+        linear(ctx->lo.rgb_fc, pooled, B, C1, lb.xh + c.depth_out, lb.ldx, ACT_RELU, true);
+        use(ctx->dt_vla);
+        tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
+    }
     // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels -> rgb_tok
     void hi_rgb(const void* rgb, int rgb_dt, int B, HiBufs& hb) {
         const HighW& w = ctx->hi;
@@ -499,11 +520,13 @@ struct Fwd {
         if (do_lo && !pair && !(skip & 4)) lo_depth(depth, B, lb);
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
-        if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
+        const bool rpair = do_hi && do_lo && ctx->hi.has_rgb_pair && !ctx->lo.rgb_simple;
+        if (rpair) { if (!(skip & 1)) rgb_pair(rgb, rgb_dt, B, hb, lb); }
+        else if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
         static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
         on(rgb_serial ? main_s : a0);
-        if (do_hi && do_lo && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
+        if (do_hi && do_lo && !rpair && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);
         if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);

@@ -87,6 +87,8 @@ struct HighW {
     // layer shapes, different weights -> grouped convs (2 groups), GroupNorm over 2C channels with 2G groups
     TrunkW depth_pair;
     bool has_depth_pair = false;
+    TrunkW rgb_pair;           // likewise for the two BatchNorm-folded RGB ResNet-50s (shared frame, 2x64-channel stem)
+    bool has_rgb_pair = false;
     BertW bert;
     LinW rgb_kv, depth_kv, rgb_linear, depth_linear;
     VlaW vla;

@@ -408,6 +408,90 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     return t;
 }
 
+// ---- hi|lo pair of the torchvision (BatchNorm-folded) RGB trunk: grouped convs with per-model folded scale/bias
+static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias) {
+    const HostTensor& g = T_(ctx, model, bn + ".weight");
+    const HostTensor& b = T_(ctx, model, bn + ".bias");
+    const HostTensor& m = T_(ctx, model, bn + ".running_mean");
+    const HostTensor& v = T_(ctx, model, bn + ".running_var");
+    scale.resize(C); bias.resize(C);
+    for (int o = 0; o < C; ++o) {
+        const float s = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
+        scale[o] = s;
+        bias[o] = b.f[o] - m.f[o] * s;
+    }
+}
+static ConvW make_conv_bn_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string& wkey, const std::string& bn) {
+    const HostTensor* ws[2] = {&T_(ctx, HCM_HIGH, wkey), &T_(ctx, HCM_LOW, wkey)};
+    ConvW c;
+    c.dt = dt;
+    c.groups = 2;
+    c.Cout = (int)ws[0]->shape[0]; c.Cin = (int)ws[0]->shape[1]; c.KH = (int)ws[0]->shape[2]; c.KW = (int)ws[0]->shape[3];
+    c.K = c.KH * c.KW * c.Cin;
+    c.Kp = round_up(c.K, 32);
+    std::vector<float> r((size_t)2 * c.Cout * c.Kp, 0.f), bias_all;
+    for (int g = 0; g < 2; ++g) {
+        std::vector<float> scale, bias;
+        bn_fold(ctx, g == 0 ? HCM_HIGH : HCM_LOW, bn, c.Cout, scale, bias);
+        bias_all.insert(bias_all.end(), bias.begin(), bias.end());
+        for (int o = 0; o < c.Cout; ++o)
+            for (int i = 0; i < c.Cin; ++i)
+                for (int kh = 0; kh < c.KH; ++kh)
+                    for (int kw = 0; kw < c.KW; ++kw)
+                        r[((size_t)g * c.Cout + o) * c.Kp + (size_t)(kh * c.KW + kw) * c.Cin + i] =
+                            ws[g]->f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw] * scale[o];
+    }
+    c.w = up.typed(r, dt);
+    c.bias = up.f32(bias_all);
+    return c;
+}
+// stem of the pair: shared RGB frame -> ONE conv with 2x64 output channels, in both K layouts (see make_stem_rowrun)
+static void make_stem_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string& wkey, const std::string& bn, ConvW& plain, ConvW& rowrun) {
+    const HostTensor* ws[2] = {&T_(ctx, HCM_HIGH, wkey), &T_(ctx, HCM_LOW, wkey)};
+    const int Co = (int)ws[0]->shape[0];
+    plain = ConvW(); rowrun = ConvW();
+    plain.dt = rowrun.dt = dt;
+    plain.Cout = rowrun.Cout = 2 * Co; plain.Cin = rowrun.Cin = 3; plain.KH = plain.KW = rowrun.KH = rowrun.KW = 7;
+    plain.K = 147; plain.Kp = 160; rowrun.K = 7 * 24; rowrun.Kp = 192;
+    std::vector<float> rp((size_t)2 * Co * plain.Kp, 0.f), rr((size_t)2 * Co * rowrun.Kp, 0.f), bias_all;
+    for (int g = 0; g < 2; ++g) {
+        std::vector<float> scale, bias;
+        bn_fold(ctx, g == 0 ? HCM_HIGH : HCM_LOW, bn, Co, scale, bias);
+        bias_all.insert(bias_all.end(), bias.begin(), bias.end());
+        for (int o = 0; o < Co; ++o)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int kh = 0; kh < 7; ++kh)
+                    for (int kw = 0; kw < 7; ++kw) {
+                        const float v = ws[g]->f[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
+                        rp[((size_t)g * Co + o) * plain.Kp + (kh * 7 + kw) * 3 + ci] = v;
+                        rr[((size_t)g * Co + o) * rowrun.Kp + kh * 24 + kw * 3 + ci] = v;
+                    }
+    }
+    plain.w = up.typed(rp, dt); rowrun.w = up.typed(rr, dt);
+    plain.bias = up.f32(bias_all); rowrun.bias = up.f32(bias_all);
+}
+static TrunkW make_tv_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& pre) {
+    TrunkW t;
+    const int dt = ctx->dt_rgb;
+    t.gn = false;
+    t.pair = true;
+    t.cin1 = 3;
+    make_stem_pair(ctx, dt, up, pre + "conv1.weight", pre + "bn1", t.conv1, t.conv1_rowrun);
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+            const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            BottleneckW b;
+            b.stride = (li > 0 && bi == 0) ? 2 : 1;
+            b.c1 = make_conv_bn_pair(ctx, dt, up, p + "conv1.weight", p + "bn1");
+            b.c2 = make_conv_bn_pair(ctx, dt, up, p + "conv2.weight", p + "bn2");
+            b.c3 = make_conv_bn_pair(ctx, dt, up, p + "conv3.weight", p + "bn3");
+            if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn_pair(ctx, dt, up, p + "downsample.0.weight", p + "downsample.1"); }
+            t.blocks.push_back(b);
+        }
+    t.out_c = 2048;
+    return t;
+}
+
 static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& pre, int cin, int hw) {
     SimpleCnnW s;
     s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
@@ -541,6 +625,10 @@ void prepare_high(hcm_ctx* ctx) {
     if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !(getenv("HCM_NO_DEPTH_PAIR") && atoi(getenv("HCM_NO_DEPTH_PAIR")))) {
         h.depth_pair = make_gn_trunk_pair(ctx, up, "depth_encoder.visual_encoder.");
         h.has_depth_pair = true;
+    }
+    if (c.build_low && c.rgb_encoder == HCM_ENC_RESNET && !(getenv("HCM_NO_RGB_PAIR") && atoi(getenv("HCM_NO_RGB_PAIR")))) {
+        h.rgb_pair = make_tv_trunk_pair(ctx, up, "rgb_encoder.cnn.");
+        h.has_rgb_pair = true;
     }
     h.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
     h.head_w = up.f32(T_(ctx, M, "linear.weight").f);
