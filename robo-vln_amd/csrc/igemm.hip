@@ -673,10 +673,25 @@ static hipError_t launch_narrow(IGemmDev d, hipStream_t s) {
         d.tilesN = 1;
         const size_t lds = 2 * (size_t)(BM + 32) * 128;
         hipLaunchKernelGGL((igemm_kernel<T, BM, 32, S>), dim3(tm8 * 8), dim3(256), lds, s, d);
-    } else {
-        d.tilesN = (d.N + 63) / 64;
+    } else if (d.N <= 64) {
+        d.tilesN = 1;
         const size_t lds = 2 * (size_t)(BM + 64) * 128;
-        hipLaunchKernelGGL((igemm_kernel<T, BM, 64, S>), dim3(tm8 * 8 * d.tilesN), dim3(256), lds, s, d);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, 64, S>), dim3(tm8 * 8), dim3(256), lds, s, d);
+    } else {
+        // 128-wide channel tiles: the (expensive) raw-frame gather is done once per pixel tile for up to 128 output channels
+        // (the hi|lo pair stem has 2 x 64)
+        d.tilesN = (d.N + 127) / 128;
+        size_t lds = 2 * (size_t)(BM + 128) * 128;
+        const size_t lds_c = (size_t)BM * (128 + 4) * 4;
+        if (lds_c > lds) lds = lds_c;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<T, BM, 128, S>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<T, BM, 128, S>), dim3(tm8 * 8 * d.tilesN), dim3(256), lds, s, d);
     }
     return hipGetLastError();
 }

@@ -177,7 +177,8 @@ def test_maxpool(prec):
 @pytest.mark.parametrize("cfg", [
     # B, H, W, C, Cout, K, stride, pad, src ("f32" | "u8" | "same"), rowrun
     (2, 32, 32, 3, 64, 7, 2, 3, "f32", 0), (2, 32, 32, 3, 64, 7, 2, 3, "f32", 1), (3, 37, 29, 3, 64, 7, 2, 3, "f32", 1),
-    (1, 16, 16, 3, 64, 7, 2, 3, "f32", 1), (2, 32, 32, 3, 64, 7, 2, 3, "u8", 0), (2, 32, 32, 1, 32, 7, 2, 3, "same", 0),
+    (1, 16, 16, 3, 64, 7, 2, 3, "f32", 1), (2, 32, 32, 3, 128, 7, 2, 3, "f32", 1), (2, 32, 32, 3, 128, 7, 2, 3, "u8", 0),
+    (2, 32, 32, 3, 64, 7, 2, 3, "u8", 0), (2, 32, 32, 1, 32, 7, 2, 3, "same", 0),
     (2, 36, 36, 1, 32, 8, 4, 0, "f32", 0), (2, 36, 36, 3, 32, 8, 4, 0, "u8", 0),
 ])
 def test_stem_conv(prec, cfg):
