@@ -150,6 +150,10 @@ int hcm_debug_enable_taps(hcm_handle h, int enable);
  * shape_out receives up to 4 dims (0-padded). */
 int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t capacity,
                       int64_t* n_out, int64_t* shape_out);
+/* Development aid: cycle totals of the implicit-GEMM K-loop phases, collected only when the process runs with
+ * HCM_IGEMM_PROF=1 (which selects instrumented builds of the 8-wave bf16 kernels).  out8: prologue, DMA issue,
+ * fragment reads + MFMA issue, DMA wait, barrier, epilogue (cycles summed over waves), waves, K iterations. */
+int hcm_debug_igemm_prof(uint64_t* out8, int reset);
 
 /* Stand-alone operator entry points used by the kernel-level parity tests (device pointers, f32 or bf16
  * per `dtype`; layouts NHWC / row-major).  See robo-vln_amd/csrc/ops_api.cpp. */

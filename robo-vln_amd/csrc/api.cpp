@@ -396,6 +396,14 @@ int hcm_debug_enable_taps(hcm_handle h, int enable) {
     return HCM_OK;
 }
 
+int hcm_debug_igemm_prof(uint64_t* out8, int reset) {
+    if (!out8) return HCM_ERR_ARG;
+    unsigned long long v[8];
+    if (hcm::igemm_prof_read(v, reset != 0) != hipSuccess) return HCM_ERR_HIP;
+    for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    return HCM_OK;
+}
+
 int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t capacity, int64_t* n_out, int64_t* shape_out) {
     REQUIRE(h && name && n_out, HCM_ERR_ARG, "null argument");
     auto it = h->taps.find(name);

@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -87,11 +89,11 @@ __device__ __forceinline__ bool tile_of_block(const IGemmDev& p, int bid, int& t
 }
 
 // Shared epilogue of both kernel variants (see the comment at its top).
-template <typename T, int BM, int BN, int NW = 4>
-__device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / (NW / 2) / 16][BM / 32], char* smem, int m0, int n0,
+template <typename T, int BM, int BN, int NW = 4, int WMc = 2>
+__device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], char* smem, int m0, int n0,
                                                int tid, int wm, int wn, int fr, int fg) {
-    constexpr int WNc = NW / 2;            // waves along the channel axis (2 along the pixel axis)
-    constexpr int TM = BM / 32;
+    constexpr int WNc = NW / WMc;          // waves along the channel axis (WMc along the pixel axis)
+    constexpr int TM = BM / WMc / 16;
     constexpr int TN = BN / WNc / 16;
     // ---- epilogue ----
     // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
@@ -105,7 +107,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
     for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const int r = wm * (BM / 2) + j * 16 + fr;
+            const int r = wm * (BM / WMc) + j * 16 + fr;
             const int cc = wn * (BN / WNc) + i * 16 + fg * 4;
             *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
@@ -475,14 +477,35 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
+// Phase timing of the K loop (debug builds of the loop selected with HCM_IGEMM_PROF=1; read back through
+// hcm_debug_igemm_prof): per-wave cycle totals [0] prologue, [1] DMA issue, [2] fragment reads + MFMA issue,
+// [3] wait for the next tile's DMA, [4] barrier, [5] epilogue, [6] waves, [7] K iterations.
+constexpr int kProfSlots = 65536;
+__device__ unsigned long long g_igemm_prof[kProfSlots][8];
+__device__ __forceinline__ unsigned long long prof_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 // NW = 4 (2x2 waves, wave tile BM/2 x BN/2) or 8 (2x4 waves, wave tile BM/2 x BN/4: twice the waves per SIMD on the same
 // LDS footprint -- more thread-level parallelism to cover ds_read / DMA-issue latency)
-template <typename T, int BM, int BN, int NBUF, int NW = 4>
+// ILV = 2: ILV = 1 plus a rotated loop -- the second K half's MFMAs are issued AFTER the barrier and after the next tile's
+// first fragment reads, so the matrix pipe has work while those reads are in flight (3-deep ring only).
+// ILV = 1: the DMA instructions of the next tile are not issued in one burst at the top of an iteration (where all waves
+// of the workgroup queue 16-32 KB on the CU's one texture-address path at once and then sit in the issue stall) but
+// one at a time between groups of MFMAs; both K halves' fragments are read up front.
+template <typename T, int BM, int BN, int NBUF, int NW = 4, int WMc = 2, bool PROF = false, int ILV = 0>
 __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if constexpr (PROF) t_prev = prof_now();
+    auto lap = [&](int slot) {
+        if constexpr (PROF) { const unsigned long long t = prof_now(); pt[slot] += t - t_prev; t_prev = t; }
+    };
     constexpr int CH = Tr<T>::CH;
     constexpr int BK = 8 * CH;
-    constexpr int WNc = NW / 2;
-    constexpr int TM = BM / 32;
+    constexpr int WNc = NW / WMc;
+    constexpr int TM = BM / WMc / 16;
     constexpr int TN = BN / WNc / 16;
     constexpr int A_IT = BM / 8 / NW;      // wave-level DMA instructions per tile (8 rows each)
     constexpr int B_IT = BN / 8 / NW;
@@ -573,14 +596,205 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     stage(0, 0);
     if (NBUF == 3 && nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
+    lap(0);
 
     const int fr = lane & 15;
     const int fg = lane >> 4;
     int cur = 0;
+    if constexpr (ILV == 2) {
+        static_assert(NBUF == 3, "the rotated loop needs the 3-deep ring");
+        constexpr int HM = TM * TN;                     // MFMAs per K half
+        constexpr int P1 = LPT / 2;                     // DMA pieces issued among the first half's MFMAs
+        constexpr int G1 = P1 > 0 ? (HM / (P1 + 1) >= 1 ? HM / (P1 + 1) : 1) : HM + 1;
+        constexpr int G2 = HM / (LPT - P1 + 1) >= 1 ? HM / (LPT - P1 + 1) : 1;
+        auto piece = [&](int i, unsigned sa2, unsigned sb2, int k, int kh, int kw, int ci) {
+            if (i < A_IT) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * (unsigned)sizeof(T);
+                dma16(sa2 + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+            } else {
+                const int ib = i - A_IT;
+                const int n = n0 + (wave + NW * ib) * 8 + rin;
+                const bool ok = (k < p.Kp) & (n < p.N);
+                const unsigned off = (unsigned)(n * p.Kp + k) * (unsigned)sizeof(T);
+                dma16(sb2 + (wave + NW * ib) * 1024, ok ? off : 0xFFFFFFFFu, rw);
+            }
+        };
+        uint4 xa[2][TM], wb[2][TN];
+        auto rd = [&](int ks, int slot) {
+            const char* sa = smem + slot * TILE_BYTES;
+            const char* sb = sa + BM * 128;
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / WMc) + j * 16 + fr;
+                xa[ks][j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * (BN / WNc) + i * 16 + fr;
+                wb[ks][i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+        };
+        rd(0, 0);
+        rd(1, 0);
+        auto body = [&](int kt, auto LIVE, auto NEXT) {
+            constexpr bool live = decltype(LIVE)::value;      // tile kt+2 exists: stage it
+            constexpr bool next = decltype(NEXT)::value;      // tile kt+1 exists: read its fragments
+            const int slot2 = cur == 0 ? 2 : cur - 1;          // (cur + 2) % 3
+            const int slot1 = cur == 2 ? 0 : cur + 1;
+            const unsigned sa2 = lds_base + slot2 * TILE_BYTES, sb2 = sa2 + BM * 128;
+            const int k = (kt + 2) * BK + c * CH;
+            int kh = 0, kw = 0, ci = k;
+            if (live && spatial) {
+                const int khw = k >> p.cin_shift;
+                ci = k & (p.Cin - 1);
+                kh = (khw * p.kw_rcp) >> 16;
+                kw = khw - kh * p.KW;
+            }
+            lap(1);
+            int cnt = 0, pc = 0;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    Mma<T>::run(acc[i][j], wb[0][i], xa[0][j]);
+                    ++cnt;
+                    if (live && pc < P1 && cnt == G1 * (pc + 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(pc, sa2, sb2, k, kh, kw, ci);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++pc;
+                    }
+                }
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < P1; ++q)
+                    if (q >= pc) piece(q, sa2, sb2, k, kh, kw, ci);
+            }
+            lap(2);
+            if (live) wait_vmcnt<P1>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lap(3);
+            __builtin_amdgcn_s_barrier();
+            lap(4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (next) rd(0, slot1);
+            __builtin_amdgcn_sched_barrier(0);
+            cnt = 0; pc = P1;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    Mma<T>::run(acc[i][j], wb[1][i], xa[1][j]);
+                    ++cnt;
+                    if (live && pc < LPT && cnt == G2 * (pc - P1 + 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(pc, sa2, sb2, k, kh, kw, ci);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++pc;
+                    }
+                }
+            if (live) {
+#pragma unroll
+                for (int q = P1; q < LPT; ++q)
+                    if (q >= pc) piece(q, sa2, sb2, k, kh, kw, ci);
+            }
+            if (next) rd(1, slot1);
+            cur = slot1;
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, std::true_type{}, std::true_type{});
+        for (; kt + 1 < nk; ++kt) body(kt, std::false_type{}, std::true_type{});
+        for (; kt < nk; ++kt) body(kt, std::false_type{}, std::false_type{});
+    } else
+    if constexpr (ILV == 1) {
+        constexpr int NMMA = 2 * TM * TN;
+        constexpr int GAP = NMMA / (LPT + 1) >= 1 ? NMMA / (LPT + 1) : 1;
+        // one DMA instruction of tile `kt2` (piece i: A rows first, then B rows)
+        auto piece = [&](int i, unsigned sa2, unsigned sb2, int k, int kh, int kw, int ci) {
+            if (i < A_IT) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * (unsigned)sizeof(T);
+                dma16(sa2 + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+            } else {
+                const int ib = i - A_IT;
+                const int n = n0 + (wave + NW * ib) * 8 + rin;
+                const bool ok = (k < p.Kp) & (n < p.N);
+                const unsigned off = (unsigned)(n * p.Kp + k) * (unsigned)sizeof(T);
+                dma16(sb2 + (wave + NW * ib) * 1024, ok ? off : 0xFFFFFFFFu, rw);
+            }
+        };
+        auto body = [&](int kt, auto LIVE) {
+            constexpr bool live = decltype(LIVE)::value;
+            const int slot = cur == 0 ? NBUF - 1 : cur - 1;
+            const unsigned sa2 = lds_base + slot * TILE_BYTES, sb2 = sa2 + BM * 128;
+            const int k = (kt + NBUF - 1) * BK + c * CH;
+            int kh = 0, kw = 0, ci = k;
+            if (live && spatial) {
+                const int khw = k >> p.cin_shift;
+                ci = k & (p.Cin - 1);
+                kh = (khw * p.kw_rcp) >> 16;
+                kw = khw - kh * p.KW;
+            }
+            lap(1);
+            const char* sa = smem + cur * TILE_BYTES;
+            const char* sb = sa + BM * 128;
+            uint4 xa[2][TM], wb[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int r = wm * (BM / WMc) + j * 16 + fr;
+                    xa[ks][j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int r = wn * (BN / WNc) + i * 16 + fr;
+                    wb[ks][i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+            }
+            int cnt = 0, pc = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        Mma<T>::run(acc[i][j], wb[ks][i], xa[ks][j]);
+                        ++cnt;
+                        if (live && pc < LPT && cnt == GAP * (pc + 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            piece(pc, sa2, sb2, k, kh, kw, ci);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++pc;
+                        }
+                    }
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                    if (q >= pc) piece(q, sa2, sb2, k, kh, kw, ci);
+            }
+            lap(2);
+            if (NBUF == 3 && live) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lap(3);
+            __builtin_amdgcn_s_barrier();
+            lap(4);
+            cur = cur == NBUF - 1 ? 0 : cur + 1;
+        };
+        int kt = 0;
+        for (; kt + (NBUF - 1) < nk; ++kt) body(kt, std::true_type{});
+        for (; kt < nk; ++kt) body(kt, std::false_type{});
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + (NBUF - 1) < nk;
         // ring slot of tile kt+NBUF-1: it was last read in iteration kt-1, which every wave has left (barrier)
         if (more) stage(kt + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
+        lap(1);
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -589,7 +803,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
             const int chunk = ks * 4 + fg;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int r = wm * (BM / 2) + j * 16 + fr;
+                const int r = wm * (BM / WMc) + j * 16 + fr;
                 xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
             }
 #pragma unroll
@@ -604,16 +818,42 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         }
         // tile kt+1 must be complete before the next iteration reads it; with the 3-deep ring the tile requested in this
         // iteration may stay in flight across the barrier
+        lap(2);
         if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lap(3);
         __builtin_amdgcn_s_barrier();
+        lap(4);
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
-    igemm_epilogue<T, BM, BN, NW>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    igemm_epilogue<T, BM, BN, NW, WMc>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(5);
+        if (lane == 0) {
+            unsigned long long* slot = g_igemm_prof[((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & (kProfSlots - 1)];
+            for (int i = 0; i < 6; ++i) atomicAdd(&slot[i], pt[i]);          // one wave per slot (collisions only past 65536 waves)
+            atomicAdd(&slot[6], 1ull);
+            atomicAdd(&slot[7], (unsigned long long)nk);
+        }
+    }
 }
 
+hipError_t igemm_prof_read(unsigned long long* host8, bool reset) {
+    std::vector<unsigned long long> h((size_t)kProfSlots * 8);
+    hipError_t e = hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_igemm_prof), h.size() * 8);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 8; ++i) host8[i] = 0;
+    for (size_t k = 0; k < h.size(); ++k) host8[k & 7] += h[k];
+    if (!reset) return hipSuccess;
+    std::fill(h.begin(), h.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_prof), h.data(), h.size() * 8);
+}
+static bool prof_on() { static const bool on = getenv("HCM_IGEMM_PROF") != nullptr; return on; }
+
 // variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring, 3 = register-staged with two
-// register sets (prefetch distance 2), 4 / 5 = variants 1 / 2 with 8 waves per workgroup
+// register sets (prefetch distance 2), 4 / 5 = variants 1 / 2 with 8 waves per workgroup, 6 / 7 = 4 / 5 with the DMA
+// instructions interleaved into the MFMA stream
 template <typename T, int BM, int BN>
 static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesM = (d.M + BM - 1) / BM;
@@ -626,7 +866,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         if (d.tilesN < 8) d.map = 0;
         else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);       // every XCD gets ceil(tilesN/8) slots per pixel tile
     }
-    size_t lds = ((variant == 2 || variant == 5) ? 3 : 2) * (size_t)(BM + BN) * 128;
+    size_t lds = ((variant == 2 || variant == 5 || variant >= 7) ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
     if (lds_c > lds) lds = lds_c;
     static bool attr_done = false;                            // one flag per template instantiation
@@ -650,9 +890,47 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         attr_done = true;
     }
     if constexpr (BN >= 64) {
+        if constexpr (std::is_same<T, bf16>::value && BN == 128) {
+            if (prof_on() && variant >= 4 && variant <= 8) {
+                const void* fp[5] = {reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2, 8, 2, true>),
+                                     reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8, 2, true>),
+                                     reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2, 8, 2, true, 1>),
+                                     reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8, 2, true, 1>),
+                                     reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8, 2, true, 2>)};
+                for (const void* f : fp) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (variant == 4) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8, 2, true>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else if (variant == 5) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8, 2, true>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else if (variant == 6) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8, 2, true, 1>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else if (variant == 7) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8, 2, true, 1>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8, 2, true, 2>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                return hipGetLastError();
+            }
+        }
         if (variant == 4) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8>), dim3(grid, d.groups), dim3(512), lds, s, d); return hipGetLastError(); }
         if (variant == 5) { hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8>), dim3(grid, d.groups), dim3(512), lds, s, d); return hipGetLastError(); }
+        if constexpr (sizeof(T) == 2) {
+            if (variant >= 6 && variant <= 8) {
+                static bool ilv_attr = false;
+                if (!ilv_attr) {
+                    const void* fi[3] = {reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2, 8, 2, false, 1>),
+                                         reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8, 2, false, 1>),
+                                         reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3, 8, 2, false, 2>)};
+                    for (const void* f : fi) {
+                        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        if (e != hipSuccess) return e;
+                    }
+                    ilv_attr = true;
+                }
+                if (variant == 6) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2, 8, 2, false, 1>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else if (variant == 7) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8, 2, false, 1>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3, 8, 2, false, 2>), dim3(grid, d.groups), dim3(512), lds, s, d);
+                return hipGetLastError();
+            }
+        } else {
+            if (variant >= 6) variant -= 2;
+        }
     } else {
+        if (variant >= 6) variant -= 2;
         if (variant >= 4) variant -= 3;             // no 8-wave instantiation for 32-wide channel tiles
     }
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(grid, d.groups), dim3(256), lds, s, d);
@@ -660,6 +938,44 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     else if (variant == 1) hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 2>), dim3(grid, d.groups), dim3(256), lds, s, d);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, 3>), dim3(grid, d.groups), dim3(256), lds, s, d);
     return hipGetLastError();
+}
+
+// 256x128 tile, 8 waves as 4 (pixel) x 2 (channel): wave tile 64x64 like the 4-wave 128x128 kernel, but half the
+// L2->LDS staging bytes per flop of a 128x128 tile (a 128x128x64 step needs 32 KB for 512 SIMD-cycles of MFMA -- exactly
+// the 64 B/clk/CU a CU can pull; 256x128 needs 48 KB for 1024).  One workgroup per CU (96 / 144 KB of LDS).
+template <typename T>
+static hipError_t launch_big(IGemmDev d, int ring, int ilv, hipStream_t s) {
+    constexpr int BM = 256, BN = 128;
+    d.tilesM = (d.M + BM - 1) / BM;
+    d.tilesN = (d.N + BN - 1) / BN;
+    const int tm8 = (d.tilesM + 7) / 8;
+    int grid = tm8 * 8 * d.tilesN;
+    static const char* fmap = getenv("HCM_IGEMM_MAP");
+    d.map = fmap ? atoi(fmap) : (((size_t)d.N * d.Kp * sizeof(T) > (2u << 20)) && d.tilesN >= 8 ? 1 : 0);
+    if (d.map == 1) {
+        if (d.tilesN < 8) d.map = 0;
+        else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);
+    }
+    size_t lds = (size_t)ring * (BM + BN) * 128;
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4;
+    if (lds_c > lds) lds = lds_c;
+    const bool prof = std::is_same<T, bf16>::value && prof_on();
+    const void* fn;
+#define HCM_BIG(R, P, I) reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, R, 8, 4, P, I>)
+    if (ilv == 2) ring = 3;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (prof) fn = ilv == 2 ? HCM_BIG(3, true, 2) : ring == 3 ? (ilv ? HCM_BIG(3, true, 1) : HCM_BIG(3, true, 0)) : (ilv ? HCM_BIG(2, true, 1) : HCM_BIG(2, true, 0));
+        else fn = ilv == 2 ? HCM_BIG(3, false, 2) : ring == 3 ? (ilv ? HCM_BIG(3, false, 1) : HCM_BIG(3, false, 0)) : (ilv ? HCM_BIG(2, false, 1) : HCM_BIG(2, false, 0));
+    } else {
+        fn = ilv == 2 ? HCM_BIG(3, false, 2) : ring == 3 ? (ilv ? HCM_BIG(3, false, 1) : HCM_BIG(3, false, 0)) : (ilv ? HCM_BIG(2, false, 1) : HCM_BIG(2, false, 0));
+    }
+#undef HCM_BIG
+    size_t lds2 = (size_t)ring * (BM + BN) * 128;
+    if (lds2 > lds) lds = lds2;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    void* args[] = {&d};
+    return hipLaunchKernel(fn, dim3(grid, d.groups), dim3(512), args, lds, s);
 }
 
 // first-layer (narrow-channel) launch: register-staged variant with the element-wise gather; N is 32 or 64
@@ -718,6 +1034,13 @@ static hipError_t launch_choice(const IGemmDev& d, int choice, hipStream_t s) {
     }
 }
 static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s) {
+    if (choice >= 100) {                                // 100 / 101: 256x128 tile with a 2- / 3-deep LDS ring; 102 / 103: interleaved DMA
+        const int ring = 2 + (choice & 1);
+        const int ilv = choice >= 104 ? 2 : choice >= 102 ? 1 : 0;       // 105: rotated loop
+        if (dt == DT_BF16) return launch_big<bf16>(d, ring, ilv, s);
+        if (dt == DT_F16) return launch_big<f16>(d, ring, ilv, s);
+        return hipErrorInvalidValue;
+    }
     if (dt == DT_BF16) return launch_choice<bf16>(d, choice, s);
     if (dt == DT_F16) return launch_choice<f16>(d, choice, s);
     if (dt == DT_F32) return launch_choice<float>(d, choice, s);
@@ -728,6 +1051,7 @@ static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s
 // LDS-DMA with 2 buffers nearly everywhere (2 workgroups per CU); the 3-deep ring only for long K loops on small
 // tiles (few workgroups, latency bound); 64-row pixel tiles whenever 128x128 would leave CUs idle or K is so short
 // that the kernel is a streaming copy with a matmul attached.
+static inline int sizeof_dt(int dt) { return dt == DT_F32 ? 4 : 2; }
 static int heuristic_choice(const IGemmDev& d, int dt) {
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128) * d.groups;
@@ -736,17 +1060,17 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     // tile index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
     // variant: 1 dma2, 2 dma3 (4 waves); 4 dma2, 5 dma3 (8 waves)
     int tile, variant;
-    const bool longk = d.K >= 1024;
+    const bool longk = d.K >= 768;
+    static const int big_rot = getenv("HCM_IGEMM_ROT128") ? atoi(getenv("HCM_IGEMM_ROT128")) : 0;
     if (d.N <= 32) { tile = 3; variant = d.K >= 2048 ? 2 : 1; }
     else if (d.N <= 64) {
         tile = d.M >= 65536 ? 1 : (b64 >= 256 ? 2 : 3);
         variant = tile == 3 ? (d.K >= 2048 ? 2 : 1) : 4;
     }
     else if (d.M <= 64) { tile = 3; variant = 1; }
-    else if (b128 >= 512) { tile = 0; variant = 4; }
-    else if (b64128 >= 128) { tile = 5; variant = longk ? 5 : 4; }
+    else if (b128 >= 512) { tile = 0; variant = (big_rot && d.K >= big_rot && sizeof_dt(dt) == 2) ? 8 : 4; }
+    else if (b64128 >= 128) { tile = 5; variant = longk ? (sizeof_dt(dt) == 2 ? 7 : 5) : 4; }   // long K: interleaved DMA issue
     else { tile = b64 >= 256 ? 2 : 3; variant = d.K >= 2048 ? 2 : 1; }
-    (void)dt;
     return variant * 6 + tile;
 }
 

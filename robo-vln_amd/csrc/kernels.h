@@ -41,6 +41,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // operands and caches the fastest (process-wide); hcm_finalize() runs one tuning step at max_batch.
 void igemm_set_tuning(bool on);
 size_t igemm_tuned_shapes();
+hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEMM_PROF=1 phase counters
 
 // First-layer im2col (Cin = 1 or 3): x [B,H,W,C] (src_dt: f32 / u8 / T) * scale -> A [B*Ho*Wo][Kp] (T), zero-padded K..Kp
 hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C,
