@@ -164,6 +164,11 @@ int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const vo
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,
                      int Cout, int KH, int KW, int stride, int pad, int K, int Kp, int rowrun, float scale, int act, void* stream);
+/* 7x7 stride-2 pad-3 RGB stem on a 16-bit trunk through the packed-frame path: x is the raw (B,H,W,3) frame (HCM_F32 or
+ * HCM_U8, H and W even), w is [Cout][224] with k = kh*32 + kw*4 + ci, scratch holds hcm_op_stem_scratch_bytes(B,H,W). */
+int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                            int Cout, float scale, int act, void* scratch, void* stream);
+int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
 int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype,

@@ -103,6 +103,19 @@ struct Fwd {
         ck(launch_igemm(g, w.dt, s), "stem conv");
     }
 
+    // 16-bit RGB trunks: pack the frame once, then the stem is an ordinary LDS-DMA implicit GEMM (kernels.h: launch_pack_frame)
+    void stem_conv_packed(const ConvW& w, const Stem& st, int B, void* out, int Ho, int Wo, int act) {
+        void* pk = alloc_t(pack_frame_elems(B, st.H, st.W));
+        if (dry) return;
+        ck(launch_pack_frame(st.x, st.x_dt, pk, w.dt, B, st.H, st.W, st.scale, s), "pack frame");
+        IGemm g;
+        g.x = pk; g.w = w.w; g.bias = w.bias; g.y = out;
+        g.B = B; g.H = st.H + 6; g.W = (st.W + 8) / 2; g.Cin = 32; g.xC = 8;
+        g.Ho = Ho; g.Wo = Wo; g.KH = 7; g.KW = 1; g.stride = 2; g.stride_w = 1; g.pad = 0;
+        g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
+        ck(launch_igemm(g, w.dt, s), "stem conv (packed)");
+    }
+
     Act trunk(const TrunkW& t, const Stem& st, int B, int Ho, int Wo, const std::string& tapname) {
         const int c1 = t.conv1.Cout;
         const int G = t.groups * (t.pair ? 2 : 1);                 // GroupNorm groups over the (possibly paired) channels
@@ -112,8 +125,12 @@ struct Fwd {
         for (auto& p : slot) p = alloc_t(max_elems);
         // 7x7/2 stem: implicit GEMM gathering straight from the raw frame (permute, /255, dtype conversion fused)
         // f32 RGB frames take the row-run fast gather; uint8 frames and the 1-channel depth stem the element-wise one
+        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        const bool packed = !t.gn && !no_pack && t.conv1_packed.w != nullptr && st.Cin == 3 && !(st.W & 1) && !(st.H & 1) &&
+                            (st.x_dt == DT_F32 || st.x_dt == DT_U8);
         const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
-        stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
+        if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
+        else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
         if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
         tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;

@@ -38,6 +38,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct IGemmDev {
     const char* x; const char* w; const float* bias; const char* res; char* y;
     int B, H, W, Cin, xC, Ho, Wo, KH, KW, stride, pad;
+    int stride_w;                  // horizontal stride (== stride except for the packed-frame stem, see launch_pack_frame)
     int M, N, K, Kp, ldy, ldr, act, out_f32;
     int cin_shift, kw_rcp, tilesM, tilesN, map;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
             const int ox = rem - oy * p.Wo;
             a_pix[i] = b * p.H * p.W;
             a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride_w - p.pad;
         } else {
             a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
         }
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
             const int ox = rem - oy * p.Wo;
             a_pix[i] = b * p.H * p.W;
             a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride_w - p.pad;
         } else {
             a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
         }
@@ -1084,8 +1085,8 @@ size_t igemm_tuned_shapes() { std::lock_guard<std::mutex> l(g_choice_mu); return
 
 static std::string shape_key(const IGemmDev& d, int dt) {
     char buf[160];
-    snprintf(buf, sizeof buf, "%d|%d,%d,%d|%d,%d,%d,%d|%d,%d,%d,%d|%d,%d", dt, d.M, d.N, d.K, d.H, d.W, d.Cin, d.xC, d.KH, d.KW, d.stride,
-             d.pad, d.res != nullptr, d.out_f32);
+    snprintf(buf, sizeof buf, "%d|%d,%d,%d|%d,%d,%d,%d|%d,%d,%d,%d,%d|%d,%d", dt, d.M, d.N, d.K, d.H, d.W, d.Cin, d.xC, d.KH, d.KW, d.stride,
+             d.stride_w, d.pad, d.res != nullptr, d.out_f32);
     return buf;
 }
 
@@ -1132,6 +1133,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.res = (const char*)g.res; d.y = (char*)g.y;
     d.B = g.B; d.H = g.H; d.W = g.W; d.Cin = g.Cin; d.xC = g.xC ? g.xC : g.Cin;
     d.Ho = g.Ho; d.Wo = g.Wo; d.KH = g.KH; d.KW = g.KW; d.stride = g.stride; d.pad = g.pad;
+    d.stride_w = g.stride_w > 0 ? g.stride_w : g.stride;
     d.M = g.M; d.N = g.N; d.K = g.K; d.Kp = g.Kp ? g.Kp : g.K;
     d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32;
     const int CH = dt_chunk(dt);

@@ -34,6 +34,7 @@ struct IGemm {
     float x_scale = 1.0f;
     int groups = 1;              // grouped launch: group g adds g*g_x / g*g_w / g*g_b / g*g_y ELEMENTS to x / w / bias / (y, res)
     long long g_x = 0, g_w = 0, g_b = 0, g_y = 0;
+    int stride_w = 0;            // horizontal stride when it differs from `stride` (0 = same); packed-frame stem only
     int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
@@ -47,6 +48,14 @@ hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEM
 hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C,
                          int KH, int KW, int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s);
 // depth pre-pool: f32 [B,H,W,1] -> avg_pool2d(2) -> T [B,H/2,W/2,1]
+// 7x7/2 pad-3 stem on a 16-bit trunk: the raw RGB frame (f32 or uint8, NHWC3) is first packed ONCE into a zero-bordered
+// 4-channel frame of the storage type, [B][H+6][W+8][4] (3 px border left/top, 5 right, 3 bottom; channel 3 = 0; values
+// multiplied by `scale`).  In that frame a kernel row of an output pixel is ONE contiguous, 16-byte-aligned run of
+// 8 px x 4 ch = 32 elements (7 real taps + 1 whose weights are zero), so the stem becomes an ordinary LDS-DMA implicit
+// GEMM over "virtual pixels" of 8 elements: H' = H+6, W' = (W+8)/2, xC = 8, Cin = 32, KH = 7, KW = 1, stride 2 down /
+// 1 across, pad 0, K = 7*32 -- no element-wise gather, no conversion in the GEMM, no bounds cases.
+hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, int H, int W, float scale, hipStream_t s);
+inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel

@@ -45,6 +45,7 @@ struct TrunkW {
     int groups = 0;
     ConvW conv1;               // 7x7/2 stem, K = (kh,kw,ci) order (element-wise gather path: uint8 / 16-bit frames)
     ConvW conv1_rowrun;        // same stem in the row-run K layout of the f32 RGB fast gather (torchvision trunk only)
+    ConvW conv1_packed;        // same stem for the packed-frame path (16-bit trunks): k = kh*32 + kw*4 + ci, K = 224
     int k1 = 7, s1 = 2, p1 = 3, cin1 = 3;
     NormW n_conv1;
     std::vector<BottleneckW> blocks;

@@ -291,6 +291,28 @@ static ConvW make_stem_rowrun(hcm_ctx* ctx, int dt, Uploader& up, int model, con
     return c;
 }
 
+static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias);
+// 7x7x3 stem weights for the packed-frame path (kernels.h: launch_pack_frame): k = kh*32 + kw*4 + ci; slots with
+// ci = 3 or kw = 7 are zero; K = Kp = 224.  BN folded as usual.
+static ConvW make_stem_packed(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
+    const HostTensor& w = T_(ctx, model, wkey);
+    ConvW c;
+    c.dt = dt;
+    c.Cout = (int)w.shape[0]; c.Cin = 3; c.KH = 7; c.KW = 7;
+    c.K = 224; c.Kp = 224;
+    std::vector<float> scale, bias;
+    bn_fold(ctx, model, bn, c.Cout, scale, bias);
+    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
+    for (int o = 0; o < c.Cout; ++o)
+        for (int ci = 0; ci < 3; ++ci)
+            for (int kh = 0; kh < 7; ++kh)
+                for (int kw = 0; kw < 7; ++kw)
+                    r[(size_t)o * c.Kp + kh * 32 + kw * 4 + ci] = w.f[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
+    c.w = up.typed(r, dt);
+    c.bias = up.f32(bias);
+    return c;
+}
+
 static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
     const int dt = ctx->dt_rgb;
@@ -298,6 +320,7 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     t.cin1 = 3;
     t.conv1 = make_conv_bn(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     t.conv1_rowrun = make_stem_rowrun(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
+    if (dt != DT_F32) t.conv1_packed = make_stem_packed(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
             const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
@@ -446,14 +469,16 @@ static ConvW make_conv_bn_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::st
     return c;
 }
 // stem of the pair: shared RGB frame -> ONE conv with 2x64 output channels, in both K layouts (see make_stem_rowrun)
-static void make_stem_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string& wkey, const std::string& bn, ConvW& plain, ConvW& rowrun) {
+static void make_stem_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string& wkey, const std::string& bn, ConvW& plain, ConvW& rowrun,
+                           ConvW& packed) {
     const HostTensor* ws[2] = {&T_(ctx, HCM_HIGH, wkey), &T_(ctx, HCM_LOW, wkey)};
     const int Co = (int)ws[0]->shape[0];
-    plain = ConvW(); rowrun = ConvW();
-    plain.dt = rowrun.dt = dt;
-    plain.Cout = rowrun.Cout = 2 * Co; plain.Cin = rowrun.Cin = 3; plain.KH = plain.KW = rowrun.KH = rowrun.KW = 7;
-    plain.K = 147; plain.Kp = 160; rowrun.K = 7 * 24; rowrun.Kp = 192;
-    std::vector<float> rp((size_t)2 * Co * plain.Kp, 0.f), rr((size_t)2 * Co * rowrun.Kp, 0.f), bias_all;
+    plain = ConvW(); rowrun = ConvW(); packed = ConvW();
+    plain.dt = rowrun.dt = packed.dt = dt;
+    plain.Cout = rowrun.Cout = packed.Cout = 2 * Co; plain.Cin = rowrun.Cin = packed.Cin = 3;
+    plain.KH = plain.KW = rowrun.KH = rowrun.KW = packed.KH = packed.KW = 7;
+    plain.K = 147; plain.Kp = 160; rowrun.K = 7 * 24; rowrun.Kp = 192; packed.K = packed.Kp = 224;
+    std::vector<float> rp((size_t)2 * Co * plain.Kp, 0.f), rr((size_t)2 * Co * rowrun.Kp, 0.f), rk((size_t)2 * Co * packed.Kp, 0.f), bias_all;
     for (int g = 0; g < 2; ++g) {
         std::vector<float> scale, bias;
         bn_fold(ctx, g == 0 ? HCM_HIGH : HCM_LOW, bn, Co, scale, bias);
@@ -465,10 +490,12 @@ static void make_stem_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string
                         const float v = ws[g]->f[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
                         rp[((size_t)g * Co + o) * plain.Kp + (kh * 7 + kw) * 3 + ci] = v;
                         rr[((size_t)g * Co + o) * rowrun.Kp + kh * 24 + kw * 3 + ci] = v;
+                        rk[((size_t)g * Co + o) * packed.Kp + kh * 32 + kw * 4 + ci] = v;
                     }
     }
     plain.w = up.typed(rp, dt); rowrun.w = up.typed(rr, dt);
     plain.bias = up.f32(bias_all); rowrun.bias = up.f32(bias_all);
+    if (dt != DT_F32) { packed.w = up.typed(rk, dt); packed.bias = up.f32(bias_all); }
 }
 static TrunkW make_tv_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& pre) {
     TrunkW t;
@@ -476,7 +503,7 @@ static TrunkW make_tv_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     t.gn = false;
     t.pair = true;
     t.cin1 = 3;
-    make_stem_pair(ctx, dt, up, pre + "conv1.weight", pre + "bn1", t.conv1, t.conv1_rowrun);
+    make_stem_pair(ctx, dt, up, pre + "conv1.weight", pre + "bn1", t.conv1, t.conv1_rowrun, t.conv1_packed);
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
             const std::string p = pre + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";

@@ -221,3 +221,38 @@ def test_stem_conv(prec, cfg):
     torch.cuda.synchronize()
     err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 64, "f32"), (2, 32, 32, 128, "u8"), (3, 38, 30, 64, "f32"), (1, 16, 16, 128, "f32"),
+                                 (2, 64, 64, 128, "u8"), (1, 2, 2, 64, "f32")])
+def test_stem_conv_packed(prec, cfg):
+    """7x7/2 RGB stem through the packed-frame path (zero-bordered 4-channel frame + ordinary LDS-DMA implicit GEMM)."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cout, src = cfg
+    x_int = torch.randint(0, 256, (B, H, W, 3), generator=torch.Generator().manual_seed(1))
+    scale = 1.0 / 255.0
+    if src == "u8":
+        xd, xcode = x_int.to(torch.uint8).cuda(), L.HCM_U8
+    else:
+        xd, xcode = x_int.float().cuda(), L.HCM_F32
+    w = (_rnd(Cout, 3, 7, 7, seed=2) * (3.0 / 147) ** 0.5).to(tdt).float()
+    bias = _rnd(Cout, seed=3)
+    xin = (x_int.float() * scale).to(tdt).float()
+    ref = F.relu(F.conv2d(xin.permute(0, 3, 1, 2), w, bias, stride=2, padding=3))
+    wl = torch.zeros(Cout, 224)
+    for kh in range(7):
+        for kw in range(7):
+            for ci in range(3):
+                wl[:, kh * 32 + kw * 4 + ci] = w[:, ci, kh, kw]
+    wd, bd = wl.to(tdt).cuda(), bias.cuda()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    assert (Ho, Wo) == (H // 2, W // 2)
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=tdt)
+    scratch = torch.empty(lib.hcm_op_stem_scratch_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+    rc = lib.hcm_op_stem_conv_packed(_p(xd), xcode, _p(wd), _p(bd), _p(y), code, B, H, W, Cout, scale, L.ACT_RELU, _p(scratch), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
