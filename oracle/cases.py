@@ -6,7 +6,7 @@ import numpy as np
 import hcm_pkg
 
 _pkg = hcm_pkg.load()
-from robo_vln_amd.config import HCMConfig  # noqa: E402
+from robo_vln_amd.config import HCMConfig, CMAConfig  # noqa: E402
 from robo_vln_amd import synth             # noqa: E402
 
 # name -> (config kwargs, batch, steps, which models)
@@ -84,3 +84,19 @@ def seq_observations(cfg, T, N):
     ids = synth.make_observations(cfg, N, step=0, seed=SEED)["instruction"]
     obs["instruction"] = np.tile(ids, (T, 1))
     return obs
+
+
+# CMANet flat baseline: name -> (CMAConfig kwargs, batch, steps)
+CMA_CASES = {
+    # paper_configs/cma_robo.yaml: bidirectional LSTM instruction encoder, LSTM state encoders
+    "cma_128_L20": (dict(rgb_hw=128, depth_hw=128, instr_len=20), 2, 3),
+    # GRU state encoders + unidirectional instruction encoder (config/default.py:113 default)
+    "cma_gru_uni_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, rnn_type="GRU", bidirectional=False), 3, 3),
+    # full frame size, L=80
+    "cma_256_L80": (dict(), 1, 2),
+}
+
+
+def cma_case_config(name):
+    kw, batch, steps = CMA_CASES[name]
+    return CMAConfig(**kw).validate(), batch, steps

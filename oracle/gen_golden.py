@@ -173,10 +173,45 @@ def run_seq_case(name):
     return worst
 
 
+def run_cma_case(name):
+    """Reference CMANet (models/cma.py) stepped T times with the scripted episode-reset masks."""
+    cfg, B, T = cases.cma_case_config(name)
+    sd = synth.make_cma_weights(cfg, cases.SEED)
+    net = ref_shims.build_cma(cfg, sd)
+    taps = {}
+    net.instruction_encoder.register_forward_hook(_hook(taps, "instruction"))
+    net.state_encoder.register_forward_hook(_hook(taps, "state", lambda o: o[0]))
+    net.second_state_compress.register_forward_hook(_hook(taps, "compress"))
+    net.second_state_encoder.register_forward_hook(_hook(taps, "rnn2_out", lambda o: o[0]))
+    R = cfg.num_recurrent_layers
+    hid = torch.zeros(R, B, cfg.hidden)
+    orc = hcm_oracle.CMAOracle(cfg, sd)
+    hid_o = torch.zeros(R, B, cfg.hidden)
+    outs, stops, worst = [], [], 0.0
+    for t in range(T):
+        obs_np = synth.make_cma_observations(cfg, B, step=t, seed=cases.SEED)
+        obs = {k: torch.from_numpy(np.asarray(v).astype(np.float32)) for k, v in obs_np.items()}
+        m = cases.step_masks(B, t)
+        with torch.no_grad():
+            out, stop, hid = net((obs, hid.clone(), torch.zeros(B, 2), ref_shims.ref_masks(m)))
+        assert "instruction" not in obs                      # cma.py:228 deletes the key
+        outs.append(out.numpy()); stops.append(stop.numpy())
+        o2, s2, hid_o = orc.forward(obs_np, hid_o, m)
+        worst = max(worst, np.abs(o2.numpy() - outs[-1]).max(), np.abs(s2.numpy() - stops[-1]).max(), np.abs(hid_o.numpy() - hid.numpy()).max())
+    gold = {"out": np.stack(outs), "stop": np.stack(stops), "hidden": hid.numpy(),
+            "meta": np.array(repr(dict(case=name, B=B, T=T, config=repr(cfg.to_dict()),
+                                       note="reference CMANet.forward, masks (B,2,1) workaround, taps from step 0")))}
+    for k, v in taps.items():
+        gold["tap." + k] = cases.subsample(v[0].numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **gold)
+    print(f"[{name}] CMANet T={T} B={B}: oracle-vs-reference worst max-abs {worst:.3e}")
+    return worst
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(cases.CASES) + list(cases.SEQ_CASES))
+    names = sys.argv[1:] or (list(cases.CASES) + list(cases.SEQ_CASES) + list(cases.CMA_CASES))
     bad = 0
     for n in names:
-        w = run_seq_case(n) if n in cases.SEQ_CASES else run_case(n)
+        w = run_cma_case(n) if n in cases.CMA_CASES else run_seq_case(n) if n in cases.SEQ_CASES else run_case(n)
         bad |= (w > 1e-4)
     sys.exit(1 if bad else 0)

@@ -383,3 +383,95 @@ class PolicyOracle:
         pred = torch.argmax(logits, dim=1)                                                                 # :1098
         vel, stop, lo_h2 = self.lo.forward(obs, lo_h, mask, pred)
         return torch.cat([logits, vel, stop], dim=1), hi_h2, lo_h2
+
+
+# ------------------------------------------------------------------ CMANet flat baseline
+def instruction_encoder(ids, w, hidden, bidirectional):
+    """InstructionEncoder.forward with final_state_only=False (models/encoders/instruction_encoder.py:70-92; CMANet sets
+    the flag at cma.py:33-35): lengths = count of non-zero ids; embedding; a (bi)LSTM over the PACKED sequence -- sample
+    b runs exactly len_b steps (the reverse direction starts at its token len_b-1), outputs past len_b are zero; the
+    padded output is cut to the longest sequence of the batch (pad_packed_sequence) and returned as (B, C, Lmax)."""
+    ids = ids.long()
+    B, L = ids.shape
+    lengths = (ids != 0).long().sum(dim=1)
+    lmax = int(lengths.max().item())
+    emb = w("embedding_layer.weight")[ids]                       # (B, L, E)
+
+    def direction(suffix, reverse):
+        Wih, Whh = w("encoder_rnn.weight_ih_l0" + suffix), w("encoder_rnn.weight_hh_l0" + suffix)
+        bih, bhh = w("encoder_rnn.bias_ih_l0" + suffix), w("encoder_rnn.bias_hh_l0" + suffix)
+        h = torch.zeros(B, hidden)
+        c = torch.zeros(B, hidden)
+        out = torch.zeros(B, lmax, hidden)
+        steps = range(lmax - 1, -1, -1) if reverse else range(lmax)
+        for t in steps:
+            act = (t < lengths).float().view(B, 1)
+            g = F.linear(emb[:, t], Wih, bih) + F.linear(h, Whh, bhh)
+            i, f, gg, o = g.chunk(4, dim=1)
+            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h2 = torch.sigmoid(o) * torch.tanh(c2)
+            h = act * h2 + (1 - act) * h
+            c = act * c2 + (1 - act) * c
+            out[:, t] = act * h2
+        return out
+
+    outs = [direction("", False)]
+    if bidirectional:
+        outs.append(direction("_reverse", True))
+    return torch.cat(outs, dim=2).permute(0, 2, 1), lengths     # (B, C, Lmax)
+
+
+def cma_attn(q, k, v, scale, mask=None):
+    """CMANet._attn (cma.py:201-209): one query per sample; logits - mask*1e8, THEN * scale, softmax over positions."""
+    logits = torch.einsum("nc,nci->ni", q, k)
+    if mask is not None:
+        logits = logits - mask.float() * 1e8
+    attn = F.softmax(logits * scale, dim=1)
+    return torch.einsum("ni,nci->nc", attn, v)
+
+
+class CMAOracle:
+    """CMANet.forward (models/cma.py:211-333), non-RCM state encoder, no prev-action embedding."""
+
+    def __init__(self, cfg, sd):
+        self.cfg = cfg
+        self.w = Weights(sd)
+
+    @torch.no_grad()
+    def forward(self, obs, hidden, mask, taps=None):
+        cfg, w = self.cfg, self.w
+        rgb = torch.as_tensor(obs["rgb"]).float()
+        depth = torch.as_tensor(obs["depth"]).float()
+        ids = torch.as_tensor(obs["instruction"]).long()
+        hidden = torch.as_tensor(hidden).float()
+        B = rgb.shape[0]
+        R = cfg.num_recurrent_layers // 2
+        mask = torch.as_tensor(mask).float().reshape(B, -1)[:, 0]                                     # :219
+        dep = depth_resnet_spatial(depth, w.sub("depth_encoder."), cfg.depth_baseplanes // 2).flatten(2)   # :220-221
+        rg = rgb_resnet_spatial(rgb, w.sub("rgb_encoder.")).flatten(2)                                # :223-224
+        ids = ids.expand(B, ids.shape[1])                                                             # :226
+        ins, lengths = instruction_encoder(ids, w.sub("instruction_encoder."), cfg.instr_hidden, cfg.bidirectional)  # :227
+        rgb_in = F.relu(F.linear(rg.mean(2), w("rgb_linear.2.weight"), w("rgb_linear.2.bias")))       # :256
+        dep_in = F.relu(F.linear(dep.flatten(1), w("depth_linear.1.weight"), w("depth_linear.1.bias")))   # :257
+        state_in = torch.cat([rgb_in, dep_in], dim=1)                                                 # :262
+        state, hid1 = rnn_forward(state_in, hidden[:R], mask, w.sub("state_encoder."), cfg.rnn_type)  # :263-270
+        scale = w("_scale")
+        q_state = F.linear(state, w("state_q.weight"), w("state_q.bias"))                             # :272
+        k_text = F.conv1d(ins, w("text_k.weight"), w("text_k.bias"))                                  # :273
+        text_mask = (ins == 0.0).all(dim=1)                                                           # :274
+        text = cma_attn(q_state, k_text, ins, scale, text_mask)                                       # :275-277
+        hh = cfg.hidden // 2
+        rgb_k, rgb_v = torch.split(F.conv1d(rg, w("rgb_kv.weight"), w("rgb_kv.bias")), hh, dim=1)    # :281-283
+        dep_k, dep_v = torch.split(F.conv1d(dep, w("depth_kv.weight"), w("depth_kv.bias")), hh, dim=1)   # :284-286
+        q_text = F.linear(text, w("text_q.weight"), w("text_q.bias"))                                 # :288
+        rgb_att = cma_attn(q_text, rgb_k, rgb_v, scale)                                               # :289
+        dep_att = cma_attn(q_text, dep_k, dep_v, scale)                                               # :290
+        x = torch.cat([state, text, rgb_att, dep_att], dim=1)                                         # :309-311
+        x = F.relu(F.linear(x, w("second_state_compress.0.weight"), w("second_state_compress.0.bias")))   # :312
+        x2, hid2 = rnn_forward(x, hidden[R:], mask, w.sub("second_state_encoder."), cfg.rnn_type)     # :313-318
+        out = F.linear(x2, w("linear.weight"), w("linear.bias"))                                      # :331
+        stop = F.linear(x2, w("stop_linear.weight"), w("stop_linear.bias"))                           # :332
+        if taps is not None:
+            taps.update(depth_spatial=dep, rgb_spatial=rg, instruction=ins, state=state, text=text, rgb_att=rgb_att,
+                        depth_att=dep_att, compress=x, rnn2_out=x2)
+        return out, stop, torch.cat([hid1, hid2], dim=0)

@@ -352,3 +352,29 @@ def ref_masks(mask_b):
     (input-only workaround)."""
     m = torch.as_tensor(mask_b, dtype=torch.float32).view(-1, 1, 1)
     return m.expand(-1, 2, 1).contiguous()
+
+
+def cma_model_config(cfg):
+    """CMAConfig -> the attr-dict CMANet's constructor reads (cma.py:28-186)."""
+    return AttrDict(
+        TORCH_GPU_ID=0, ablate_instruction=False, ablate_depth=False, ablate_rgb=False,
+        INSTRUCTION_ENCODER=AttrDict(vocab_size=cfg.vocab_size, embedding_size=cfg.embedding_size, hidden_size=cfg.instr_hidden,
+                                     rnn_type=cfg.instr_rnn, bidirectional=cfg.bidirectional, final_state_only=True,
+                                     use_pretrained_embeddings=False, fine_tune_embeddings=False),
+        DEPTH_ENCODER=AttrDict(cnn_type="VlnResnetDepthEncoder", output_size=cfg.depth_out, backbone="resnet50",
+                               ddppo_checkpoint="NONE"),
+        RGB_ENCODER=AttrDict(cnn_type="TorchVisionResNet50", output_size=cfg.rgb_out, resnet_output_size=256),
+        CMA=AttrDict(use=True, use_prev_action=False, rcm_state_encoder=False),
+        STATE_ENCODER=AttrDict(hidden_size=cfg.hidden, rnn_type=cfg.rnn_type),
+        PROGRESS_MONITOR=AttrDict(use=False, alpha=1.0),
+    )
+
+
+def build_cma(cfg, sd=None):
+    """Construct the reference CMANet (robo_vln_trainer.py:326-331) and load a numpy state_dict with strict=True."""
+    install()
+    from robo_vln_baselines.models.cma import CMANet
+    net = CMANet(obs_space(cfg), cfg.num_actions, cma_model_config(cfg)).eval()
+    if sd is not None:
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return net

@@ -92,3 +92,59 @@ def baseline_config(idx: int) -> "HCMConfig":
     if idx == 4:   # ResNet50 + N=6, L=160
         return HCMConfig(instr_len=160, vla_layers=6)
     raise IndexError(idx)
+
+
+@dataclass
+class CMAConfig:
+    """`CMANet` flat baseline (models/cma.py:28-186) with the values of paper_configs/cma_robo.yaml over
+    config/default.py:97-115,:180-216: bidirectional LSTM instruction encoder over a 2504-word vocabulary, both
+    ResNet-50 encoders in spatial mode, two recurrent state encoders."""
+    rgb_hw: int = 256
+    depth_hw: int = 256
+    instr_len: int = 80            # padded instruction length handed to the model (INSTRUCTION_ENCODER.max_length = 200)
+    vocab_size: int = 2504         # INSTRUCTION_ENCODER.vocab_size
+    embedding_size: int = 50
+    instr_hidden: int = 256        # INSTRUCTION_ENCODER.hidden_size
+    bidirectional: bool = True     # cma_robo.yaml
+    instr_rnn: str = "LSTM"
+    rgb_out: int = 256
+    depth_out: int = 128
+    depth_baseplanes: int = 32
+    hidden: int = 512
+    rnn_type: str = "LSTM"
+    num_actions: int = 2           # robo_vln_trainer.py:327-331
+    use_prev_action: bool = False
+    rcm_state_encoder: bool = False
+    progress_monitor: bool = False
+    ablate_instruction: bool = False
+    ablate_depth: bool = False
+    ablate_rgb: bool = False
+
+    def validate(self):
+        if self.use_prev_action or self.rcm_state_encoder:
+            raise ValueError("CMA.use_prev_action / CMA.rcm_state_encoder are not built (default.py:211-212 are False)")
+        if self.instr_rnn != "LSTM":
+            raise ValueError("INSTRUCTION_ENCODER.rnn_type: only LSTM (the default, default.py:111) is built")
+        if self.rnn_type not in ("LSTM", "GRU"):
+            raise ValueError("STATE_ENCODER.rnn_type must be LSTM or GRU")
+        if self.ablate_instruction or self.ablate_depth or self.ablate_rgb or self.progress_monitor:
+            raise ValueError("ablation / progress-monitor branches are not built")
+        return self
+
+    @property
+    def instr_out(self):           # InstructionEncoder.output_size (instruction_encoder.py:49-51)
+        return self.instr_hidden * (2 if self.bidirectional else 1)
+
+    @property
+    def num_recurrent_layers(self):   # cma.py:190-194: both state encoders
+        return 2 * (2 if self.rnn_type == "LSTM" else 1)
+
+    def depth_final_spatial(self):
+        return int((self.depth_hw // 2) / 32)
+
+    def depth_compress_channels(self):
+        fs = self.depth_final_spatial()
+        return int(round(2048 / (fs * fs)))
+
+    def to_dict(self):
+        return asdict(self)

@@ -15,7 +15,7 @@ Appendix B).  `oracle/gen_golden.py` checks them with
 import math
 import numpy as np
 
-from .config import HCMConfig
+from .config import HCMConfig, CMAConfig
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -259,6 +259,48 @@ def low_level_spec(cfg: HCMConfig):
     return s
 
 
+def _rnn_generic(prefix, gates, hs, in_f, suffix=""):
+    return [
+        (prefix + "weight_ih_l0" + suffix, (gates * hs, in_f), "w", (in_f, 1.0)),
+        (prefix + "weight_hh_l0" + suffix, (gates * hs, hs), "w", (hs, 1.0)),
+        (prefix + "bias_ih_l0" + suffix, (gates * hs,), "b", None),
+        (prefix + "bias_hh_l0" + suffix, (gates * hs,), "b", None),
+    ]
+
+
+def cma_spec(cfg):
+    """CMANet state_dict (models/cma.py:28-186; InstructionEncoder instruction_encoder.py:9-47)."""
+    cfg.validate()
+    fs = cfg.depth_final_spatial()
+    cc = cfg.depth_compress_channels()
+    dC, rC = cc + 64, 2048 + 64
+    hh = cfg.hidden // 2
+    g = 4 if cfg.rnn_type == "LSTM" else 3
+    s = [("instruction_encoder.embedding_layer.weight", (cfg.vocab_size, cfg.embedding_size), "emb", 1.0)]
+    s += _rnn_generic("instruction_encoder.encoder_rnn.", 4, cfg.instr_hidden, cfg.embedding_size)
+    if cfg.bidirectional:
+        s += _rnn_generic("instruction_encoder.encoder_rnn.", 4, cfg.instr_hidden, cfg.embedding_size, "_reverse")
+    s += habitat_gn_resnet50_spec("depth_encoder.visual_encoder.", 1, cfg.depth_baseplanes, cc)
+    s += [("depth_encoder.spatial_embeddings.weight", (fs * fs, 64), "emb", 0.5)]
+    s += torchvision_resnet50_spec("rgb_encoder.cnn.", with_fc=False)
+    s += [("rgb_encoder.spatial_embeddings.weight", (16, 64), "emb", 0.5)]
+    s += _linear("rgb_linear.2", cfg.rgb_out, rC, gain=RELU_GAIN)
+    s += _linear("depth_linear.1", cfg.depth_out, dC * fs * fs, gain=RELU_GAIN)
+    s += _rnn_generic("state_encoder.rnn.", g, cfg.hidden, cfg.rgb_out + cfg.depth_out)
+    s += [("rgb_kv.weight", (hh + cfg.rgb_out, rC, 1), "w", (rC, 1.0)), ("rgb_kv.bias", (hh + cfg.rgb_out,), "b", None)]
+    s += [("depth_kv.weight", (hh + cfg.depth_out, dC, 1), "w", (dC, 1.0)), ("depth_kv.bias", (hh + cfg.depth_out,), "b", None)]
+    s += _linear("state_q", hh, cfg.hidden, gain=2.0)
+    s += [("text_k.weight", (hh, cfg.instr_out, 1), "w", (cfg.instr_out, 2.0)), ("text_k.bias", (hh,), "b", None)]
+    s += _linear("text_q", hh, cfg.instr_out, gain=2.0)
+    s += [("_scale", (), "const", 1.0 / math.sqrt(hh))]
+    s += _linear("second_state_compress.0", cfg.hidden, cfg.hidden + cfg.rgb_out + cfg.depth_out + cfg.instr_out, gain=RELU_GAIN)
+    s += _rnn_generic("second_state_encoder.rnn.", g, cfg.hidden, cfg.hidden)
+    s += _linear("progress_monitor", 1, cfg.hidden)
+    s += _linear("linear", cfg.num_actions, cfg.hidden)
+    s += _linear("stop_linear", 1, cfg.hidden)
+    return s
+
+
 def materialize(spec, model_tag: str, seed: int = 0):
     """spec -> {key: np.ndarray}.  `model_tag` separates the hi and lo models' streams."""
     out = {}
@@ -266,6 +308,9 @@ def materialize(spec, model_tag: str, seed: int = 0):
         n = int(np.prod(shape)) if len(shape) else 1
         if kind == "nbt":
             out[key] = np.zeros((), dtype=np.int64)
+            continue
+        if kind == "const":
+            out[key] = np.full(shape, aux, dtype=np.float32)
             continue
         u = uniform01(model_tag + "/" + key, n, seed)
         if kind == "w":
@@ -306,5 +351,27 @@ def make_observations(cfg: HCMConfig, batch: int, step: int = 0, seed: int = 0, 
     for b in range(B):
         ids[b, 0] = 101
         ids[b, lens[b] - 1] = 102
+        ids[b, lens[b]:] = 0
+    return {"rgb": rgb, "depth": depth.astype(np.float32), "instruction": ids}
+
+
+def make_cma_weights(cfg, seed: int = 0):
+    """CMANet state_dict as a numpy fp32 dict (row 0 of the word embedding is the padding row: zeros)."""
+    sd = materialize(cma_spec(cfg), "cma", seed)
+    sd["instruction_encoder.embedding_layer.weight"][0] = 0.0
+    return sd
+
+
+def make_cma_observations(cfg, batch: int, step: int = 0, seed: int = 0, rgb_uint8: bool = False):
+    """As make_observations, with instruction ids from the CMANet vocabulary: 1..vocab-1, 0-padded, per-row length
+    in [L/2, L] (InstructionEncoder derives the lengths from `!= 0`, instruction_encoder.py:79)."""
+    B, L = batch, cfg.instr_len
+    tag = f"obs/{step}"
+    rgb = np.floor(uniform01(tag + "/rgb", B * cfg.rgb_hw * cfg.rgb_hw * 3, seed) * 256.0)
+    rgb = rgb.reshape(B, cfg.rgb_hw, cfg.rgb_hw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
+    depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
+    ids = randint("obs/cma_instr", B * L, 1, cfg.vocab_size, seed).reshape(B, L)
+    lens = randint("obs/cma_instr_len", B, max(2, L // 2), L + 1, seed)
+    for b in range(B):
         ids[b, lens[b]:] = 0
     return {"rgb": rgb, "depth": depth.astype(np.float32), "instruction": ids}

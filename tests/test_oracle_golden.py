@@ -50,6 +50,37 @@ def test_oracle_matches_reference_golden(name):
     np.testing.assert_allclose(lo_h.numpy(), gold["lo_hidden"], atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("name", list(cases.CMA_CASES))
+def test_cma_oracle_matches_reference_golden(name):
+    """CMANet flat baseline (models/cma.py:211-333): outputs, final hidden state and step-0 intermediates."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, B, T = cases.cma_case_config(name)
+    orc = hcm_oracle.CMAOracle(cfg, synth.make_cma_weights(cfg, cases.SEED))
+    hid = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden)
+    for t in range(T):
+        taps = {}
+        out, stop, hid = orc.forward(synth.make_cma_observations(cfg, B, step=t, seed=cases.SEED), hid, cases.step_masks(B, t), taps)
+        np.testing.assert_allclose(out.numpy(), gold["out"][t], atol=TOL, rtol=0)
+        np.testing.assert_allclose(stop.numpy(), gold["stop"][t], atol=TOL, rtol=0)
+        if t == 0:
+            for k in ("instruction", "state", "compress", "rnn2_out"):
+                np.testing.assert_allclose(cases.subsample(taps[k].numpy()), gold["tap." + k], atol=TOL, rtol=0)
+    np.testing.assert_allclose(hid.numpy(), gold["hidden"], atol=TOL, rtol=0)
+
+
+def test_instruction_encoder_packed_semantics():
+    """Packed (bi)LSTM: outputs beyond a row's length are zero, the output is cut to the longest row, and the reverse
+    direction of a short row starts at ITS last token (instruction_encoder.py:79-92)."""
+    cfg = cases.CMAConfig(rgb_hw=128, depth_hw=128, instr_len=10)
+    w = hcm_oracle.Weights(synth.make_cma_weights(cfg, 1)).sub("instruction_encoder.")
+    ids = torch.tensor([[5, 6, 7, 0, 0, 0, 0, 0, 0, 0], [9, 8, 7, 6, 5, 4, 0, 0, 0, 0]])
+    out, lengths = hcm_oracle.instruction_encoder(ids, w, cfg.instr_hidden, True)
+    assert out.shape == (2, 512, 6) and lengths.tolist() == [3, 6]
+    assert (out[0, :, 3:] == 0).all() and (out[0, :, :3] != 0).any()
+    alone, _ = hcm_oracle.instruction_encoder(ids[:1, :3], w, cfg.instr_hidden, True)
+    np.testing.assert_allclose(out[0, :, :3].numpy(), alone[0].numpy(), atol=1e-6)
+
+
 def test_spatial_embedding_view_quirk():
     """channel c, pixel (y,x) of the pos-emb block reads E.flat[c*16+y*4+x]."""
     E = torch.arange(16 * 64, dtype=torch.float32).view(16, 64)
