@@ -35,7 +35,7 @@ enum hcm_status {
 };
 
 enum hcm_dtype { HCM_F32 = 0, HCM_BF16 = 1, HCM_I32 = 2, HCM_I64 = 3, HCM_U8 = 4, HCM_F16 = 5 };
-enum hcm_model { HCM_HIGH = 0, HCM_LOW = 1 };
+enum hcm_model { HCM_HIGH = 0, HCM_LOW = 1, HCM_CMA = 2 /* CMANet flat baseline: hcm_cma_create handles only */ };
 enum hcm_encoder { HCM_ENC_RESNET = 0, HCM_ENC_SIMPLECNN = 1 };
 enum hcm_rnn { HCM_LSTM = 0, HCM_GRU = 1 };
 
@@ -141,6 +141,38 @@ int hcm_query(hcm_handle h, int what, int64_t* out);
 const char* hcm_last_error(hcm_handle h);
 
 void hcm_destroy(hcm_handle h);
+
+/* ---- CMANet flat baseline ----
+ * `CMANet` (models/cma.py:19-333; constructed at robo_vln_trainer.py:326-331 with num_actions = 2) behind the same
+ * handle type: hcm_cma_create -> hcm_load_tensor(h, HCM_CMA, key, ...) for every entry of the module's state_dict
+ * (strict) -> hcm_finalize -> hcm_cma_forward ...; hcm_query / hcm_last_error / hcm_destroy work as for the HCM handles. */
+typedef struct hcm_cma_config {
+    int32_t struct_size;
+    int32_t precision;            /* HCM_BF16 (16-bit trunks, fp32 text / recurrent / attention side) or HCM_F32 */
+    int32_t max_batch;
+    int32_t rgb_h, rgb_w, depth_h, depth_w;
+    int32_t instr_len;            /* padded token count per instruction handed to forward (<= 256) */
+    int32_t vocab_size, embedding_size, instr_hidden, bidirectional;   /* MODEL.INSTRUCTION_ENCODER.* (default.py:97-115) */
+    int32_t rgb_out, depth_out, depth_baseplanes;
+    int32_t hidden, rnn_type;     /* MODEL.STATE_ENCODER.* for both state encoders */
+    int32_t num_actions;          /* 2 */
+    int32_t use_prev_action;      /* must be 0 (MODEL.CMA.use_prev_action default) */
+    int32_t rcm_state_encoder;    /* must be 0 (MODEL.CMA.rcm_state_encoder default) */
+    int32_t progress_monitor;     /* must be 0: the auxiliary loss is a training-only branch (cma.py:320-329) */
+    int32_t reserved[8];
+} hcm_cma_config;
+
+int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out);
+
+/* Replaces `output, stop_out, rnn_hidden_states = actor_critic((observations, rnn_hidden_states, prev_actions, masks))`
+ * (robo_vln_trainer.py:1096 -> models/cma.py:211-333).
+ *   rgb (B,H,W,3) HCM_F32 / HCM_U8; depth (B,H,W,1) f32; ids (B,L) HCM_I32 / HCM_I64 / HCM_F32, 0 = padding
+ *   h_in (R,B,hidden) f32 with R = hcm_query(HCM_NUM_RECURRENT_LAYERS) = both state encoders (4 for LSTM, 2 for GRU)
+ *   mask (B,) f32 (column 0 of the reference's masks, cma.py:219)
+ *   out (B,num_actions), stop (B,1), h_out (R,B,hidden): f32 outputs.  The reference writes the new hidden state into
+ *   the tensor it was given and returns it; here h_out may alias h_in to get the same effect. */
+int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+                    const float* h_in, const float* mask, float* out, float* stop, float* h_out, void* stream);
 
 /* ---- test / profiling hooks (not part of the drop-in surface) ---- */
 

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhcm.so")
 
 HCM_F32, HCM_BF16, HCM_I32, HCM_I64, HCM_U8, HCM_F16 = 0, 1, 2, 3, 4, 5
-HCM_HIGH, HCM_LOW = 0, 1
+HCM_HIGH, HCM_LOW, HCM_CMA = 0, 1, 2
 HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
@@ -28,7 +28,17 @@ class HcmConfigStruct(C.Structure):
         "build_high", "build_low", "use_prev_action", "ablate_instruction", "progress_monitor")] + [("reserved", C.c_int32 * 8)]
 
 
+class HcmCmaConfigStruct(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "precision", "max_batch", "rgb_h", "rgb_w", "depth_h", "depth_w", "instr_len",
+        "vocab_size", "embedding_size", "instr_hidden", "bidirectional", "rgb_out", "depth_out", "depth_baseplanes",
+        "hidden", "rnn_type", "num_actions", "use_prev_action", "rcm_state_encoder", "progress_monitor")] + [("reserved", C.c_int32 * 8)]
+
+
 EXPORTS = {
+    "hcm_cma_create": (C.c_int, [C.POINTER(HcmCmaConfigStruct), C.POINTER(C.c_void_p)]),
+    "hcm_cma_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_create": (C.c_int, [C.POINTER(HcmConfigStruct), C.POINTER(C.c_void_p)]),
     "hcm_load_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "hcm_finalize": (C.c_int, [C.c_void_p]),

@@ -11,6 +11,10 @@ void build_spec_high(hcm_ctx* ctx);
 void build_spec_low(hcm_ctx* ctx);
 void prepare_high(hcm_ctx* ctx);
 void prepare_low(hcm_ctx* ctx);
+void build_spec_cma(hcm_ctx* ctx);
+void prepare_cma(hcm_ctx* ctx);
+void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
+             const float* mask, float* out, float* stop, float* h_out);
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
               int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
               int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out, int T = 1);
@@ -95,10 +99,57 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     return HCM_OK;
 }
 
+int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
+    hcm_ctx* h = nullptr;
+    REQUIRE(cfg && out, HCM_ERR_ARG, "hcm_cma_create: null argument");
+    REQUIRE(cfg->struct_size == (int32_t)sizeof(hcm_cma_config), HCM_ERR_ARG, "hcm_cma_create: struct_size mismatch");
+    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16, HCM_ERR_ARG, "precision must be HCM_F32 or HCM_BF16");
+    REQUIRE(cfg->max_batch >= 1, HCM_ERR_ARG, "max_batch must be >= 1");
+    REQUIRE(!cfg->use_prev_action && !cfg->rcm_state_encoder, HCM_ERR_UNSUPPORTED,
+            "CMA.use_prev_action / CMA.rcm_state_encoder (default.py:211-212 default False) are not built");
+    REQUIRE(!cfg->progress_monitor, HCM_ERR_UNSUPPORTED, "the progress monitor is a training-only auxiliary loss (cma.py:320-329)");
+    REQUIRE(cfg->rnn_type == HCM_LSTM || cfg->rnn_type == HCM_GRU, HCM_ERR_ARG, "STATE_ENCODER.rnn_type must be LSTM or GRU");
+    REQUIRE(cfg->hidden >= 64 && cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
+    REQUIRE(cfg->instr_hidden >= 4 && cfg->instr_hidden % 4 == 0 && cfg->embedding_size >= 1 && cfg->vocab_size >= 2, HCM_ERR_ARG,
+            "bad INSTRUCTION_ENCODER sizes");
+    REQUIRE(cfg->instr_len >= 1 && cfg->instr_len <= 256, HCM_ERR_UNSUPPORTED, "1 <= instr_len <= 256");
+    REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
+    REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0, HCM_ERR_UNSUPPORTED, "depth frame size must be a multiple of 64");
+    REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
+    REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
+    REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0 && cfg->num_actions >= 1, HCM_ERR_UNSUPPORTED, "bad output sizes");
+    h = new hcm_ctx();
+    h->kind = 1;
+    h->cma_cfg = *cfg;
+    std::memset(&h->cfg, 0, sizeof(h->cfg));
+    hcm_config& c = h->cfg;                      // the fields the shared trunk / recurrent code reads
+    c.struct_size = (int32_t)sizeof(hcm_config);
+    c.precision = cfg->precision; c.max_batch = cfg->max_batch;
+    c.rgb_h = cfg->rgb_h; c.rgb_w = cfg->rgb_w; c.depth_h = cfg->depth_h; c.depth_w = cfg->depth_w; c.instr_len = cfg->instr_len;
+    c.rgb_encoder = c.depth_encoder = HCM_ENC_RESNET;
+    c.rgb_out = cfg->rgb_out; c.depth_out = cfg->depth_out; c.depth_baseplanes = cfg->depth_baseplanes;
+    c.hidden = cfg->hidden; c.rnn_type = cfg->rnn_type; c.num_actions = cfg->num_actions;
+    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
+    h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
+    if (h->dt == DT_BF16) h->dt_depth = DT_F16;  // GroupNorm depth trunk on fp16 tiles
+    h->use_graph = false;
+    try {
+        build_spec_cma(h);
+    } catch (const std::exception& e) {
+        std::string m = e.what();
+        delete h;
+        h = nullptr;
+        return fail(nullptr, HCM_ERR_ARG, m);
+    }
+    *out = h;
+    return HCM_OK;
+}
+
 int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
     REQUIRE(h, HCM_ERR_ARG, "null handle");
     REQUIRE(!h->finalized, HCM_ERR_STATE, "hcm_load_tensor after hcm_finalize");
-    REQUIRE(model == HCM_HIGH || model == HCM_LOW, HCM_ERR_ARG, "model must be HCM_HIGH or HCM_LOW");
+    if (h->kind == 1) REQUIRE(model == HCM_CMA, HCM_ERR_ARG, "a CMANet handle takes model = HCM_CMA");
+    else REQUIRE(model == HCM_HIGH || model == HCM_LOW, HCM_ERR_ARG, "model must be HCM_HIGH or HCM_LOW");
     REQUIRE(key && data && (shape || ndim == 0), HCM_ERR_ARG, "null argument");
     auto& sd = h->sd[model];
     auto it = sd.find(key);
@@ -126,6 +177,10 @@ int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, 
 static void dry_run(hcm_ctx* h, int B) {
     h->arena.dry = true;
     h->arena.peak = 0;
+    if (h->kind == 1) {
+        run_cma(h, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return;
+    }
     run_step(h, h->cfg.build_high != 0, h->cfg.build_low != 0, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr,
              nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr);
 }
@@ -133,10 +188,14 @@ static void dry_run(hcm_ctx* h, int B) {
 int hcm_finalize(hcm_handle h) {
     REQUIRE(h, HCM_ERR_ARG, "null handle");
     REQUIRE(!h->finalized, HCM_ERR_STATE, "hcm_finalize called twice");
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 3; ++m)
         for (auto& kv : h->sd[m])
             if (!kv.second.loaded) return fail(h, HCM_ERR_KEY, std::string("Missing key in state_dict: ") + kv.first);
     try {
+        if (h->kind == 1) {
+            prepare_cma(h);
+            if (hipMalloc((void**)&h->len_buf, (size_t)h->cfg.max_batch * sizeof(int)) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+        }
         if (h->cfg.build_high) prepare_high(h);
         if (h->cfg.build_low) prepare_low(h);
         dry_run(h, h->cfg.max_batch);
@@ -158,7 +217,7 @@ int hcm_finalize(hcm_handle h) {
         // (opt-in: HCM_TUNE=1.  Isolated per-kernel timings rank variants differently from the concurrent multi-stream
         //  schedule, where the built-in heuristic measured faster end to end)
         const char* nt = getenv("HCM_TUNE");
-        if (nt && atoi(nt)) {
+        if (nt && atoi(nt) && h->kind == 0) {
             const hcm_config& c = h->cfg;
             const size_t B = c.max_batch, R = c.rnn_type == HCM_LSTM ? 2 : 1;
             const size_t n_rgb = B * c.rgb_h * c.rgb_w * 3 * 4, n_dep = B * c.depth_h * c.depth_w * 4, n_ids = B * c.instr_len * 8;
@@ -201,7 +260,7 @@ int hcm_finalize(hcm_handle h) {
         return fail(h, HCM_ERR_HIP, std::string("hcm_finalize: ") + e.what());
     }
     // host copies are no longer needed
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 3; ++m)
         for (auto& kv : h->sd[m]) { std::vector<float>().swap(kv.second.f); }
     h->finalized = true;
     return HCM_OK;
@@ -245,6 +304,22 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
     try {
         run_step(h, false, true, rgb, rgb_dtype, depth, nullptr, DT_I64, B, nullptr, h_in, mask, subtask, nullptr, 0, vel,
                  h->cfg.lo_actions, stop, 1, nullptr, h_out);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
+}
+
+int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+                    const float* h_in, const float* mask, float* out, float* stop, float* h_out, void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->kind == 1, HCM_ERR_STATE, "not a CMANet handle (hcm_cma_create)");
+    REQUIRE(rgb && depth && ids && h_in && mask && out && stop && h_out, HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
+    h->stream = (hipStream_t)stream;
+    try {
+        run_cma(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, out, stop, h_out);
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, e.what());
     }
@@ -359,7 +434,7 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, co
 int hcm_query(hcm_handle h, int what, int64_t* out) {
     REQUIRE(h && out, HCM_ERR_ARG, "null argument");
     switch (what) {
-        case HCM_NUM_RECURRENT_LAYERS: *out = h->cfg.rnn_type == HCM_LSTM ? 2 : 1; break;
+        case HCM_NUM_RECURRENT_LAYERS: *out = (h->cfg.rnn_type == HCM_LSTM ? 2 : 1) * (h->kind == 1 ? 2 : 1); break;   // cma.py:190-194
         case HCM_HIDDEN_SIZE: *out = h->cfg.hidden; break;
         case HCM_NUM_ACTIONS: *out = h->cfg.num_actions; break;
         case HCM_RECORD_WIDTH: *out = h->cfg.num_actions + h->cfg.lo_actions + 1; break;
@@ -380,6 +455,7 @@ void hcm_destroy(hcm_handle h) {
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
+    if (h->len_buf) (void)hipFree(h->len_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 4; ++i) {

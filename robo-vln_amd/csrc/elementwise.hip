@@ -612,6 +612,112 @@ hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ CMANet instruction encoder
+// InstructionEncoder.forward (models/encoders/instruction_encoder.py:70-92): lengths = #non-zero ids, embedding lookup.
+// x[row][0..E) = table[id], zero-padded to ldx columns; one block per sample also counts its length.
+template <typename I>
+__global__ void instr_embed_kernel(const I* __restrict__ ids, const float* __restrict__ table, float* __restrict__ x,
+                                   int* __restrict__ lengths, int L, int E, int ldx, int vocab) {
+    const int b = blockIdx.x;
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) mine += ((long)ids[(size_t)b * L + t] != 0) ? 1 : 0;
+    if (mine) atomicAdd(&cnt, mine);
+    for (int e = threadIdx.x; e < L * ldx; e += blockDim.x) {
+        const int t = e / ldx, j = e - t * ldx;
+        long id = (long)ids[(size_t)b * L + t];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        x[((size_t)b * L + t) * ldx + j] = j < E ? table[(size_t)id * E + j] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lengths[b] = cnt;
+}
+hipError_t launch_instr_embed(const void* ids, int ids_dt, const float* table, float* x, int* lengths, int B, int L, int E, int ldx,
+                              int vocab, hipStream_t s) {
+    if (ids_dt == DT_I64) hipLaunchKernelGGL(instr_embed_kernel<int64_t>, dim3(B), dim3(256), 0, s, (const int64_t*)ids, table, x, lengths, L, E, ldx, vocab);
+    else if (ids_dt == DT_I32) hipLaunchKernelGGL(instr_embed_kernel<int32_t>, dim3(B), dim3(256), 0, s, (const int32_t*)ids, table, x, lengths, L, E, ldx, vocab);
+    else if (ids_dt == DT_F32) hipLaunchKernelGGL(instr_embed_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)ids, table, x, lengths, L, E, ldx, vocab);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// One time step of the PACKED LSTM (nn.LSTM over pack_padded_sequence): sample b is active at step t iff t < len_b; an
+// inactive sample keeps (h, c) and emits zeros -- which makes the reverse direction start at the sample's own last
+// token.  pre = x_t W_ih^T + b_ih + b_hh for every token [B*L][4H]; gh = h W_hh^T [B][4H]; gate order i,f,g,o.
+__global__ void instr_lstm_cell_kernel(const float* __restrict__ pre, const float* __restrict__ gh, float* __restrict__ h,
+                                       float* __restrict__ c, const int* __restrict__ lengths, float* __restrict__ out, int t, int L,
+                                       int Hd, int ld_out, int col0) {
+    const int b = blockIdx.x;
+    const bool act = t < lengths[b];
+    const float* p = pre + ((size_t)b * L + t) * 4 * Hd;
+    const float* g = gh + (size_t)b * 4 * Hd;
+    float* o = out + ((size_t)b * L + t) * ld_out + col0;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        if (!act) { o[j] = 0.f; continue; }
+        const float gi = sigmoidf_(p[j] + g[j]), gf = sigmoidf_(p[Hd + j] + g[Hd + j]);
+        const float gg = tanhf(p[2 * Hd + j] + g[2 * Hd + j]), go = sigmoidf_(p[3 * Hd + j] + g[3 * Hd + j]);
+        const float c2 = gf * c[(size_t)b * Hd + j] + gi * gg;
+        const float h2 = go * tanhf(c2);
+        c[(size_t)b * Hd + j] = c2;
+        h[(size_t)b * Hd + j] = h2;
+        o[j] = h2;
+    }
+}
+hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, float* c, const int* lengths, float* out, int t, int B,
+                                  int L, int Hd, int ld_out, int col0, hipStream_t s) {
+    hipLaunchKernelGGL(instr_lstm_cell_kernel, dim3(B), dim3(256), 0, s, pre, gh, h, c, lengths, out, t, L, Hd, ld_out, col0);
+    return hipGetLastError();
+}
+
+// CMANet._attn (models/cma.py:201-209): ONE query per sample over S positions:
+//   logits[s] = q . k[s];  logits -= 1e8 where masked (s >= len_b when lengths != null);  p = softmax(logits * scale);
+//   out = sum_s p[s] v[s].   q [B][D] (ldq), k [B][S][.] (ldk), v [B][S][.] (ldv), out [B][.] (ldo); all f32.
+__global__ void attn1q_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v,
+                              int ldv, const int* __restrict__ lengths, float* __restrict__ out, int ldo, int S, int D, int Dv,
+                              float scale) {
+    extern __shared__ float sh[];            // [S] probabilities
+    __shared__ float red[2];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float* qb = q + (size_t)b * ldq;
+    const int len = lengths ? lengths[b] : S;
+    for (int sidx = wave; sidx < S; sidx += nw) {
+        const float* kr = k + ((size_t)b * S + sidx) * ldk;
+        float acc = 0.f;
+        for (int j = lane; j < D; j += 64) acc += qb[j] * kr[j];
+        acc = wave_sum(acc);
+        if (lane == 0) sh[sidx] = (acc - (sidx >= len ? 1e8f : 0.f)) * scale;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -3.0e38f;
+        for (int i = lane; i < S; i += 64) m = fmaxf(m, sh[i]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int i = lane; i < S; i += 64) sum += expf(sh[i] - m);
+        sum = wave_sum(sum);
+        if (lane == 0) { red[0] = m; red[1] = 1.f / sum; }
+    }
+    __syncthreads();
+    const float m = red[0], inv = red[1];
+    for (int i = threadIdx.x; i < S; i += blockDim.x) sh[i] = expf(sh[i] - m) * inv;
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < Dv; cidx += blockDim.x) {
+        float acc = 0.f;
+        const float* vb = v + (size_t)b * S * ldv + cidx;
+        for (int i = 0; i < S; ++i) acc += sh[i] * vb[(size_t)i * ldv];
+        out[(size_t)b * ldo + cidx] = acc;
+    }
+}
+hipError_t launch_attn1q(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int* lengths, float* out,
+                         int ldo, int B, int S, int D, int Dv, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(attn1q_kernel, dim3(B), dim3(256), S * sizeof(float), s, q, ldq, k, ldk, v, ldv, lengths, out, ldo, S, D, Dv, scale);
+    return hipGetLastError();
+}
+
 // torch.argmax(output, dim=1) (hierarchical_trainer.py:1098): first maximal index
 __global__ void argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ pred, int B, int n, int ld) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -489,6 +489,121 @@ struct Fwd {
         tap("lo.rnn_in", lb.xh, false, {B, lb.ldx});
     }
 
+    // ---------------------------------------------------------------- CMANet.forward (models/cma.py:211-333)
+    void cma_step(const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
+                  const float* mask, float* out, float* stop, float* h_out) {
+        ar.reset();
+        const hcm_config& c = ctx->cfg;
+        const hcm_cma_config& m = ctx->cma_cfg;
+        const CmaW& w = ctx->cma;
+        const int L = c.instr_len, Hi = m.instr_hidden, C = Hi * w.dirs, E = m.embedding_size;
+        const int H = c.hidden, hh = H / 2, rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
+        const int R = c.rnn_type == HCM_LSTM ? 2 : 1;
+        const bool multi = ctx->concurrent && !ctx->taps_on;
+        hipStream_t main_s = ctx->stream;
+        hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s;
+        // buffers shared across the forked chains
+        use(ctx->dt_vla);
+        void* rgb_tok = alloc_t((size_t)B * 16 * rC);
+        void* dep_tok = alloc_t((size_t)B * dS * dC);
+        float* ins = alloc_f((size_t)B * L * C);                 // (B, C, L) of the reference, token-major [B][L][C]
+        if (multi) fork_join_begin(2);
+
+        // chain A (aux 0): instruction encoder (instruction_encoder.py:70-92) -- embedding, input projection of every token
+        // at once, then L packed-LSTM steps per direction.  All L steps run (no host sync on the longest length): steps
+        // past a sample's length emit zeros, which the attention masks exactly as pad_packed_sequence's cut does.
+        on(a0);
+        {
+            const int ldx = w.ih[0].Kp;
+            float* x = alloc_f((size_t)B * L * ldx);
+            if (!dry) ck(launch_instr_embed(ids, ids_dt, w.emb, x, ctx->len_buf, B, L, E, ldx, m.vocab_size, s), "instr embed");
+            float* pre = alloc_f((size_t)B * L * 4 * Hi);
+            float* gh = alloc_f((size_t)B * 4 * Hi);
+            float* hc = alloc_f((size_t)2 * B * Hi);
+            for (int d = 0; d < w.dirs; ++d) {
+                linear(w.ih[d], x, B * L, ldx, pre, 4 * Hi, ACT_NONE, true);
+                if (!dry) ck(hipMemsetAsync(hc, 0, (size_t)2 * B * Hi * 4, s), "lstm state reset");
+                for (int k = 0; k < L; ++k) {
+                    const int t = d == 0 ? k : L - 1 - k;
+                    linear(w.hh[d], hc, B, Hi, gh, 4 * Hi, ACT_NONE, true);
+                    if (!dry) ck(launch_instr_lstm_cell(pre, gh, hc, hc + (size_t)B * Hi, ctx->len_buf, ins, t, B, L, Hi, C, d * Hi, s), "instr lstm cell");
+                }
+            }
+            tap("cma.instruction", ins, false, {B, L, C});
+        }
+        // chain B (aux 1): depth encoder -> spatial tokens (cma.py:220-221)
+        on(a1);
+        {
+            use(ctx->dt_depth);
+            Act o = depth_trunk(w.depth, depth, B, "cma.depth");
+            void* tok = ctx->dt_depth == ctx->dt_vla ? dep_tok : alloc_t((size_t)B * dS * dC);
+            if (!dry) {
+                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
+                ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+                if (tok != dep_tok) ck(launch_convert(tok, ctx->dt_depth, dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
+            }
+            use(ctx->dt_vla);
+            tap("cma.depth_spatial", dep_tok, true, {B, dS, dC});
+        }
+        // chain C (caller's stream): RGB encoder -> spatial tokens (cma.py:223-224)
+        on(main_s);
+        {
+            use(ctx->dt_rgb);
+            Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "cma.rgb");
+            void* tok = ctx->dt_rgb == ctx->dt_vla ? rgb_tok : alloc_t((size_t)B * 16 * rC);
+            if (!dry) {
+                ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
+                ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+                if (tok != rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
+            }
+            use(ctx->dt_vla);
+            tap("cma.rgb_spatial", rgb_tok, true, {B, 16, rC});
+        }
+        if (multi) fork_join_end(2);
+
+        // first state encoder over [rgb_in | depth_in] (cma.py:256-270)
+        const int ld1 = w.rnn1.in + H;
+        float* xh1 = alloc_f((size_t)B * ld1);
+        void* rmean = alloc_t((size_t)B * rC);
+        if (!dry) ck(launch_mean_rows(rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
+        linear(w.rgb_linear, rmean, B, rC, xh1, ld1, ACT_RELU, true);
+        linear(w.depth_linear, dep_tok, B, dS * dC, xh1 + c.rgb_out, ld1, ACT_RELU, true);
+        rnn_step(w.rnn1, xh1, ld1, B, h_in, mask, h_out, Heads{});
+        const float* state = h_out;                               // new h of the first encoder: (B, H)
+        tap("cma.state", state, false, {B, H});
+        // x = [state | text | rgb | depth] (cma.py:309-311)
+        const int ldc = H + C + c.rgb_out + c.depth_out;
+        float* xc = alloc_f((size_t)B * ldc);
+        if (!dry) ck(hipMemcpy2DAsync(xc, (size_t)ldc * 4, state, (size_t)H * 4, (size_t)H * 4, B, hipMemcpyDeviceToDevice, s), "state copy");
+        // text attention (:272-277): the query is the state, keys text_k(instruction), values the instruction itself
+        float* q1 = alloc_f((size_t)B * hh);
+        linear(w.state_q, state, B, H, q1, hh, ACT_NONE, true);
+        float* kt = alloc_f((size_t)B * L * hh);
+        linear(w.text_k, ins, B * L, C, kt, hh, ACT_NONE, true);
+        if (!dry) ck(launch_attn1q(q1, hh, kt, hh, ins, C, ctx->len_buf, xc + H, ldc, B, L, hh, C, w.scale, s), "text attention");
+        // visual attention (:281-290): query text_q(text); keys | values are the two halves of rgb_kv / depth_kv
+        float* q2 = alloc_f((size_t)B * hh);
+        linear(w.text_q, xc + H, B, ldc, q2, hh, ACT_NONE, true);
+        float* rkv = alloc_f((size_t)B * 16 * w.rgb_kv.N);
+        linear(w.rgb_kv, rgb_tok, B * 16, rC, rkv, w.rgb_kv.N, ACT_NONE, true);
+        float* dkv = alloc_f((size_t)B * dS * w.depth_kv.N);
+        linear(w.depth_kv, dep_tok, B * dS, dC, dkv, w.depth_kv.N, ACT_NONE, true);
+        if (!dry) {
+            ck(launch_attn1q(q2, hh, rkv, w.rgb_kv.N, rkv + hh, w.rgb_kv.N, nullptr, xc + H + C, ldc, B, 16, hh, c.rgb_out, w.scale, s), "rgb attention");
+            ck(launch_attn1q(q2, hh, dkv, w.depth_kv.N, dkv + hh, w.depth_kv.N, nullptr, xc + H + C + c.rgb_out, ldc, B, dS, hh, c.depth_out, w.scale, s), "depth attention");
+        }
+        // second_state_compress + second state encoder + heads (:312-332)
+        const int ld2 = w.rnn2.in + H;
+        float* xh2 = alloc_f((size_t)B * ld2);
+        linear(w.compress, xc, B, ldc, xh2, ld2, ACT_RELU, true);
+        tap("cma.compress", xh2, false, {B, ld2});
+        Heads hd;
+        hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = out; hd.r0 = c.num_actions; hd.ld0 = c.num_actions;
+        hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = 1;
+        rnn_step(w.rnn2, xh2, ld2, B, h_in + (size_t)R * B * H, mask, h_out + (size_t)R * B * H, hd);
+    }
+
+
     // ---------------------------------------------------------------- one step: independent encoder chains run on
     // separate HIP streams (fork/join by events, capturable into a hipGraph): the two RGB ResNet-50s, the two depth
     // trunks and BERT have no data dependence until the cross-modal block / the recurrent cells.  Each chain owns a
@@ -567,4 +682,12 @@ void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt,
            stop, ld_stop, hi_h_out, lo_h_out);
 }
 
+}  // namespace hcm
+
+namespace hcm {
+void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
+             const float* mask, float* out, float* stop, float* h_out) {
+    Fwd f(ctx);
+    f.cma_step(rgb, rgb_dt, depth, ids, ids_dt, B, h_in, mask, out, stop, h_out);
+}
 }  // namespace hcm

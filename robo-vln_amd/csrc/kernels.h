@@ -92,6 +92,13 @@ hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* 
 // GRU cell from gi, gh [B][3H] (r,z,n); h = h_in[0]*mask; writes h_out (1,B,H)
 hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, const float* mask, float* h_out,
                            int B, int Hd, const Heads& heads, hipStream_t s);
+// CMANet (models/cma.py) pieces: instruction embedding + lengths, one packed-LSTM time step, single-query attention
+hipError_t launch_instr_embed(const void* ids, int ids_dt, const float* table, float* x, int* lengths, int B, int L, int E, int ldx,
+                              int vocab, hipStream_t s);
+hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, float* c, const int* lengths, float* out, int t, int B,
+                                  int L, int Hd, int ld_out, int col0, hipStream_t s);
+hipError_t launch_attn1q(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int* lengths, float* out,
+                         int ldo, int B, int S, int D, int Dv, float scale, hipStream_t s);
 // pred[b] = argmax_j logits[b*ld + j] (first max), int64
 hipError_t launch_argmax(const float* logits, int64_t* pred, int B, int n, int ld, hipStream_t s);
 // xh[b][col0 + j] = emb[subtask[b]][j]

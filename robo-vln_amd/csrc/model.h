@@ -106,6 +106,21 @@ struct LowW {
     float* lin_w = nullptr; float* lin_b = nullptr; float* stop_w = nullptr; float* stop_b = nullptr;
 };
 
+// CMANet (models/cma.py:28-186)
+struct CmaW {
+    TrunkW rgb, depth;
+    float* rgb_pe = nullptr; float* depth_pe = nullptr;
+    int depth_S = 0, depth_C = 0;
+    float* emb = nullptr;          // word embedding table [vocab][E] f32
+    LinW ih[2], hh[2];             // per direction: W_ih (bias = b_ih + b_hh) and W_hh, f32
+    int dirs = 1;
+    LinW rgb_linear, depth_linear, rgb_kv, depth_kv;    // token-side projections (dt_vla weights, f32 outputs)
+    LinW state_q, text_k, text_q, compress;             // f32
+    RnnW rnn1, rnn2;
+    float scale = 0.f;
+    float* lin_w = nullptr; float* lin_b = nullptr; float* stop_w = nullptr; float* stop_b = nullptr;
+};
+
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0, peak = 0;
@@ -132,7 +147,11 @@ struct hcm_ctx {
     // storage / MFMA input type per sub-network: in bf16 mode the GroupNorm depth trunk runs
     // on fp16 MFMA tiles (same rate, 3 more mantissa bits), everything else on bf16
     int dt_rgb = 0, dt_depth = 0, dt_bert = 0, dt_vla = 0;
-    std::map<std::string, hcm::HostTensor> sd[2];
+    std::map<std::string, hcm::HostTensor> sd[3];       // HCM_HIGH, HCM_LOW, HCM_CMA
+    int kind = 0;                   // 0: HCM hi/lo handle, 1: CMANet handle (hcm_cma_create)
+    hcm_cma_config cma_cfg;
+    hcm::CmaW cma;
+    int* len_buf = nullptr;         // CMANet: per-sample instruction lengths
     bool finalized = false;
     std::vector<void*> dev_allocs;
     size_t weight_bytes = 0;

@@ -154,6 +154,43 @@ void build_spec_low(hcm_ctx* ctx) {
     s.linear("stop_linear", 1, c.hidden);
 }
 
+// CMANet state_dict (models/cma.py:28-186; InstructionEncoder models/encoders/instruction_encoder.py:9-47)
+void build_spec_cma(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    const hcm_cma_config& m = ctx->cma_cfg;
+    SpecB s{ctx->sd[HCM_CMA]};
+    s.add("instruction_encoder.embedding_layer.weight", {m.vocab_size, m.embedding_size});
+    for (int d = 0; d < (m.bidirectional ? 2 : 1); ++d) {
+        const std::string sfx = d ? "_reverse" : "";
+        const std::string p = "instruction_encoder.encoder_rnn.";
+        s.add(p + "weight_ih_l0" + sfx, {4 * m.instr_hidden, m.embedding_size});
+        s.add(p + "weight_hh_l0" + sfx, {4 * m.instr_hidden, m.instr_hidden});
+        s.add(p + "bias_ih_l0" + sfx, {4 * m.instr_hidden});
+        s.add(p + "bias_hh_l0" + sfx, {4 * m.instr_hidden});
+    }
+    const int fs = depth_final_spatial(c), cc = depth_compress_channels(c);
+    const int dC = cc + 64, rC = 2048 + 64, hh = c.hidden / 2;
+    const int instr_out = m.instr_hidden * (m.bidirectional ? 2 : 1);
+    spec_gn_resnet50(s, "depth_encoder.visual_encoder.", 1, c.depth_baseplanes, cc);
+    s.add("depth_encoder.spatial_embeddings.weight", {fs * fs, 64});
+    spec_tv_resnet50(s, "rgb_encoder.cnn.", false);
+    s.add("rgb_encoder.spatial_embeddings.weight", {16, 64});
+    s.linear("rgb_linear.2", c.rgb_out, rC);
+    s.linear("depth_linear.1", c.depth_out, dC * fs * fs);
+    spec_rnn(s, "state_encoder.rnn.", c, c.rgb_out + c.depth_out);
+    s.add("rgb_kv.weight", {hh + c.rgb_out, rC, 1}); s.add("rgb_kv.bias", {hh + c.rgb_out});
+    s.add("depth_kv.weight", {hh + c.depth_out, dC, 1}); s.add("depth_kv.bias", {hh + c.depth_out});
+    s.linear("state_q", hh, c.hidden);
+    s.add("text_k.weight", {hh, instr_out, 1}); s.add("text_k.bias", {hh});
+    s.linear("text_q", hh, instr_out);
+    s.add("_scale", {});
+    s.linear("second_state_compress.0", c.hidden, c.hidden + c.rgb_out + c.depth_out + instr_out);
+    spec_rnn(s, "second_state_encoder.rnn.", c, c.hidden);
+    s.linear("progress_monitor", 1, c.hidden);
+    s.linear("linear", c.num_actions, c.hidden);
+    s.linear("stop_linear", 1, c.hidden);
+}
+
 // ------------------------------------------------------------------------------------------------ upload helpers
 static uint16_t f2bf_host(float f) {
     uint32_t u;
@@ -694,4 +731,57 @@ void prepare_low(hcm_ctx* ctx) {
     l.stop_b = up.f32(T_(ctx, M, "stop_linear.bias").f);
 }
 
+}  // namespace hcm
+
+namespace hcm {
+void prepare_cma(hcm_ctx* ctx) {
+    const hcm_config& c = ctx->cfg;
+    const hcm_cma_config& m = ctx->cma_cfg;
+    const int M = HCM_CMA;
+    Uploader up{ctx};
+    CmaW& w = ctx->cma;
+    w.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
+    w.depth = make_gn_trunk(ctx, up, M, "depth_encoder.visual_encoder.");
+    w.rgb_pe = make_pe_view(up, T_(ctx, M, "rgb_encoder.spatial_embeddings.weight"));
+    w.depth_pe = make_pe_view(up, T_(ctx, M, "depth_encoder.spatial_embeddings.weight"));
+    const int fs = depth_final_spatial(c);
+    w.depth_S = fs * fs;
+    w.depth_C = depth_compress_channels(c) + 64;
+    w.emb = up.f32(T_(ctx, M, "instruction_encoder.embedding_layer.weight").f);
+    w.dirs = m.bidirectional ? 2 : 1;
+    for (int d = 0; d < w.dirs; ++d) {
+        const std::string sfx = d ? "_reverse" : "";
+        const std::string p = "instruction_encoder.encoder_rnn.";
+        const HostTensor& bih = T_(ctx, M, p + "bias_ih_l0" + sfx);
+        const HostTensor& bhh = T_(ctx, M, p + "bias_hh_l0" + sfx);
+        HostTensor b;
+        b.shape = bih.shape;
+        b.f.resize(bih.f.size());
+        for (size_t i = 0; i < b.f.size(); ++i) b.f[i] = bih.f[i] + bhh.f[i];
+        w.ih[d] = make_linear(up, {&T_(ctx, M, p + "weight_ih_l0" + sfx)}, {&b}, DT_F32);
+        w.ih[d].K = w.ih[d].Kp;          // the embedded tokens are stored zero-padded to Kp columns (E = 50 is not a vector multiple)
+        w.hh[d] = make_linear(up, {&T_(ctx, M, p + "weight_hh_l0" + sfx)}, {}, DT_F32);
+    }
+    w.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
+    {
+        const int S = w.depth_S, dC = w.depth_C;          // Flatten of (B, dC, S): column c*S + s; ours [B][S][dC]
+        std::vector<int> perm((size_t)S * dC);
+        for (int s = 0; s < S; ++s)
+            for (int ch = 0; ch < dC; ++ch) perm[(size_t)s * dC + ch] = ch * S + s;
+        w.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt_vla, &perm);
+    }
+    w.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
+    w.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla);
+    w.state_q = make_linear(up, {&T_(ctx, M, "state_q.weight")}, {&T_(ctx, M, "state_q.bias")}, DT_F32);
+    w.text_k = make_linear(up, {&T_(ctx, M, "text_k.weight")}, {&T_(ctx, M, "text_k.bias")}, DT_F32);
+    w.text_q = make_linear(up, {&T_(ctx, M, "text_q.weight")}, {&T_(ctx, M, "text_q.bias")}, DT_F32);
+    w.compress = make_linear(up, {&T_(ctx, M, "second_state_compress.0.weight")}, {&T_(ctx, M, "second_state_compress.0.bias")}, DT_F32);
+    w.rnn1 = make_rnn(ctx, up, M, "state_encoder.rnn.");
+    w.rnn2 = make_rnn(ctx, up, M, "second_state_encoder.rnn.");
+    w.scale = T_(ctx, M, "_scale").f[0];                  // registered buffer: 1 / sqrt(hidden / 2) (cma.py:147)
+    w.lin_w = up.f32(T_(ctx, M, "linear.weight").f);
+    w.lin_b = up.f32(T_(ctx, M, "linear.bias").f);
+    w.stop_w = up.f32(T_(ctx, M, "stop_linear.weight").f);
+    w.stop_b = up.f32(T_(ctx, M, "stop_linear.bias").f);
+}
 }  // namespace hcm
