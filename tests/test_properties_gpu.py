@@ -1,0 +1,172 @@
+"""Size-independent properties of the fused step at BASELINE.json's full size (configs[1]: B=64, 256x256 RGB-D, L=80,
+16-bit path), where the CPU oracle is too slow to be the checker: determinism, batch-permutation equivariance, batch
+independence (a row of a B=64 call equals the B=1 call on that row), episode reset semantics, instruction row
+broadcast; plus boundary edge cases (B=1, B < max_batch, shortest / unpadded instructions)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from robo_vln_amd import synth
+from robo_vln_amd.config import HCMConfig
+
+pytestmark = pytest.mark.gpu
+B = 64
+
+
+@pytest.fixture(scope="module")
+def full():
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig().validate()
+    hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16")
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=5, rgb_uint8=True).items()}
+    g = torch.Generator().manual_seed(11)
+    R = cfg.num_recurrent_layers
+    hh = ((torch.rand(R, B, cfg.hidden, generator=g) - 0.5) * 0.5).cuda()
+    lh = ((torch.rand(R, B, cfg.hidden, generator=g) - 0.5) * 0.5).cuda()
+    mask = torch.ones(B, device="cuda")
+    mask[::7] = 0
+    yield cfg, eng, obs, hh, lh, mask
+    eng.close()
+
+
+def _act(eng, obs, hh, lh, mask):
+    rec, h2, l2 = eng.act(dict(obs), hh, lh, mask)
+    torch.cuda.synchronize()
+    return rec.clone(), h2.clone(), l2.clone()
+
+
+def test_deterministic_bitwise(full):
+    cfg, eng, obs, hh, lh, mask = full
+    a = _act(eng, obs, hh, lh, mask)
+    b = _act(eng, obs, hh, lh, mask)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.isfinite(a[0]).all() and a[0].shape == (B, 7)
+
+
+def test_batch_permutation_equivariance(full):
+    """Every op of the path is per-sample: permuting the environments permutes the outputs, bit for bit."""
+    cfg, eng, obs, hh, lh, mask = full
+    base = _act(eng, obs, hh, lh, mask)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    pobs = {k: v[perm].contiguous() for k, v in obs.items()}
+    out = _act(eng, pobs, hh[:, perm].contiguous(), lh[:, perm].contiguous(), mask[perm].contiguous())
+    assert torch.equal(out[0], base[0][perm])
+    assert torch.equal(out[1], base[1][:, perm])
+    assert torch.equal(out[2], base[2][:, perm])
+
+
+def test_rows_equal_single_env_calls(full):
+    """Sharding contract: a row of the B=64 step equals the same environment run alone (B=1) or in a batch of 5 -- up to
+    the tile-shape dependent reduction order of GroupNorm / skinny GEMMs (16-bit storage: 2e-3)."""
+    cfg, eng, obs, hh, lh, mask = full
+    base = _act(eng, obs, hh, lh, mask)
+    for rows in ([0], [63], [7, 8, 9, 10, 11]):
+        idx = torch.tensor(rows, device="cuda")
+        sub = {k: v[idx].contiguous() for k, v in obs.items()}
+        rec, h2, l2 = _act(eng, sub, hh[:, idx].contiguous(), lh[:, idx].contiguous(), mask[idx].contiguous())
+        assert (rec - base[0][idx]).abs().max().item() <= 2e-3
+        assert (h2 - base[1][:, idx]).abs().max().item() <= 2e-3
+        assert (l2 - base[2][:, idx]).abs().max().item() <= 2e-3
+
+
+def test_episode_reset_ignores_stale_state(full):
+    """mask = 0 multiplies h and c by zero before the step (state_encoder.py:64-81): whatever was in the hidden state of a
+    finished episode cannot leak into the next one."""
+    cfg, eng, obs, hh, lh, mask = full
+    zero_mask = torch.zeros(B, device="cuda")
+    a = _act(eng, obs, hh, lh, zero_mask)
+    b = _act(eng, obs, torch.zeros_like(hh), torch.full_like(lh, 3.0), zero_mask)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    c = _act(eng, obs, torch.zeros_like(hh), torch.zeros_like(lh), torch.ones(B, device="cuda"))
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)
+
+
+def test_instruction_row_broadcast(full):
+    """A (1, L) instruction is expanded to the batch (seq2seq_highlevel_cma.py:189-190)."""
+    cfg, eng, obs, hh, lh, mask = full
+    one = dict(obs)
+    one["instruction"] = obs["instruction"][:1].contiguous()
+    full_ids = dict(obs)
+    full_ids["instruction"] = obs["instruction"][:1].expand(B, -1).contiguous()
+    a = _act(eng, one, hh, lh, mask)
+    b = _act(eng, full_ids, hh, lh, mask)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_instruction_dtypes_and_padding_extremes(full):
+    """ids arrive as f32 from batch_obs (common/utils.py:78-83), as int32 or int64; a row may be one token long or
+    completely unpadded (the reference attends to the padding, so pads are ordinary tokens)."""
+    cfg, eng, obs, hh, lh, mask = full
+    ids = obs["instruction"].clone()
+    ids[0, 1:] = 0
+    ids[0, 0] = 101
+    ids[1] = torch.randint(1000, cfg.bert_vocab, (cfg.instr_len,), generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for dt in (torch.int64, torch.int32, torch.float32):
+        o = dict(obs)
+        o["instruction"] = ids.to(dt)
+        outs.append(_act(eng, o, hh, lh, mask))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert torch.equal(x, y)
+    assert torch.isfinite(outs[0][0]).all()
+
+
+def test_float_frames_equal_uint8_frames(full):
+    cfg, eng, obs, hh, lh, mask = full
+    f = dict(obs)
+    f["rgb"] = obs["rgb"].float()
+    a = _act(eng, obs, hh, lh, mask)
+    b = _act(eng, f, hh, lh, mask)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)          # both go through the same packed bf16 frame
+
+
+def test_rejects_oversized_batch_and_bad_shapes(full):
+    cfg, eng, obs, hh, lh, mask = full
+    big = {k: torch.cat([v, v[:1]]) for k, v in obs.items()}
+    with pytest.raises(ValueError):
+        eng.act(big, torch.zeros(2, B + 1, cfg.hidden, device="cuda"), torch.zeros(2, B + 1, cfg.hidden, device="cuda"),
+                torch.ones(B + 1, device="cuda"))
+    bad = dict(obs)
+    bad["depth"] = obs["depth"][:, :128]
+    with pytest.raises(ValueError):
+        eng.act(bad, hh, lh, mask)
+    with pytest.raises(ValueError):
+        eng.act(obs, hh[:1], lh, mask)
+
+
+def test_cma_rows_independent_and_length_extremes():
+    """CMANet at 256x256, B=8: rows with a 1-token instruction and with a completely unpadded one; permutation of the
+    batch permutes the outputs; deterministic."""
+    from robo_vln_amd.cma import CMAEngine
+    from robo_vln_amd.config import CMAConfig
+    cfg = CMAConfig().validate()
+    n = 8
+    eng = CMAEngine(cfg, synth.make_cma_weights(cfg, 2), max_batch=n, precision="bf16")
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_observations(cfg, n, seed=2, rgb_uint8=True).items()}
+    obs["instruction"][0, 1:] = 0
+    obs["instruction"][1] = torch.randint(1, cfg.vocab_size, (cfg.instr_len,), generator=torch.Generator().manual_seed(4)).cuda()
+    R = cfg.num_recurrent_layers
+    hid = ((torch.rand(R, n, cfg.hidden, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.5).cuda()
+    mask = torch.ones(n, device="cuda")
+    mask[3] = 0
+    a = eng.forward(obs, hid, mask)
+    b = eng.forward(obs, hid, mask)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y) and torch.isfinite(x).all()
+    perm = torch.tensor([5, 0, 7, 2, 1, 6, 3, 4], device="cuda")
+    p = eng.forward({k: v[perm].contiguous() for k, v in obs.items()}, hid[:, perm].contiguous(), mask[perm].contiguous())
+    torch.cuda.synchronize()
+    assert (p[0] - a[0][perm]).abs().max().item() <= 1e-6
+    assert (p[1] - a[1][perm]).abs().max().item() <= 1e-6
+    assert (p[2] - a[2][:, perm]).abs().max().item() <= 1e-6
+    eng.close()
