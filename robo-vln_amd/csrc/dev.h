@@ -66,6 +66,22 @@ __device__ __forceinline__ void ld_chunk(const f16* p, float (&o)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f[i];
 }
+// 16 bytes already in registers -> 8 floats (T selects the decoding)
+template <typename T> __device__ __forceinline__ void cvt_chunk(const uint4& v, float (&o)[8]);
+template <> __device__ __forceinline__ void cvt_chunk<bf16>(const uint4& v, float (&o)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(w[i] << 16);
+        o[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+template <> __device__ __forceinline__ void cvt_chunk<f16>(const uint4& v, float (&o)[8]) {
+    const half8_t h = __builtin_bit_cast(half8_t, v);
+    const float8_t f = __builtin_convertvector(h, float8_t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f[i];
+}
 __device__ __forceinline__ void st_chunk(f16* p, const float (&o)[8]) {
     float8_t f;
 #pragma unroll

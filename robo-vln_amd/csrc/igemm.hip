@@ -90,9 +90,9 @@ __device__ __forceinline__ bool tile_of_block(const IGemmDev& p, int bid, int& t
 }
 
 // Shared epilogue of both kernel variants (see the comment at its top).
-template <typename T, int BM, int BN, int NW = 4, int WMc = 2>
+template <typename T, int BM, int BN, int NW = 4, int WMc = 2, int NPRE = 1>
 __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], char* smem, int m0, int n0,
-                                               int tid, int wm, int wn, int fr, int fg) {
+                                               int tid, int wm, int wn, int fr, int fg, const uint4 (&rpre)[NPRE], bool have_pre) {
     constexpr int WNc = NW / WMc;          // waves along the channel axis (WMc along the pixel axis)
     constexpr int TM = BM / WMc / 16;
     constexpr int TN = BN / WNc / 16;
@@ -145,7 +145,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
         if (p.res) {
             const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
             if constexpr (sizeof(T) == 2) {
-                if (wide16r) {
+                if (have_pre) {                 // residual chunk prefetched at kernel start (see igemm_dma_kernel)
+                    float rr[8];
+                    cvt_chunk<T>(rpre[pass < NPRE ? pass : 0], rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                } else if (wide16r) {
                     float rr[8];
                     ld_chunk(rp, rr);
 #pragma unroll
@@ -445,7 +450,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
         }
     }
 
-    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    const uint4 no_pre[1] = {make_uint4(0u, 0u, 0u, 0u)};
+    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, no_pre, false);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -593,6 +599,26 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
+    // Residual prefetch (8-wave, 16-bit kernels): the epilogue adds res[m][n..n+8) per thread and pass.  Requested here,
+    // before the first tile, the residual tile travels together with the operand tiles instead of being a second exposed
+    // HBM round trip after the K loop -- the 1x1 expansion convs of the ResNet bottlenecks have K = 64..512, i.e. 1-8
+    // K iterations, and are bounded by exactly these round trips.  (Older than every DMA request, so each counted vmcnt
+    // wait of the loop also covers them.)
+    constexpr int E_TPR = BN / 8, E_RPP = 64 * NW / E_TPR, E_NP = BM / E_RPP;
+    uint4 rpre[E_NP];
+    bool have_pre = false;
+    if constexpr (sizeof(T) == 2 && NW == 8 && E_NP <= 8) {
+        if (p.res && (p.ldr % 8) == 0 && (p.N % 8) == 0) {
+            have_pre = true;
+            const int n = n0 + (tid % E_TPR) * 8;
+#pragma unroll
+            for (int pass = 0; pass < E_NP; ++pass) {
+                const int m = m0 + pass * E_RPP + tid / E_TPR;
+                rpre[pass] = make_uint4(0u, 0u, 0u, 0u);
+                if (m < p.M && n + 8 <= p.N) rpre[pass] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n);
+            }
+        }
+    }
     // prologue: NBUF-1 tiles in flight; tile 0 must have landed (for every wave) before the first fragment read
     stage(0, 0);
     if (NBUF == 3 && nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
@@ -827,7 +853,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         lap(4);
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
-    igemm_epilogue<T, BM, BN, NW, WMc>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    igemm_epilogue<T, BM, BN, NW, WMc, E_NP>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, rpre, have_pre);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lap(5);
