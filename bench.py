@@ -206,7 +206,7 @@ def main():
                          "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
                          # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
                          # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
-                         "traffic": 19.34 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
+                         "traffic": 19.37 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
                          "traffic_source": "profiles/r1_pmc_traffic_bench.md",
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s"},
         }
