@@ -558,7 +558,15 @@ int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, co
 }
 int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta, int dtype, int B, int HW, int C,
                      int groups, float eps, int relu, void* stream) {
-    return op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, nullptr, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
+    static float* scratch = nullptr;            // partial-sum scratch of the two-launch path, grown on demand (test entry point)
+    static size_t scratch_floats = 0;
+    const size_t need = gn_stats_floats(B, HW, groups);
+    if (need > scratch_floats) {
+        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); }
+        if (hipMalloc((void**)&scratch, need * 4) != hipSuccess) return HCM_ERR_NOMEM;
+        scratch_floats = need;
+    }
+    return op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, scratch, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
 }
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

@@ -342,11 +342,125 @@ static long gn_slab_limit() {
     return v;
 }
 
-hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* /*stats*/, int dt, int B,
+// Large feature maps (HW >= 256 pixels per sample): two launches over (sample, pixel chunk) workgroups that read whole
+// pixel rows -- every access is a full 128-byte-or-wider run, where the slab kernel above would touch 16 bytes of each
+// line (the stem's 64 x 64 x 64 map: 143 us -> ~30 us).  Launch 1 writes per-(sample, chunk, group) sum / sum of squares;
+// launch 2 adds the <= 16 partials of its sample in a fixed order (deterministic, no atomics), normalises its chunk, adds
+// the residual, applies ReLU.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C, int G, int P) {
+    constexpr int CH = Tr<T>::CH;
+    __shared__ float s_p1[4][512], s_p2[4][512];     // C <= 512 on this path
+    const int b = blockIdx.y, pc = blockIdx.x;
+    const int cpr = C / CH;                       // power of two, <= 64 (f16/bf16) or 128 (f32)
+    const int tid = threadIdx.x;
+    const int cc = tid % cpr, prow = tid / cpr, pstep = 256 / cpr;
+    const int chunk = HW / P;
+    const T* xb = x + ((size_t)b * HW + (size_t)pc * chunk) * C + cc * CH;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int p = prow; p < chunk; p += pstep) {
+        float v[CH];
+        ld_chunk(xb + (size_t)p * C, v);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+    }
+    for (int o = 32; o >= cpr; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    const int wv = tid >> 6;
+    for (int i = tid; i < 4 * C; i += 256) { s_p1[i / C][i % C] = 0.f; s_p2[i / C][i % C] = 0.f; }
+    __syncthreads();
+    // cpr <= 64: after the butterfly lanes < cpr hold the wave's totals; cpr = 128 (f32): a wave covers half a pixel row and
+    // every lane owns distinct channels (the other half-row waves leave zeros in this wave's slots)
+    if ((tid & 63) < cpr || cpr > 64) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s_p1[wv][cc * CH + j] = s1[j]; s_p2[wv][cc * CH + j] = s2[j]; }
+    }
+    __syncthreads();
+    const int Cg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        float a = 0.f, q = 0.f;
+        for (int j = 0; j < Cg; ++j) {
+            const int ch = g * Cg + j;
+            a += (s_p1[0][ch] + s_p1[1][ch]) + (s_p1[2][ch] + s_p1[3][ch]);
+            q += (s_p2[0][ch] + s_p2[1][ch]) + (s_p2[2][ch] + s_p2[3][ch]);
+        }
+        float* o = part + (((size_t)b * P + pc) * G + g) * 2;
+        o[0] = a; o[1] = q;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ part, int HW, int C, int G,
+                                                        int P, float eps, int relu) {
+    constexpr int CH = Tr<T>::CH;
+    __shared__ float s_scale[512], s_shift[512];
+    __shared__ float s_mean[256], s_rstd[256];
+    const int b = blockIdx.y, pc = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int Cg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        float a = 0.f, q = 0.f;
+        for (int i = 0; i < P; ++i) {
+            const float* o = part + (((size_t)b * P + i) * G + g) * 2;
+            a += o[0]; q += o[1];
+        }
+        const float inv_n = 1.0f / ((float)HW * (float)Cg);
+        const float mean = a * inv_n;
+        const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+        s_mean[g] = mean;
+        s_rstd[g] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {
+        const int g = ch / Cg;
+        const float sc = s_rstd[g] * gamma[ch];
+        s_scale[ch] = sc;
+        s_shift[ch] = s_mean[g] * sc - beta[ch];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const int cc = tid % cpr, prow = tid / cpr, pstep = 256 / cpr;
+    const int chunk = HW / P;
+    const size_t base = ((size_t)b * HW + (size_t)pc * chunk) * C + cc * CH;
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sc[j] = s_scale[cc * CH + j]; sh[j] = s_shift[cc * CH + j]; }
+    for (int p = prow; p < chunk; p += pstep) {
+        float v[CH], r[CH];
+        ld_chunk(x + base + (size_t)p * C, v);
+        if (res) ld_chunk(res + base + (size_t)p * C, r);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            float o = v[j] * sc[j] - sh[j];
+            if (res) o += r[j];
+            if (relu) o = fmaxf(o, 0.f);
+            v[j] = o;
+        }
+        st_chunk(x + base + (size_t)p * C, v);
+    }
+}
+
+hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats, int dt, int B,
                             int HW, int C, int G, float eps, int relu, hipStream_t s) {
     const int CH = dt_chunk(dt);
     if (C % CH || C % G) return hipErrorInvalidValue;
     const int Cg = C / G;
+    static const int two_pass = getenv("HCM_GN_TWO") ? atoi(getenv("HCM_GN_TWO")) : 1;
+    const int P = gn_partials(HW);
+    const int cprw = C / CH;
+    if (two_pass && stats && P > 0 && !(cprw & (cprw - 1)) && cprw <= 128 && C <= 512 && G <= 256 && HW % P == 0 &&
+        (HW >= 1024 || C <= 256)) {             // 16 x 16 maps with 512 channels: the slab kernel is faster (13 vs 21 us)
+        HCM_DISPATCH_T(dt, {
+            hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(P, B), dim3(256), 0, s, (const T*)x, stats, HW, C, G, P);
+            hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(P, B), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, stats, HW, C, G, P, eps, relu);
+        });
+        return hipGetLastError();
+    }
     // slab: whole groups, multiple of the chunk, power-of-two chunk count <= 32, about 32 K elements per workgroup
     int unit = Cg > CH ? Cg : CH;
     if (unit % Cg || unit % CH) return hipErrorInvalidValue;

@@ -77,7 +77,7 @@ struct Fwd {
         ck(launch_igemm(g, wdt < 0 ? w.dt : wdt, s), "linear igemm");
     }
     void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu) {
-        float* stats = alloc_f((size_t)B * 2 * G);
+        float* stats = alloc_f(gn_stats_floats(B, HW, G));
         if (dry) return;
         ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, 1e-5f, relu ? 1 : 0, s), "groupnorm");
     }

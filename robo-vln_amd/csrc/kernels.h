@@ -67,6 +67,9 @@ hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C,
 hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int C, int ldy, hipStream_t s);
 
 // GroupNorm over NHWC x [B,HW,C] in place: x = relu?( (x-mean)*rstd*gamma+beta (+res) ); stats scratch [B*G*2] f32
+// pixel chunks per sample of the two-launch GroupNorm (0: single-launch slab kernel); `stats` must hold gn_stats_floats()
+inline int gn_partials(int HW) { return HW >= 256 ? (HW / 64 < 16 ? HW / 64 : 16) : 0; }
+inline size_t gn_stats_floats(int B, int HW, int G) { const int P = gn_partials(HW); return (size_t)B * (P > 0 ? P : 1) * G * 2; }
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats,
                             int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s);
 // LayerNorm rows: y = LN(x (+res)) * gamma + beta (+ post[row % post_rows][:])

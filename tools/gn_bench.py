@@ -6,8 +6,10 @@ from robo_vln_amd import _lib
 lib = _lib.lib()
 B = 64
 tot = 0
-for HW, Cc, G, cnt in ((4096, 32, 16, 2), (1024, 32, 16, 12), (1024, 128, 16, 8), (256, 64, 16, 16), (256, 256, 16, 10), (64, 128, 16, 24),
-                       (64, 512, 16, 14), (16, 256, 16, 12), (16, 1024, 16, 8), (16, 128, 1, 2)):
+# (pixels per sample, channels, groups, launches per step) of the hi|lo PAIR depth trunk at 256x256 frames
+for HW, Cc, G, cnt in ((4096, 64, 32, 1), (1024, 64, 32, 6), (1024, 256, 32, 4), (1024, 128, 32, 1), (256, 128, 32, 7), (256, 512, 32, 5),
+                       (256, 256, 32, 1), (64, 256, 32, 11), (64, 1024, 32, 7), (64, 512, 32, 1), (16, 512, 32, 5), (16, 2048, 32, 4),
+                       (16, 256, 2, 1)):
     x = torch.randn(B, HW, Cc, device="cuda").half(); r = torch.randn(B, HW, Cc, device="cuda").half()
     g = torch.randn(Cc, device="cuda"); b = torch.randn(Cc, device="cuda")
     st = torch.empty(B * G * 2, device="cuda")
