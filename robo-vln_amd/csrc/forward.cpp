@@ -272,6 +272,11 @@ struct Fwd {
         void* emb = nullptr;       // BERT last hidden state [B][L][768]                            (dt_bert)
         float* xh = nullptr;       // [rgb_in | depth_in | ins_rgb | ins_depth | h*mask]  f32
         int ldx = 0;
+        // produced inside the encoder chains (each depends on ONE encoder only), consumed by hi_tail:
+        void* I = nullptr;         // LN(ReLU(ins_fc(bert))) + PE   [B*L][d]     (BERT chain)
+        std::vector<void*> Q;      // per-layer fc_q(I)                            (BERT chain)
+        void* kvin[2] = {nullptr, nullptr};   // LN(ReLU(vis_fc(rgb_kv / depth_kv(tokens))))  [B*max(S,L)][d]  (RGB / depth chain)
+        void* kv0[2] = {nullptr, nullptr};    // layer-0 fc_k|fc_v of kvin        [B*max(S,L)][2d]
     };
     struct LoBufs { float* xh = nullptr; int ldx = 0; };   // [depth | rgb | subtask | h*mask] (seq2seq_lowlevel.py:143)
 
@@ -286,7 +291,68 @@ struct Fwd {
         b.emb = alloc_t((size_t)B * c.instr_len * c.bert_hidden);
         b.ldx = w.rnn.in + c.hidden;
         b.xh = alloc_f((size_t)B * b.ldx);
+        use(ctx->dt_vla);
+        const int L = c.instr_len, d = c.d_model;
+        b.I = alloc_t((size_t)B * L * d);
+        b.Q.resize(w.vla.layers.size());
+        for (auto& q : b.Q) q = alloc_t((size_t)B * L * d);
+        for (int st = 0; st < 2; ++st) {
+            const int S = st == 0 ? 16 : w.depth_S;
+            b.kvin[st] = alloc_t((size_t)B * (S > L ? S : L) * d);
+            b.kv0[st] = alloc_t((size_t)B * (S > L ? S : L) * 2 * d);
+        }
         return b;
+    }
+
+    // The part of Visual_Ling_Attn that depends on ONE visual encoder only (transformer.py:258-262 + the layer-0 key/value
+    // projection) and the encoder's own projection into the recurrent input (seq2seq_highlevel_cma.py:198-199,:213-214):
+    // enqueued at the end of that encoder's chain, so it overlaps the other chains instead of sitting in the serial tail.
+    void hi_vis_pre(int stream, int B, HiBufs& hb) {
+        const hcm_config& c = ctx->cfg;
+        const HighW& w = ctx->hi;
+        const VlaW& v = w.vla;
+        const int d = c.d_model, rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
+        use(ctx->dt_vla);
+        const size_t m = ar.mark();
+        const int S = stream == 0 ? 16 : dS;
+        const void* tok = stream == 0 ? hb.rgb_tok : hb.dep_tok;
+        const int tokC = stream == 0 ? rC : dC;
+        const LinW& kvproj = stream == 0 ? w.rgb_kv : w.depth_kv;
+        void* vis = alloc_t((size_t)B * S * c.vis_in);
+        linear(kvproj, tok, B * S, tokC, vis, c.vis_in, ACT_NONE, false);              // rgb_kv / depth_kv Conv1d(k=1)
+        tap(stream == 0 ? "hi.rgb_kv" : "hi.depth_kv", vis, true, {B, S, c.vis_in});
+        void* vtmp = alloc_t((size_t)B * S * d);
+        linear(v.vis_fc, vis, B * S, c.vis_in, vtmp, d, ACT_RELU, false);
+        ln(vtmp, nullptr, v.ln, nullptr, 0, hb.kvin[stream], B * S, d, 1e-5f);
+        linear(v.layers[0].kv, hb.kvin[stream], B * S, d, hb.kv0[stream], 2 * d, ACT_NONE, false);
+        if (stream == 0) {
+            // rgb_linear (:213): mean over the 16 tokens -> Linear -> ReLU
+            void* rmean = alloc_t((size_t)B * rC);
+            if (!dry) ck(launch_mean_rows(hb.rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
+            linear(w.rgb_linear, rmean, B, rC, hb.xh, hb.ldx, ACT_RELU, true);
+        } else {
+            // depth_linear (:214): Flatten -> Linear -> ReLU
+            linear(w.depth_linear, hb.dep_tok, B, dS * dC, hb.xh + c.rgb_out, hb.ldx, ACT_RELU, true);
+        }
+        // NOTE: no ar.release(m): chains run concurrently and allocate from one bump arena
+        (void)m;
+    }
+    // The instruction stream of Visual_Ling_Attn (transformer.py:263-269): identical for both calls, depends on BERT only.
+    void hi_ins_pre(int B, HiBufs& hb) {
+        const hcm_config& c = ctx->cfg;
+        const VlaW& v = ctx->hi.vla;
+        const int L = c.instr_len, d = c.d_model, rows = B * L;
+        use(ctx->dt_vla);
+        void* emb = hb.emb;
+        if (ctx->dt_bert != ctx->dt_vla) {
+            void* e2 = alloc_t((size_t)rows * c.bert_hidden);
+            if (!dry) ck(launch_convert(emb, ctx->dt_bert, e2, ctx->dt_vla, (size_t)rows * c.bert_hidden, s), "bert out convert");
+            emb = e2;
+        }
+        void* tmp = alloc_t((size_t)rows * d);
+        linear(v.ins_fc, emb, rows, c.bert_hidden, tmp, d, ACT_RELU, false);
+        ln(tmp, nullptr, v.ln, v.pe, L, hb.I, rows, d, 1e-5f);     // LN then + PE; identical for both calls -> computed once
+        for (size_t l = 0; l < v.layers.size(); ++l) linear(v.layers[l].q, hb.I, rows, d, hb.Q[l], d, ACT_NONE, false);
     }
     LoBufs lo_alloc(int B) {
         LoBufs b;
@@ -309,6 +375,7 @@ struct Fwd {
         }
         use(ctx->dt_vla);
         tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
+        hi_vis_pre(1, B, hb);
     }
     // Both depth encoders in one pass over the shared frame (hcm_act): channel-concatenated pair trunk, then the hi half
     // becomes dep_tok (+ pos-emb) and the lo half goes through visual_fc (resnet_encoders.py:56-62,:108) into the lo RNN input.
@@ -329,6 +396,7 @@ struct Fwd {
         linear(ctx->lo.depth_fc, lo_feat, B, dS * cc, lb.xh, lb.ldx, ACT_RELU, true);     // visual_fc
         use(ctx->dt_vla);
         tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
+        hi_vis_pre(1, B, hb);
     }
     // Both RGB encoders in one pass (hcm_act): hi half -> adaptive_avg_pool2d(4,4) + pos-emb -> rgb_tok; lo half -> global
     // average pool -> fc -> ReLU (resnet_encoders.py:234-237) into the lo RNN input.
@@ -350,6 +418,7 @@ struct Fwd {
         linear(ctx->lo.rgb_fc, pooled, B, C1, lb.xh + c.depth_out, lb.ldx, ACT_RELU, true);
         use(ctx->dt_vla);
         tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
+        hi_vis_pre(0, B, hb);
     }
     // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels -> rgb_tok
     void hi_rgb(const void* rgb, int rgb_dt, int B, HiBufs& hb) {
@@ -365,64 +434,42 @@ struct Fwd {
         }
         use(ctx->dt_vla);
         tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
+        hi_vis_pre(0, B, hb);
     }
     // BERT (:189-195) -> emb
     void hi_bert(const void* ids, int ids_dt, int B, HiBufs& hb) {
         use(ctx->dt_bert);
         bert(ctx->hi.bert, ids, ids_dt, B, hb.emb);
         tap("hi.bert", hb.emb, true, {B, ctx->cfg.instr_len, ctx->cfg.bert_hidden});
+        hi_ins_pre(B, hb);
     }
-    // Visual_Ling_Attn x2, poolers, projections, state encoder, head (:198-232)
+    // Visual_Ling_Attn x2 (the cross-modal part), poolers, state encoder, head (:200-232)
     void hi_tail(int B, HiBufs& hb, const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
         const hcm_config& c = ctx->cfg;
         const HighW& w = ctx->hi;
         const int L = c.instr_len, d = c.d_model;
-        const int rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
+        const int dS = w.depth_S;
         const int ldx = hb.ldx;
         float* xh = hb.xh;
         use(ctx->dt_vla);
-        void* emb = hb.emb;
-        if (ctx->dt_bert != ctx->dt_vla) {
-            void* e2 = alloc_t((size_t)B * L * c.bert_hidden);
-            if (!dry) ck(launch_convert(emb, ctx->dt_bert, e2, ctx->dt_vla, (size_t)B * L * c.bert_hidden, s), "bert out convert");
-            emb = e2;
-        }
-        // Visual_Ling_Attn x2 (:198-201; models/transformer/transformer.py:251-281)
         const VlaW& v = w.vla;
         const int rows = B * L;
-        void* I = alloc_t((size_t)rows * d);
-        void* tmp = alloc_t((size_t)rows * d);
-        linear(v.ins_fc, emb, rows, c.bert_hidden, tmp, d, ACT_RELU, false);
-        ln(tmp, nullptr, v.ln, v.pe, L, I, rows, d, 1e-5f);     // LN then + PE; identical for both calls -> computed once
-        std::vector<void*> Q(v.layers.size());
-        for (size_t l = 0; l < v.layers.size(); ++l) {
-            Q[l] = alloc_t((size_t)rows * d);
-            linear(v.layers[l].q, I, rows, d, Q[l], d, ACT_NONE, false);
-        }
+        void* I = hb.I;
         for (int stream = 0; stream < 2; ++stream) {
             const size_t m = ar.mark();
             const int S = stream == 0 ? 16 : dS;
-            const void* tok = stream == 0 ? hb.rgb_tok : hb.dep_tok;
-            const int tokC = stream == 0 ? rC : dC;
-            const LinW& kvproj = stream == 0 ? w.rgb_kv : w.depth_kv;
-            void* vis = alloc_t((size_t)B * S * c.vis_in);
-            linear(kvproj, tok, B * S, tokC, vis, c.vis_in, ACT_NONE, false);              // rgb_kv / depth_kv Conv1d(k=1)
-            tap(stream == 0 ? "hi.rgb_kv" : "hi.depth_kv", vis, true, {B, S, c.vis_in});
-            void* vtmp = alloc_t((size_t)B * S * d);
-            void* kvin = alloc_t((size_t)B * (S > L ? S : L) * d);
-            linear(v.vis_fc, vis, B * S, c.vis_in, vtmp, d, ACT_RELU, false);
-            ln(vtmp, nullptr, v.ln, nullptr, 0, kvin, B * S, d, 1e-5f);
             int Lk = S;
             void* kv = alloc_t((size_t)B * (S > L ? S : L) * 2 * d);
             void* att = alloc_t((size_t)rows * d);
             void* t2 = alloc_t((size_t)rows * d);
             void* ffh = alloc_t((size_t)rows * c.d_ff);
             void* out = alloc_t((size_t)rows * d);
-            const void* cur_kv = kvin;
+            void* kvin = hb.kvin[stream];
             for (size_t l = 0; l < v.layers.size(); ++l) {
                 const VlaLayerW& ly = v.layers[l];
-                linear(ly.kv, cur_kv, B * Lk, d, kv, 2 * d, ACT_NONE, false);
-                if (!dry) ck(launch_attention(Q[l], kv, (char*)kv + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s), "vla attention");
+                const void* kvl = hb.kv0[stream];                                          // layer 0: projected in the encoder chain
+                if (l > 0) { linear(ly.kv, kvin, B * Lk, d, kv, 2 * d, ACT_NONE, false); kvl = kv; }
+                if (!dry) ck(launch_attention(hb.Q[l], kvl, (const char*)kvl + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s), "vla attention");
                 linear(ly.o, att, rows, d, t2, d, ACT_NONE, false, I, d);                 // queries + att
                 ln(t2, nullptr, ly.ln_att, nullptr, 0, att, rows, d, 1e-5f);             // MultiHeadAttention.layer_norm
                 linear(ly.ff1, att, rows, d, ffh, c.d_ff, ACT_RELU, false);
@@ -431,7 +478,6 @@ struct Fwd {
                 if (l + 1 < v.layers.size()) {
                     // next layer attends over this layer's output (B,L,d)
                     if (!dry) ck(hipMemcpyAsync(kvin, out, (size_t)rows * d * esz, hipMemcpyDeviceToDevice, s), "vla copy");
-                    cur_kv = kvin;
                     Lk = L;
                 }
             }
@@ -440,11 +486,6 @@ struct Fwd {
             if (!dry) ck(launch_mean_rows(out, xh + c.rgb_out + c.depth_out + stream * d, dt, B, L, d, d, ldx, 1, s), "cross_pooler");
             ar.release(m);
         }
-        // rgb_linear (:213): mean over 16 tokens -> Linear -> ReLU ; depth_linear (:214): Flatten -> Linear -> ReLU
-        void* rmean = alloc_t((size_t)B * rC);
-        if (!dry) ck(launch_mean_rows(hb.rgb_tok, rmean, dt, B, 16, rC, rC, rC, 0, s), "rgb mean");
-        linear(w.rgb_linear, rmean, B, rC, xh, ldx, ACT_RELU, true);
-        linear(w.depth_linear, hb.dep_tok, B, dS * dC, xh + c.rgb_out, ldx, ACT_RELU, true);
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;

@@ -1094,7 +1094,7 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
         tile = d.M >= 65536 ? 1 : (b64 >= 256 ? 2 : 3);
         variant = tile == 3 ? (d.K >= 2048 ? 2 : 1) : 4;
     }
-    else if (d.M <= 64) { tile = 3; variant = 1; }
+    else if (d.M <= 64) { tile = 3; variant = d.K >= 512 ? 2 : 1; }     // skinny, latency-bound: deeper ring
     else if (b128 >= 512) { tile = 0; variant = (big_rot && d.K >= big_rot && sizeof_dt(dt) == 2) ? 8 : 4; }
     else if (b64128 >= 128) { tile = 5; variant = longk ? (sizeof_dt(dt) == 2 ? 7 : 5) : 4; }   // long K: interleaved DMA issue
     else { tile = b64 >= 256 ? 2 : 3; variant = d.K >= 2048 ? 2 : 1; }
