@@ -229,20 +229,43 @@ struct Fwd {
     }
 
     // ---------------------------------------------------------------- recurrent step + heads
-    void rnn_step(const RnnW& w, float* xh, int ld, int B, const float* h_in, const float* mask, float* h_out, const Heads& heads) {
+    // One recurrent step in two halves (RnnW: the input row is [x_early | h*mask | x_late]):
+    //   rnn_pre    h*mask into the row, then the gate pre-activations of the first early+H columns (+ bias) -- needs only the
+    //              encoders' own projections and the previous state, so callers run it beside the cross-modal block;
+    //   rnn_finish adds the late columns' contribution and runs the cell (+ fused heads).
+    float* rnn_pre(const RnnW& w, float* xh, int ld, int B, const float* h_in, const float* mask) {
         const int H = ctx->cfg.hidden;
-        if (!dry) ck(launch_rnn_prep(h_in, mask, xh, B, H, ld, w.in, s), "rnn_prep");
+        if (!dry) ck(launch_rnn_prep(h_in, mask, xh, B, H, ld, w.early, s), "rnn_prep");
+        if (ctx->cfg.rnn_type != HCM_LSTM) return nullptr;
+        float* gates = alloc_f((size_t)B * 4 * H);
+        LinW first = w.cat;
+        first.K = w.early + H;
+        linear(first, xh, B, ld, gates, 4 * H, ACT_NONE, true);
+        return gates;
+    }
+    void rnn_finish(const RnnW& w, float* xh, int ld, int B, float* gates, const float* h_in, const float* mask, float* h_out,
+                    const Heads& heads) {
+        const int H = ctx->cfg.hidden;
         if (ctx->cfg.rnn_type == HCM_LSTM) {
-            float* gates = alloc_f((size_t)B * 4 * H);
-            linear(w.cat, xh, B, ld, gates, 4 * H, ACT_NONE, true);
+            if (w.early < w.in) {
+                LinW late = w.cat;
+                late.w = (char*)w.cat.w + (size_t)(w.early + H) * 4;       // f32 weights: column offset inside every row
+                late.K = w.in - w.early;
+                late.bias = nullptr;
+                linear(late, xh + w.early + H, B, ld, gates, 4 * H, ACT_NONE, true, gates, 4 * H);
+            }
             if (!dry) ck(launch_lstm_cell(gates, h_in, mask, h_out, B, H, heads, s), "lstm_cell");
         } else {
             float* gi = alloc_f((size_t)B * 3 * H);
             float* gh = alloc_f((size_t)B * 3 * H);
             linear(w.ih, xh, B, ld, gi, 3 * H, ACT_NONE, true);
-            linear(w.hh, xh + w.in, B, ld, gh, 3 * H, ACT_NONE, true);
+            linear(w.hh, xh + w.early, B, ld, gh, 3 * H, ACT_NONE, true);
             if (!dry) ck(launch_gru_cell(gi, gh, h_in, mask, h_out, B, H, heads, s), "gru_cell");
         }
+    }
+    void rnn_step(const RnnW& w, float* xh, int ld, int B, const float* h_in, const float* mask, float* h_out, const Heads& heads) {
+        float* gates = rnn_pre(w, xh, ld, B, h_in, mask);
+        rnn_finish(w, xh, ld, B, gates, h_in, mask, h_out, heads);
     }
 
     // RNNStateEncoder.forward (models/decoder/state_encoder.py:135-137): single_forward when the feature batch equals
@@ -263,6 +286,20 @@ struct Fwd {
         }
     }
 
+    // rnn_in tap: the logical input x (without the h*mask block that sits between its early and late columns)
+    void tap_rnn_in(const std::string& name, const RnnW& w, const float* xh, int ld, int B) {
+        if (dry || !ctx->taps_on) return;
+        float* tmp = nullptr;
+        ck(hipMalloc((void**)&tmp, (size_t)B * w.in * 4), "tap scratch");
+        const int H = ctx->cfg.hidden;
+        ck(hipMemcpy2DAsync(tmp, (size_t)w.in * 4, xh, (size_t)ld * 4, (size_t)w.early * 4, B, hipMemcpyDeviceToDevice, s), "tap gather");
+        if (w.early < w.in)
+            ck(hipMemcpy2DAsync(tmp + w.early, (size_t)w.in * 4, xh + w.early + H, (size_t)ld * 4, (size_t)(w.in - w.early) * 4, B, hipMemcpyDeviceToDevice, s), "tap gather");
+        tap(name, tmp, false, {B, w.in});
+        ck(hipStreamSynchronize(s), "tap sync");
+        (void)hipFree(tmp);
+    }
+
     int T = 1;      // time steps packed in the batch (training / validation path); 1 = the per-step rollout call
 
     // ---------------------------------------------------------------- stages of Seq2Seq_HighLevel_CMA.forward
@@ -278,7 +315,12 @@ struct Fwd {
         void* kvin[2] = {nullptr, nullptr};   // LN(ReLU(vis_fc(rgb_kv / depth_kv(tokens))))  [B*max(S,L)][d]  (RGB / depth chain)
         void* kv0[2] = {nullptr, nullptr};    // layer-0 fc_k|fc_v of kvin        [B*max(S,L)][2d]
     };
-    struct LoBufs { float* xh = nullptr; int ldx = 0; };   // [depth | rgb | subtask | h*mask] (seq2seq_lowlevel.py:143)
+    struct LoBufs { float* xh = nullptr; int ldx = 0; };   // [depth | rgb | h*mask | subtask] (seq2seq_lowlevel.py:143; RnnW layout)
+    // the low-level model's recurrent input, handed to hi_tail so that its early gate GEMM can run beside the cross-modal block
+    LoBufs* lo_early = nullptr;
+    const float* lo_h_in_early = nullptr;
+    float* lo_pre = nullptr;
+
 
     HiBufs hi_alloc(int B) {
         const hcm_config& c = ctx->cfg;
@@ -455,8 +497,12 @@ struct Fwd {
         const VlaW& v = w.vla;
         const int rows = B * L;
         void* I = hb.I;
+        // the two Visual_Ling_Attn calls (rgb, depth) are independent until the recurrent input: run them on two streams
+        const bool fork = ctx->concurrent && !ctx->taps_on;
+        hipStream_t main_s = s;
+        if (fork) fork_join_begin(2);
         for (int stream = 0; stream < 2; ++stream) {
-            const size_t m = ar.mark();
+            if (fork) on(stream == 0 ? main_s : ctx->aux[0]);
             const int S = stream == 0 ? 16 : dS;
             int Lk = S;
             void* kv = alloc_t((size_t)B * (S > L ? S : L) * 2 * d);
@@ -483,14 +529,23 @@ struct Fwd {
             }
             tap(stream == 0 ? "hi.vla_rgb" : "hi.vla_depth", out, true, {B, L, d});
             // cross_pooler: mean over all L tokens (:209-210) -> xh columns
-            if (!dry) ck(launch_mean_rows(out, xh + c.rgb_out + c.depth_out + stream * d, dt, B, L, d, d, ldx, 1, s), "cross_pooler");
-            ar.release(m);
+            if (!dry) ck(launch_mean_rows(out, xh + w.rnn.xcol(c.rgb_out + c.depth_out + stream * d), dt, B, L, d, d, ldx, 1, s), "cross_pooler");
         }
+        // meanwhile (third stream): the early halves of both recurrent steps
+        float* hi_pre = nullptr;
+        const bool split = T == 1;
+        if (split) {
+            if (fork) on(ctx->aux[1]);
+            hi_pre = rnn_pre(w.rnn, xh, ldx, B, h_in, mask);
+            if (lo_early) lo_pre = rnn_pre(ctx->lo.rnn, lo_early->xh, lo_early->ldx, B, lo_h_in_early, mask);
+        }
+        if (fork) { on(main_s); fork_join_end(2); }
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
-        rnn_scan(w.rnn, xh, ldx, T, B / T, h_in, mask, h_out, hd);
-        tap("hi.rnn_in", xh, false, {B, ldx});
+        if (split) rnn_finish(w.rnn, xh, ldx, B, hi_pre, h_in, mask, h_out, hd);
+        else rnn_scan(w.rnn, xh, ldx, T, B / T, h_in, mask, h_out, hd);
+        tap_rnn_in("hi.rnn_in", w.rnn, xh, ldx, B);
     }
 
     // ---------------------------------------------------------------- stages of Seq2Seq_LowLevel.forward
@@ -522,12 +577,13 @@ struct Fwd {
         const hcm_config& c = ctx->cfg;
         const LowW& w = ctx->lo;
         use(ctx->dt_vla);
-        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, lb.xh, B, 32, lb.ldx, c.depth_out + c.rgb_out, c.num_sub_tasks + 1, s), "subtask emb");
+        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, lb.xh, B, 32, lb.ldx, w.rnn.xcol(c.depth_out + c.rgb_out), c.num_sub_tasks + 1, s), "subtask emb");
         Heads hd;
         hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;
         hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = ld_stop;
-        rnn_scan(w.rnn, lb.xh, lb.ldx, T, B / T, h_in, mask, h_out, hd);
-        tap("lo.rnn_in", lb.xh, false, {B, lb.ldx});
+        if (lo_pre) rnn_finish(w.rnn, lb.xh, lb.ldx, B, lo_pre, h_in, mask, h_out, hd);     // early half done beside the high-level tail
+        else rnn_scan(w.rnn, lb.xh, lb.ldx, T, B / T, h_in, mask, h_out, hd);
+        tap_rnn_in("lo.rnn_in", w.rnn, lb.xh, lb.ldx, B);
     }
 
     // ---------------------------------------------------------------- CMANet.forward (models/cma.py:211-333)
@@ -702,6 +758,7 @@ struct Fwd {
         if (do_hi && do_lo && !rpair && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);
+        if (do_hi && do_lo && T == 1) { lo_early = &lb; lo_h_in_early = lo_h_in; }
         if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);
         const int64_t* st_ids = subtask;
         if (do_hi && do_lo) {

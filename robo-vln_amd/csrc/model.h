@@ -75,9 +75,14 @@ struct VlaW {
     float* pe = nullptr;       // sinusoid table [L][d_model] f32, built once (common/utils.py:167-185)
 };
 struct RnnW {
-    LinW cat;                  // LSTM: [4H][in+H] f32, bias = b_ih + b_hh
+    LinW cat;                  // LSTM: [4H][in+H] f32, bias = b_ih + b_hh; columns ordered like the input row (below)
     LinW ih, hh;               // GRU: separate
     int in = 0;
+    // input row layout: [x[0:early) | h*mask (H) | x[early:in)].  The gate pre-activations of the first early+H columns
+    // depend only on the encoders' own projections and the previous state, so that GEMM runs beside the cross-modal block
+    // and only the `in - early` late columns are multiplied in the serial tail (LSTM only; GRU keeps early = in).
+    int early = 0;
+    int xcol(int j) const { return j < early ? j : j + (cat.w ? cat.N / 4 : 0); }
 };
 struct HighW {
     TrunkW rgb, depth;

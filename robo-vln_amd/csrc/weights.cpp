@@ -571,7 +571,7 @@ static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model,
     return s;
 }
 
-static RnnW make_rnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
+static RnnW make_rnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre, int early = -1) {
     RnnW r;
     const HostTensor& wih = T_(ctx, model, pre + "weight_ih_l0");
     const HostTensor& whh = T_(ctx, model, pre + "weight_hh_l0");
@@ -579,14 +579,17 @@ static RnnW make_rnn(hcm_ctx* ctx, Uploader& up, int model, const std::string& p
     const HostTensor& bhh = T_(ctx, model, pre + "bias_hh_l0");
     r.in = (int)wih.shape[1];
     const int H = ctx->cfg.hidden;
+    r.early = r.in;
     if (ctx->cfg.rnn_type == HCM_LSTM) {
-        const int N = 4 * H, K = r.in + H;
+        if (early >= 0 && early <= r.in && early % 4 == 0 && (r.in - early) % 4 == 0) r.early = early;
+        const int N = 4 * H, K = r.in + H, e = r.early;
         HostTensor cat;
         cat.shape = {N, K};
         cat.f.resize((size_t)N * K);
-        for (int n = 0; n < N; ++n) {
-            std::memcpy(&cat.f[(size_t)n * K], &wih.f[(size_t)n * r.in], r.in * 4);
-            std::memcpy(&cat.f[(size_t)n * K + r.in], &whh.f[(size_t)n * H], H * 4);
+        for (int n = 0; n < N; ++n) {         // [W_ih[:, :e] | W_hh | W_ih[:, e:]]
+            std::memcpy(&cat.f[(size_t)n * K], &wih.f[(size_t)n * r.in], e * 4);
+            std::memcpy(&cat.f[(size_t)n * K + e], &whh.f[(size_t)n * H], H * 4);
+            std::memcpy(&cat.f[(size_t)n * K + e + H], &wih.f[(size_t)n * r.in + e], (r.in - e) * 4);
         }
         HostTensor b;
         b.shape = {N};
@@ -694,7 +697,7 @@ void prepare_high(hcm_ctx* ctx) {
         h.rgb_pair = make_tv_trunk_pair(ctx, up, "rgb_encoder.cnn.");
         h.has_rgb_pair = true;
     }
-    h.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
+    h.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.", c.rgb_out + c.depth_out);     // early: rgb_in | depth_in
     h.head_w = up.f32(T_(ctx, M, "linear.weight").f);
     h.head_b = up.f32(T_(ctx, M, "linear.bias").f);
 }
@@ -724,7 +727,7 @@ void prepare_low(hcm_ctx* ctx) {
         l.rgb_s = make_simple_cnn(ctx, ctx->dt_rgb, up, M, "rgb_encoder.", 3, c.rgb_h);
     }
     l.subtask_emb = up.f32(T_(ctx, M, "sub_task_embedding.weight").f);
-    l.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.");
+    l.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.", ctx->cfg.depth_out + ctx->cfg.rgb_out);   // early: depth | rgb; late: sub-task embedding
     l.lin_w = up.f32(T_(ctx, M, "linear.weight").f);
     l.lin_b = up.f32(T_(ctx, M, "linear.bias").f);
     l.stop_w = up.f32(T_(ctx, M, "stop_linear.weight").f);
