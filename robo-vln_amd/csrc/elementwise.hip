@@ -1,4 +1,4 @@
-// Memory-bound kernels of the HCM step: first-layer im2col, pooling, GroupNorm, LayerNorm, BERT
+// Memory-bound kernels of the HCM step: frame packing, pooling, GroupNorm, LayerNorm, BERT
 // embeddings, recurrent cells + heads, small glue.  All are HBM/L2-bound: 16-byte vector accesses,
 // grid-stride loops, wave64 reductions.
 #include <cstdlib>
@@ -21,64 +21,6 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
     if (g < 1) g = 1;
     if (g > (size_t)cap) g = cap;
     return (int)g;
-}
-
-// ------------------------------------------------------------------------------------------ im2col (first conv)
-// Replaces: `permute(0,3,1,2)`, `/255` (resnet_encoders.py:211-213, simple_cnns.py:144-145) + the gather half of
-// the first convolution (7x7/2 of both ResNets, 8x8/4 of SimpleCNN), whose Cin (1 or 3) is too narrow for the
-// 16-byte implicit-GEMM gather.  One thread produces one 16-byte chunk of the [M][Kp] matrix.
-template <typename S> __device__ __forceinline__ float ld_src(const S* p);
-template <> __device__ __forceinline__ float ld_src<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld_src<uint8_t>(const uint8_t* p) { return (float)*p; }
-template <> __device__ __forceinline__ float ld_src<bf16>(const bf16* p) { return bf2f(p->v); }
-template <> __device__ __forceinline__ float ld_src<f16>(const f16* p) { return Tr<f16>::ld(p); }
-
-template <typename S, typename T>
-__global__ void im2col_kernel(const S* __restrict__ x, T* __restrict__ a, int B, int H, int W, int C, int KH, int KW,
-                              int stride, int pad, int Ho, int Wo, int K, int Kp, float scale) {
-    constexpr int CH = Tr<T>::CH;
-    const int kchunks = Kp / CH;
-    const size_t total = (size_t)B * Ho * Wo * kchunks;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(e % kchunks);
-        const size_t m = e / kchunks;
-        const int ox = (int)(m % Wo);
-        const int oy = (int)((m / Wo) % Ho);
-        const int b = (int)(m / ((size_t)Wo * Ho));
-        float v[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int k = kc * CH + j;
-            float val = 0.f;
-            if (k < K) {
-                const int ci = k % C;
-                const int khw = k / C;
-                const int kh = khw / KW, kw = khw - kh * KW;
-                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    val = ld_src<S>(x + ((size_t)(b * H + iy) * W + ix) * C + ci) * scale;
-            }
-            v[j] = val;
-        }
-        st_chunk(a + m * Kp + (size_t)kc * CH, v);
-    }
-}
-
-hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C, int KH, int KW,
-                         int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s) {
-    const int K = KH * KW * C;
-    const int CH = dt_chunk(dt);
-    const size_t total = (size_t)B * Ho * Wo * (Kp / CH);
-    const int g = grid_for(total, 256, 256 * 32);
-#define L(S) hipLaunchKernelGGL((im2col_kernel<S, T>), dim3(g), dim3(256), 0, s, (const S*)x, (T*)a, B, H, W, C, KH, KW, stride, pad, Ho, Wo, K, Kp, scale)
-    HCM_DISPATCH_T(dt, {
-        if (src_dt == DT_F32) L(float);
-        else if (src_dt == DT_U8) L(uint8_t);
-        else if (src_dt == dt) L(T);
-        else return hipErrorInvalidValue;
-    });
-#undef L
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ packed RGB frame (stem)

@@ -88,7 +88,7 @@ struct Fwd {
 
     // ---------------------------------------------------------------- ResNet-50 trunks
     // torchvision resnet50 conv1..layer4 with BN folded (RGB), or habitat GN-ResNet50 (+compression) (depth).
-    // `first` is the im2col'ed input [B*Ho*Wo][Kp]; returns the trunk output living in arena memory.
+    // Returns the trunk output living in arena memory.
     struct Stem { const void* x; int x_dt; float scale; int H, W, Cin; };   // raw frame feeding the 7x7/2 stem conv
 
     void stem_conv(const ConvW& w, const Stem& st, int B, int k, int stride, int pad, void* out, int Ho, int Wo, int act) {
@@ -730,7 +730,6 @@ struct Fwd {
         const bool multi = ctx->concurrent && !ctx->taps_on;    // taps allocate/synchronise: keep them single-stream
         hipStream_t main_s = ctx->stream;
         hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s, a2 = multi ? ctx->aux[2] : main_s;
-        hipStream_t a3 = multi ? ctx->aux[3] : main_s;
         static const int skip = getenv("HCM_SKIP") ? atoi(getenv("HCM_SKIP")) : 0;   // profiling aid: drop chains (bitmask)
         if (multi) fork_join_begin(4);
         // Host enqueue order = start order on the GPU: the chains made of many small dependent launches go first (BERT,
@@ -744,8 +743,7 @@ struct Fwd {
         if (pair) {
             if (!(skip & 4)) depth_pair(depth, B, hb, lb);
         } else if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
-        static const int dsplit = getenv("HCM_DEPTH_SPLIT") ? atoi(getenv("HCM_DEPTH_SPLIT")) : 0;
-        on((do_hi && dsplit) ? a3 : a1);
+        on(a1);
         if (do_lo && !pair && !(skip & 4)) lo_depth(depth, B, lb);
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);

@@ -7,11 +7,16 @@
 // channels of ONE output pixel: the epilogue (bias + residual + activation) then stores 8 B (bf16) or
 // 16 B (f32) per lane into the NHWC output with no transpose.
 //
-// Tile: BM output pixels x BN output channels x 128 bytes of K per step (64 bf16 / 32 f32), 4 waves (2x2),
-// LDS double-buffered, global->register->LDS staging (the im2col gather needs per-chunk predication, so
-// the LDS-DMA path with its lane-linear destination is not used here).  LDS rows are 128 B; the 16-byte
-// chunk index is XOR-swizzled with (row & 7), which makes both the ds_write_b128 staging and the
-// ds_read_b128 fragment reads bank-conflict free (cdna_hip_programming.md T2).
+// Tile: BM output pixels x BN output channels x 128 bytes of K per step (64 bf16/f16, 32 f32); 4 waves (2x2) or 8 waves
+// (2x4, 4x2 for the 256x128 tile).  Two kernels share the tile math and the epilogue:
+//   igemm_dma_kernel  (every conv / linear): both operand tiles travel L2/HBM -> LDS with bounds-checked
+//                     `buffer_load_dwordx4 ... lds` issued from inline asm (zero fill for the im2col padding comes from the
+//                     hardware range check), 2-buffer or 3-deep ring, counted vmcnt waits, optionally with the DMA issue
+//                     interleaved into the MFMA stream (ILV) and a rotated loop; see the comment above the kernel;
+//   igemm_kernel      register-staged (global -> VGPR -> LDS); its narrow-channel form gathers first layers (Cin = 1 or 3)
+//                     element-wise from the raw frame (fp32 path, depth stems, SimpleCNN).
+// LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row & 7), which makes the staging writes and the
+// ds_read_b128 fragment reads bank-conflict free (cdna_hip_programming.md T2; 0 conflicts measured).
 //
 // K ordering inside one MFMA step is permuted consistently for both operands (lane group g consumes the
 // g-th 16-byte chunk of the 64-byte half row), which a dot product is invariant to; this lets the f32
@@ -1088,14 +1093,14 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     // variant: 1 dma2, 2 dma3 (4 waves); 4 dma2, 5 dma3 (8 waves)
     int tile, variant;
     const bool longk = d.K >= 768;
-    static const int big_rot = getenv("HCM_IGEMM_ROT128") ? atoi(getenv("HCM_IGEMM_ROT128")) : 0;
     if (d.N <= 32) { tile = 3; variant = d.K >= 2048 ? 2 : 1; }
     else if (d.N <= 64) {
         tile = d.M >= 65536 ? 1 : (b64 >= 256 ? 2 : 3);
         variant = tile == 3 ? (d.K >= 2048 ? 2 : 1) : 4;
     }
     else if (d.M <= 64) { tile = 3; variant = d.K >= 512 ? 2 : 1; }     // skinny, latency-bound: deeper ring
-    else if (b128 >= 512) { tile = 0; variant = (big_rot && d.K >= big_rot && sizeof_dt(dt) == 2) ? 8 : 4; }
+    else if (b128 >= 512) { tile = 0; variant = 4; }     // (the rotated 3-ring variant 8 wins stand-alone for K >= 2048 but
+                                                         //  loses end to end: 1 workgroup per CU blocks the other streams)
     else if (b64128 >= 128) { tile = 5; variant = longk ? (sizeof_dt(dt) == 2 ? 7 : 5) : 4; }   // long K: interleaved DMA issue
     else { tile = b64 >= 256 ? 2 : 3; variant = d.K >= 2048 ? 2 : 1; }
     return variant * 6 + tile;

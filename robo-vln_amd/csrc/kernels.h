@@ -44,10 +44,6 @@ void igemm_set_tuning(bool on);
 size_t igemm_tuned_shapes();
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEMM_PROF=1 phase counters
 
-// First-layer im2col (Cin = 1 or 3): x [B,H,W,C] (src_dt: f32 / u8 / T) * scale -> A [B*Ho*Wo][Kp] (T), zero-padded K..Kp
-hipError_t launch_im2col(const void* x, int src_dt, void* a, int dt, int B, int H, int W, int C,
-                         int KH, int KW, int stride, int pad, int Ho, int Wo, int Kp, float scale, hipStream_t s);
-// depth pre-pool: f32 [B,H,W,1] -> avg_pool2d(2) -> T [B,H/2,W/2,1]
 // 7x7/2 pad-3 stem on a 16-bit trunk: the raw RGB frame (f32 or uint8, NHWC3) is first packed ONCE into a zero-bordered
 // 4-channel frame of the storage type, [B][H+6][W+8][4] (3 px border left/top, 5 right, 3 bottom; channel 3 = 0; values
 // multiplied by `scale`).  In that frame a kernel row of an output pixel is ONE contiguous, 16-byte-aligned run of

@@ -54,7 +54,7 @@ struct TrunkW {
     int out_c = 0;
 };
 struct SimpleCnnW {
-    ConvW c0, c1, c2;          // 8x8/4 (im2col), 4x4/2, 3x3/1
+    ConvW c0, c1, c2;          // 8x8/4 (narrow-channel gather), 4x4/2, 3x3/1
     LinW fc;
     int cin = 1, hw = 0, h3 = 0;
 };
