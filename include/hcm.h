@@ -192,6 +192,11 @@ int hcm_debug_igemm_prof(uint64_t* out8, int reset);
 int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y,
                   int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                   int act, void* stream);
+/* conv2d (no bias) + GroupNorm(groups) (+ residual) (+ ReLU) in one launch; the output map must have Ho*Wo | 64 pixels and
+ * Cout / groups must be a multiple of 8 dividing 128 (the GN-ResNet layers at 8x8 and 4x4). */
+int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
+                     int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
+                     int relu, void* stream);
 /* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,

@@ -513,6 +513,19 @@ int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const vo
     g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = act;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
+                     int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
+                     int relu, void* stream) {
+    if (groups < 1 || Cout % groups) return HCM_ERR_ARG;
+    IGemm g;
+    g.x = x; g.w = w_ohwi; g.res = residual; g.y = y;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.xC = Cin;
+    g.Ho = (H + 2 * pad - KH) / stride + 1; g.Wo = (W + 2 * pad - KW) / stride + 1;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = relu ? ACT_RELU : ACT_NONE;
+    g.gn_gamma = gamma; g.gn_beta = beta; g.gn_cg = Cout / groups; g.gn_hw = g.Ho * g.Wo; g.gn_eps = eps;
+    return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C, int Cout,
                      int KH, int KW, int stride, int pad, int K, int Kp, int rowrun, float scale, int act, void* stream) {
     IGemm g;

@@ -53,9 +53,25 @@ struct Fwd {
     }
 
     // ---------------------------------------------------------------- primitive wrappers
-    void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo) {
+    // conv followed by GroupNorm (+ residual + ReLU): one launch when the output map is small enough for the fused
+    // epilogue (igemm.hip), else conv + the stand-alone GroupNorm kernels
+    void conv_gn(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, const NormW& n, int G, bool relu, int Ho,
+                 int Wo) {
+        static const bool no_fuse = getenv("HCM_NO_GN_FUSE") != nullptr;
+        const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
+        const bool fuse = !no_fuse && hw <= 64 && 64 % hw == 0 && cg % 8 == 0 && 128 % cg == 0 && w.Cout % cg == 0 && !w.bias;
+        if (fuse) {
+            conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg);
+        } else {
+            conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
+            gn(out, res, n, in.B, hw, C, G, relu);
+        }
+    }
+    void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo,
+              const NormW* gnw = nullptr, int gn_cg = 0) {
         if (dry) return;
         IGemm g;
+        if (gnw) { g.gn_gamma = gnw->gamma; g.gn_beta = gnw->beta; g.gn_cg = gn_cg; g.gn_hw = Ho * Wo; g.gn_eps = 1e-5f; }
         g.x = in.p; g.w = w.w; g.bias = w.bias; g.res = res; g.y = out;
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
         g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
@@ -144,20 +160,19 @@ struct Fwd {
             void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
             const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
-            conv(b.c1, x, sa, 1, 0, nullptr, t.gn ? ACT_NONE : ACT_RELU, x.H, x.W);
-            if (t.gn) gn(sa, nullptr, b.n1, B, x.H * x.W, CO(b.c1), G, true);
+            if (t.gn) conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
+            else conv(b.c1, x, sa, 1, 0, nullptr, ACT_RELU, x.H, x.W);
             Act o2{sb, B, Ho2, Wo2, CO(b.c2)};
-            conv(b.c2, o1, sb, b.stride, 1, nullptr, t.gn ? ACT_NONE : ACT_RELU, Ho2, Wo2);
-            if (t.gn) gn(sb, nullptr, b.n2, B, Ho2 * Wo2, CO(b.c2), G, true);
+            if (t.gn) conv_gn(b.c2, o1, sb, b.stride, 1, nullptr, b.n2, G, true, Ho2, Wo2);
+            else conv(b.c2, o1, sb, b.stride, 1, nullptr, ACT_RELU, Ho2, Wo2);
             const void* idt = x.p;
             if (b.has_ds) {
-                conv(b.ds, x, sa, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);       // o1 is dead: reuse its slot
-                if (t.gn) gn(sa, nullptr, b.nds, B, Ho2 * Wo2, CO(b.ds), G, false);
+                if (t.gn) conv_gn(b.ds, x, sa, b.stride, 0, nullptr, b.nds, G, false, Ho2, Wo2);   // o1 is dead: reuse its slot
+                else conv(b.ds, x, sa, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);
                 idt = sa;
             }
             if (t.gn) {
-                conv(b.c3, o2, sc, 1, 0, nullptr, ACT_NONE, Ho2, Wo2);
-                gn(sc, idt, b.n3, B, Ho2 * Wo2, CO(b.c3), G, true);                // relu(GN(conv) + identity)
+                conv_gn(b.c3, o2, sc, 1, 0, idt, b.n3, G, true, Ho2, Wo2);          // relu(GN(conv) + identity)
             } else {
                 conv(b.c3, o2, sc, 1, 0, idt, ACT_RELU, Ho2, Wo2);                  // relu(bn(conv) + identity), fused
             }
@@ -169,8 +184,7 @@ struct Fwd {
         }
         if (t.gn) {
             int fr = (xi + 1) & 3;
-            conv(t.compress, x, slot[fr], 1, 1, nullptr, ACT_NONE, x.H, x.W);
-            gn(slot[fr], nullptr, t.n_compress, B, x.H * x.W, CO(t.compress), t.pair ? 2 : 1, true);
+            conv_gn(t.compress, x, slot[fr], 1, 1, nullptr, t.n_compress, t.pair ? 2 : 1, true, x.H, x.W);
             x = Act{slot[fr], B, x.H, x.W, CO(t.compress)};
         }
         return x;

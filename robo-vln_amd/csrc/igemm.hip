@@ -51,6 +51,8 @@ struct IGemmDev {
     int rowrun;                    // RGB f32 stem: K laid out as KH runs of 24 (see igemm_kernel)
     // grouped launch (blockIdx.y = group): element offsets added to x / w / bias / y+res per group
     int groups; long long g_x, g_w, g_b, g_y;
+    // fused GroupNorm epilogue (small maps: a 64-row tile holds whole samples): y = GN(conv) * gamma + beta (+ res) (ReLU)
+    const float* gn_gamma; const float* gn_beta; int gn_cg, gn_hw; float gn_eps;
 };
 
 template <typename T> struct Mma;
@@ -118,6 +120,34 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
             *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
     __syncthreads();
+    // Fused GroupNorm (habitat GN-ResNet layers whose map has <= 64 pixels): the tile holds BM / hw whole samples and BN / cg
+    // whole groups; one wave per (sample, group) reduces its hw x cg block of the f32 image (fixed order), then the
+    // normalisation rides in phase 2.  The un-normalised conv output is never written.
+    float* gst = sc + BM * LDC;            // [sample][group][mean, rstd]
+    const int gn_ng = p.gn_cg ? BN / p.gn_cg : 0;
+    if (p.gn_cg) {
+        const int hw = p.gn_hw, cg = p.gn_cg;
+        const int pairs = (BM / hw) * gn_ng;
+        const int lane_ = tid & 63;
+        for (int pr = tid >> 6; pr < pairs; pr += NW) {
+            const int sidx = pr / gn_ng, g = pr - sidx * gn_ng;
+            const int ne = hw * cg;
+            float a = 0.f, q = 0.f;
+            for (int e = lane_; e < ne; e += 64) {
+                const int r = sidx * hw + e / cg, cix = g * cg + e % cg;
+                const float v = sc[r * LDC + cix];
+                a += v; q += v * v;
+            }
+            a = wave_sum(a); q = wave_sum(q);
+            if (lane_ == 0) {
+                const float inv = 1.0f / (float)ne;
+                const float mean = a * inv;
+                gst[pr * 2] = mean;
+                gst[pr * 2 + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
+            }
+        }
+        __syncthreads();
+    }
     constexpr int TPR = BN / 8;            // threads per tile row
     constexpr int RPP = 64 * NW / TPR;     // rows per pass
     const int c8 = (tid % TPR) * 8;
@@ -146,6 +176,16 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
             const float4 a1 = *reinterpret_cast<const float4*>(sc + r * LDC + c8 + 4);
             v[0] = a0.x + bias8[0]; v[1] = a0.y + bias8[1]; v[2] = a0.z + bias8[2]; v[3] = a0.w + bias8[3];
             v[4] = a1.x + bias8[4]; v[5] = a1.y + bias8[5]; v[6] = a1.z + bias8[6]; v[7] = a1.w + bias8[7];
+        }
+        if (p.gn_cg) {                     // cg is a multiple of 8: the thread's 8 channels share one group
+            const float* ms = gst + ((r / p.gn_hw) * gn_ng + c8 / p.gn_cg) * 2;
+            const float mean = ms[0], rstd = ms[1];
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gn_gamma + n), g1 = *reinterpret_cast<const float4*>(p.gn_gamma + n + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.gn_beta + n), b1 = *reinterpret_cast<const float4*>(p.gn_beta + n + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
         }
         if (p.res) {
             const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
@@ -532,6 +572,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         p.x += g * p.g_x * (long long)sizeof(T);
         p.w += g * p.g_w * (long long)sizeof(T);
         if (p.bias) p.bias += g * p.g_b;
+        if (p.gn_cg) { p.gn_gamma += g * p.g_b; p.gn_beta += g * p.g_b; }
         if (p.res) p.res += g * p.g_y * (long long)sizeof(T);
         p.y += g * p.g_y * (long long)(p.out_f32 ? 4 : sizeof(T));
     }
@@ -899,7 +940,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);       // every XCD gets ceil(tilesN/8) slots per pixel tile
     }
     size_t lds = ((variant == 2 || variant == 5 || variant >= 7) ? 3 : 2) * (size_t)(BM + BN) * 128;
-    const size_t lds_c = (size_t)BM * (BN + 4) * 4;           // f32 output-tile image of the epilogue
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024;    // f32 output-tile image of the epilogue (+ fused-GroupNorm statistics)
     if (lds_c > lds) lds = lds_c;
     static bool attr_done = false;                            // one flag per template instantiation
     if (!attr_done) {
@@ -1179,6 +1220,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.rowrun = 0;
     d.groups = g.groups > 1 ? g.groups : 1;
     d.g_x = g.g_x; d.g_w = g.g_w; d.g_b = g.g_b; d.g_y = g.g_y;
+    d.gn_gamma = g.gn_gamma; d.gn_beta = g.gn_beta; d.gn_cg = g.gn_gamma ? g.gn_cg : 0; d.gn_hw = g.gn_hw; d.gn_eps = g.gn_eps;
     if (g.x_src_dt >= 0) {
         // narrow-channel first layer: element-wise gather from the raw frame
         d.rowrun = g.x_rowrun;
@@ -1207,6 +1249,13 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if ((g.Cin % CH) || (d.xC % CH) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
         return hipErrorInvalidValue;
     if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
+    if (d.gn_cg) {
+        // fused GroupNorm: 64-row tiles of whole samples, 128 channels of whole groups (igemm_epilogue)
+        if (g.x_src_dt >= 0 || d.gn_hw <= 0 || 64 % d.gn_hw || d.M % d.gn_hw || d.gn_cg % 8 || 128 % d.gn_cg || d.N % d.gn_cg || d.bias ||
+            d.out_f32 || !d.gn_beta)
+            return hipErrorInvalidValue;
+        return launch_dt(d, dt, ((d.K >= 768 && dt != DT_F32) ? 7 : 4) * 6 + 5, s);
+    }
     static const char* force = getenv("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
     if (force) return launch_dt(d, dt, atoi(force), s);
     const std::string key = shape_key(d, dt);

@@ -35,6 +35,9 @@ struct IGemm {
     int groups = 1;              // grouped launch: group g adds g*g_x / g*g_w / g*g_b / g*g_y ELEMENTS to x / w / bias / (y, res)
     long long g_x = 0, g_w = 0, g_b = 0, g_y = 0;
     int stride_w = 0;            // horizontal stride when it differs from `stride` (0 = same); packed-frame stem only
+    // fused GroupNorm epilogue (launch_igemm checks: map of gn_hw | 64 pixels per sample, gn_cg channels per group with 8 | gn_cg | 128,
+    // no bias): y = (conv - mean) * rstd * gamma + beta, then residual / activation as usual; 64x128 tiles are forced
+    const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int gn_cg = 0, gn_hw = 0; float gn_eps = 1e-5f;
     int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);

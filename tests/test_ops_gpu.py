@@ -256,3 +256,37 @@ def test_stem_conv_packed(prec, cfg):
     torch.cuda.synchronize()
     err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [
+    # B, H, Cin, Cout, K, stride, pad, GN groups, residual, relu
+    (4, 8, 256, 256, 1, 1, 0, 32, False, True), (4, 8, 128, 128, 3, 1, 1, 16, False, True), (3, 8, 128, 512, 1, 1, 0, 16, True, True),
+    (8, 4, 256, 256, 3, 1, 1, 16, False, True), (8, 4, 256, 1024, 1, 1, 0, 16, True, True), (5, 16, 128, 256, 1, 2, 0, 32, False, False),
+    (8, 4, 512, 128, 3, 1, 1, 1, False, True), (8, 8, 64, 128, 3, 2, 1, 8, True, True), (4, 2, 256, 512, 1, 1, 0, 32, True, True),
+])
+def test_conv2d_groupnorm_fused(prec, cfg):
+    """conv + GroupNorm (+ residual) (+ ReLU) in one launch (GN-ResNet layers with <= 64 pixels per sample)."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, Cin, Cout, K, stride, pad, G, use_res, relu = cfg
+    x = _rnd(B, H, H, Cin, seed=1).to(tdt)
+    w = (_rnd(Cout, K, K, Cin, seed=2) * (2.0 / (Cin * K * K)) ** 0.5).to(tdt)
+    gamma, beta = _rnd(Cout, seed=3) * 0.5 + 1.0, _rnd(Cout, seed=4) * 0.1
+    conv = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride=stride, padding=pad)
+    Ho = conv.shape[2]
+    res = _rnd(B, Ho, Ho, Cout, seed=5).to(tdt) if use_res else None
+    ref = F.group_norm(conv, G, gamma, beta, 1e-5)
+    if use_res:
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    if relu:
+        ref = F.relu(ref)
+    xd, wd, gd, bd = x.cuda(), w.cuda(), gamma.cuda(), beta.cuda()
+    rd = res.cuda() if use_res else None
+    y = torch.full((B, Ho, Ho, Cout), float("nan"), device="cuda", dtype=tdt)
+    rc = lib.hcm_op_conv2d_gn(_p(xd), _p(wd), _p(gd), _p(bd), _p(rd) if use_res else None, _p(y), code, B, H, H, Cin, Cout, K, K, stride, pad,
+                              G, 1e-5, int(relu), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 2 * tol * max(1.0, ref.abs().max().item()), err
