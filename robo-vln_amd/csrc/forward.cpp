@@ -59,7 +59,11 @@ struct Fwd {
                  int Wo) {
         static const bool no_fuse = getenv("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
-        const bool fuse = !no_fuse && hw <= 64 && 64 % hw == 0 && cg % 8 == 0 && 128 % cg == 0 && w.Cout % cg == 0 && !w.bias;
+        // the fused epilogue needs 64x128 tiles: not worth it when that leaves a long-K conv on a handful of workgroups
+        // (the 3x3 compression conv: K = 18432 on 32 workgroups, 119 us fused vs 63 + 8 us separate)
+        const long blocks = (long)((in.B * hw + 63) / 64) * ((w.Cout + 127) / 128) * w.groups;
+        const bool fuse = !no_fuse && hw <= 64 && 64 % hw == 0 && cg % 8 == 0 && 128 % cg == 0 && w.Cout % cg == 0 && !w.bias &&
+                          (blocks >= 64 || w.K < 4096);
         if (fuse) {
             conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg);
         } else {
