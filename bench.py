@@ -158,15 +158,30 @@ def main():
         stager.host["depth"].copy_(torch.from_numpy(obs_np["depth"]))
         stager.host["instruction"].copy_(torch.from_numpy(obs_np["instruction"].astype("int32")))
 
+    # The all-gather of step i is enqueued on a communication stream and overlaps the compute of step i+1 (the gathered
+    # records are the step's OUTPUT towards the environments; nothing in the next policy step reads them).  The engine's
+    # record buffers ping-pong, so step i+2 waits for gather i before overwriting its source.
+    comm = torch.cuda.Stream() if use_dist else None
+    pending = []
+
     def step(mask):
         nonlocal hh, lh, obs
+        if use_dist and len(pending) >= 2:
+            torch.cuda.current_stream().wait_event(pending.pop(0))
         if stager is not None:
             for k in ("rgb", "depth"):
                 stager.dev[k].copy_(stager.host[k], non_blocking=True)
             obs = stager.dev
         r, hh, lh = eng.act(obs, hh, lh, mask)
         if use_dist:
-            gather_records(r, all_rec)              # ONE RCCL all-gather of the (B,7) records per step
+            ready = torch.cuda.Event()
+            ready.record()
+            comm.wait_event(ready)
+            with torch.cuda.stream(comm):
+                gather_records(r, all_rec)              # ONE RCCL all-gather of the (B,7) records per step
+                done = torch.cuda.Event()
+                done.record(comm)
+            pending.append(done)
         else:
             rec.copy_(r)
 
