@@ -1016,9 +1016,8 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
 // 256x128 tile, 8 waves as 4 (pixel) x 2 (channel): wave tile 64x64 like the 4-wave 128x128 kernel, but half the
 // L2->LDS staging bytes per flop of a 128x128 tile (a 128x128x64 step needs 32 KB for 512 SIMD-cycles of MFMA -- exactly
 // the 64 B/clk/CU a CU can pull; 256x128 needs 48 KB for 1024).  One workgroup per CU (96 / 144 KB of LDS).
-template <typename T>
+template <typename T, int BM = 256, int BN = 128, int WMc = 4>
 static hipError_t launch_big(IGemmDev d, int ring, int ilv, hipStream_t s) {
-    constexpr int BM = 256, BN = 128;
     d.tilesM = (d.M + BM - 1) / BM;
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
@@ -1030,11 +1029,11 @@ static hipError_t launch_big(IGemmDev d, int ring, int ilv, hipStream_t s) {
         else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);
     }
     size_t lds = (size_t)ring * (BM + BN) * 128;
-    const size_t lds_c = (size_t)BM * (BN + 4) * 4;
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024;
     if (lds_c > lds) lds = lds_c;
     const bool prof = std::is_same<T, bf16>::value && prof_on();
     const void* fn;
-#define HCM_BIG(R, P, I) reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, R, 8, 4, P, I>)
+#define HCM_BIG(R, P, I) reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, R, 8, WMc, P, I>)
     if (ilv == 2) ring = 3;
     if constexpr (std::is_same<T, bf16>::value) {
         if (prof) fn = ilv == 2 ? HCM_BIG(3, true, 2) : ring == 3 ? (ilv ? HCM_BIG(3, true, 1) : HCM_BIG(3, true, 0)) : (ilv ? HCM_BIG(2, true, 1) : HCM_BIG(2, true, 0));
@@ -1107,6 +1106,14 @@ static hipError_t launch_choice(const IGemmDev& d, int choice, hipStream_t s) {
     }
 }
 static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s) {
+    if (choice >= 110) {                                // 110..115: 64 pixels x 256 channels (whole 512-byte output rows per workgroup)
+        const int c2 = choice - 110;
+        const int ring = 2 + (c2 & 1);
+        const int ilv = c2 >= 4 ? 2 : c2 >= 2 ? 1 : 0;
+        if (dt == DT_BF16) return launch_big<bf16, 64, 256, 2>(d, ring, ilv, s);
+        if (dt == DT_F16) return launch_big<f16, 64, 256, 2>(d, ring, ilv, s);
+        return hipErrorInvalidValue;
+    }
     if (choice >= 100) {                                // 100 / 101: 256x128 tile with a 2- / 3-deep LDS ring; 102 / 103: interleaved DMA
         const int ring = 2 + (choice & 1);
         const int ilv = choice >= 104 ? 2 : choice >= 102 ? 1 : 0;       // 105: rotated loop
@@ -1133,6 +1140,11 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     // tile index into kTiles: 0 128x128, 1 128x64, 2 64x64, 3 64x32, 4 128x32, 5 64x128
     // variant: 1 dma2, 2 dma3 (4 waves); 4 dma2, 5 dma3 (8 waves)
     int tile, variant;
+    // write-dominated expansions (small K, >= 256 output channels, big M): 64 x 256 tiles write whole 512-byte pixel rows.
+    // Stand-alone (no residual, one group) layer1's 64 -> 256 goes 55 -> 45 us; in the step (hi|lo groups, residual) it
+    // measured 1.5 % SLOWER end to end, so it stays opt-in.
+    static const int row_tiles = getenv("HCM_IGEMM_ROW256") ? atoi(getenv("HCM_IGEMM_ROW256")) : 0;
+    if (row_tiles && dt != DT_F32 && d.N >= 256 && d.N % 256 == 0 && d.K <= 256 && (long)d.M * d.groups >= 32768) return 110;
     const bool longk = d.K >= 768;
     if (d.N <= 32) { tile = 3; variant = d.K >= 2048 ? 2 : 1; }
     else if (d.N <= 64) {
