@@ -119,7 +119,9 @@ struct Fwd {
         g.Ho = Ho; g.Wo = Wo; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad;
         g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
         g.x_src_dt = st.x_dt; g.x_scale = st.scale;
-        g.x_rowrun = (w.K == w.KH * 24 && st.Cin == 3) ? 1 : 0;
+        // row-run K layout (kh*24 + kw*3 + ci): the 7x7 stem's row-run weights, and any 3-channel kernel with KW = 8 (SimpleCNN's
+        // 8x8/4, where it coincides with the plain layout); the vector gather exists for f32 frames only
+        g.x_rowrun = (w.K == w.KH * 24 && st.Cin == 3 && st.x_dt == DT_F32) ? 1 : 0;
         ck(launch_igemm(g, w.dt, s), "stem conv");
     }
 

@@ -67,6 +67,18 @@ def test_uint8_rgb_equals_float_rgb():
         assert s["max_abs"] <= 1e-2
 
 
+def test_simplecnn_uint8_frames():
+    """Low-level model with SimpleCNN encoders fed uint8 RGB frames (the 8x8/4 first conv gathers element-wise from the
+    raw frame; regression: its K = 8*8*3 = 192 equals the 7x7 stem's row-run K and used to select the f32-only gather)."""
+    from tests import parity_util
+    rep = parity_util.run_case("lo_simplecnn_256", "bf16", taps=False, rgb_uint8=True)
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-2, s
+    rep = parity_util.run_case("lo_simplecnn_256", "fp32", taps=False, rgb_uint8=True)
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-3, s
+
+
 def test_hipgraph_replay_equals_eager():
     """act() served by the captured hipGraph (engine-owned stream + static I/O) must equal the eager multi-stream path
     bit for bit over a multi-step rollout with an episode reset."""
