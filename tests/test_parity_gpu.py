@@ -67,6 +67,16 @@ def test_uint8_rgb_equals_float_rgb():
         assert s["max_abs"] <= 1e-2
 
 
+@pytest.mark.parametrize("name", ["gru_128_L20", "native_224_256", "cfg4_L160_N6"])
+def test_uint8_frames_other_configs(name):
+    """uint8 RGB frames through every model variant (GRU state encoders, the reference's native 224/256 frame sizes, the
+    high-level model alone)."""
+    from tests import parity_util
+    rep = parity_util.run_case(name, "bf16", taps=False, rgb_uint8=True)
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-2, s
+
+
 def test_simplecnn_uint8_frames():
     """Low-level model with SimpleCNN encoders fed uint8 RGB frames (the 8x8/4 first conv gathers element-wise from the
     raw frame; regression: its K = 8*8*3 = 192 equals the 7x7 stem's row-run K and used to select the f32-only gather)."""
