@@ -62,6 +62,10 @@ class HCMConfig:
             raise ValueError("DEPTH_ENCODER.cnn_type must be SimpleDepthCNN or VlnResnetDepthEncoder")
         if self.d_model % self.vla_heads:
             raise ValueError("d_model must be divisible by h")
+        if self.depth_encoder == "VlnResnetDepthEncoder":
+            k = self.depth_hw // 64
+            if self.depth_hw % 64 or k < 1 or (k & (k - 1)):
+                raise ValueError("depth frame size must be 64 * 2^k for the ResNet depth encoder (compression channels 2048 / (H/64)^2)")
         return self
 
     @property

@@ -46,6 +46,11 @@ def test_create_rejects_broken_reference_flags():
     assert rc == -6 and b"output_shape" in l.hcm_last_error(None)
     with pytest.raises(ValueError):
         HCMConfig(use_prev_action=True).validate()
+    # depth frames whose compression conv would get a non-vector channel count (192 -> 2048 / 9 = 228) are rejected up front
+    l, rc, h = _create(HCMConfig(), depth_h=192, depth_w=192)
+    assert rc == -6 and b"depth frame size" in l.hcm_last_error(None)
+    with pytest.raises(ValueError):
+        HCMConfig(depth_hw=192).validate()
 
 
 def test_strict_state_dict_keys_and_shapes():

@@ -154,3 +154,37 @@ def test_seq_forward_matches_oracle(name, precision):
         assert np.abs(logits.cpu().numpy() - gold["logits"]).max() <= tol
         assert np.abs(vel.cpu().numpy() - gold["vel"]).max() <= tol
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("kw,batch", [
+    (dict(rgb_hw=128, depth_hw=128, instr_len=37, bert_layers=2), 3),      # odd instruction length, odd batch
+    (dict(rgb_hw=128, depth_hw=128, instr_len=7, bert_layers=1, vla_layers=2), 5),
+    (dict(rgb_hw=128, depth_hw=128, instr_len=160, bert_layers=1), 1),     # longest supported instruction, single env
+    (dict(rgb_hw=192, depth_hw=128, instr_len=20, bert_layers=1), 2),      # 192: 6x6 RGB map -> overlapping adaptive pool windows
+])
+def test_odd_shapes_vs_oracle(kw, batch, precision):
+    """Shapes no golden covers (odd L and B, L = 160, 192-pixel RGB frames): HIP path vs the CPU oracle, two steps."""
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import HCMConfig
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(**kw).validate()
+    B = batch
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=4)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B + 1, precision=precision)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+    ohh = torch.zeros(R, B, cfg.hidden); olh = torch.zeros(R, B, cfg.hidden)
+    for t in range(2):
+        obs_np = synth.make_observations(cfg, B, step=t, seed=4)
+        m = cases.step_masks(B, t)
+        rec, hh, lh = eng.act({k: torch.from_numpy(v).cuda() for k, v in obs_np.items()}, hh, lh, torch.from_numpy(m).cuda())
+        rec = rec.cpu()
+        logits, ohh = ora.hi.forward(obs_np, ohh, m)
+        vel, stop, olh = ora.lo.forward(obs_np, olh, m, torch.argmax(rec[:, :4], 1))
+        ref = torch.cat([logits, vel, stop], 1)
+        assert (rec - ref).abs().max().item() <= TOL[precision], (t, (rec - ref).abs().max().item())
+    eng.close()
