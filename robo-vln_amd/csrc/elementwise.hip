@@ -680,6 +680,30 @@ hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ split-K reduction
+// y[m][n] = act(sum_s part[s][m][n] + bias[n]) in a fixed order (deterministic); part is f32 [S][M][N], y is T or f32 at ldy.
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, void* __restrict__ y, int S, int M,
+                                     int N, int ldy, int act, int out_f32) {
+    const size_t total = (size_t)M * N;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e % N);
+        const size_t m = e / N;
+        float a = bias ? bias[n] : 0.f;
+        for (int s_ = 0; s_ < S; ++s_) a += part[(size_t)s_ * total + e];
+        if (act == ACT_RELU) a = fmaxf(a, 0.f);
+        else if (act == ACT_GELU) a = gelu_erf(a);
+        if (out_f32) reinterpret_cast<float*>(y)[m * ldy + n] = a;
+        else Tr<T>::st(reinterpret_cast<T*>(y) + m * ldy + n, a);
+    }
+}
+hipError_t launch_splitk_reduce(const float* part, const float* bias, void* y, int dt, int S, int M, int N, int ldy, int act, int out_f32,
+                                hipStream_t s) {
+    const size_t total = (size_t)M * N;
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, part, bias, y, S, M, N, ldy, act, out_f32));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ CMANet instruction encoder
 // InstructionEncoder.forward (models/encoders/instruction_encoder.py:70-92): lengths = #non-zero ids, embedding lookup.
 // x[row][0..E) = table[id], zero-padded to ldx columns; one block per sample also counts its length.

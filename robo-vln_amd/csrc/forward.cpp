@@ -87,14 +87,35 @@ struct Fwd {
         ck(launch_igemm(g, w.dt, s), "conv igemm");
     }
     // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
+    // Skinny long-K layers (the M = batch projections behind the encoders, SimpleCNN's 25088-wide FC) would run on a few
+    // dozen workgroups with hundreds of serial K steps: they are split along K through the grouped-launch mechanism (group s
+    // = columns [s*Ks, (s+1)*Ks) of A and W, f32 partials), then summed in a fixed order with bias + activation.
     void linear(const LinW& w, const void* a, int M, int lda, void* y, int ldy, int act, bool out_f32,
                 const void* res = nullptr, int ldr = 0, int wdt = -1) {
+        const int wd = wdt < 0 ? w.dt : wdt;
+        const int CHw = wd == DT_F32 ? 4 : 8;
+        int S = 1;
+        static const bool no_split = getenv("HCM_NO_SPLITK") != nullptr;
+        if (!no_split && !res && M <= 256 && w.K >= 2048) {
+            const long blocks = (long)((M + 63) / 64) * ((w.N + 31) / 32);
+            while (S < 16 && blocks * S < 256 && w.K % (2 * S * 64) == 0 && w.K / (2 * S) >= 256) S *= 2;
+            if (w.K % (S * CHw)) S = 1;
+        }
+        float* part = S > 1 ? alloc_f((size_t)S * M * w.N) : nullptr;       // allocated in the dry run too
         if (dry) return;
         IGemm g;
         g.x = a; g.w = w.w; g.bias = w.bias; g.res = res; g.y = y;
         g.B = M; g.Cin = w.K; g.xC = lda; g.M = M; g.N = w.N; g.K = w.K; g.Kp = w.Kp;
         g.ldy = ldy; g.ldr = ldr ? ldr : w.N; g.act = act; g.out_f32 = out_f32 ? 1 : 0;
-        ck(launch_igemm(g, wdt < 0 ? w.dt : wdt, s), "linear igemm");
+        if (S > 1) {
+            const int Ks = w.K / S;
+            g.K = Ks; g.Cin = Ks; g.bias = nullptr; g.y = part; g.ldy = w.N; g.ldr = w.N; g.act = ACT_NONE; g.out_f32 = 1;
+            g.groups = S; g.g_x = Ks; g.g_w = Ks; g.g_b = 0; g.g_y = (long long)M * w.N;
+            ck(launch_igemm(g, wd, s), "linear igemm (split-K)");
+            ck(launch_splitk_reduce(part, w.bias, y, wd, S, M, w.N, ldy, act, out_f32 ? 1 : 0, s), "split-K reduce");
+            return;
+        }
+        ck(launch_igemm(g, wd, s), "linear igemm");
     }
     void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu) {
         float* stats = alloc_f(gn_stats_floats(B, HW, G));

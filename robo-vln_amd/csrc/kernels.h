@@ -94,6 +94,9 @@ hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* 
 // GRU cell from gi, gh [B][3H] (r,z,n); h = h_in[0]*mask; writes h_out (1,B,H)
 hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, const float* mask, float* h_out,
                            int B, int Hd, const Heads& heads, hipStream_t s);
+// split-K: fixed-order sum of S f32 partial results [S][M][N] + bias + activation (see Fwd::linear)
+hipError_t launch_splitk_reduce(const float* part, const float* bias, void* y, int dt, int S, int M, int N, int ldy, int act, int out_f32,
+                                hipStream_t s);
 // CMANet (models/cma.py) pieces: instruction embedding + lengths, one packed-LSTM time step, single-query attention
 hipError_t launch_instr_embed(const void* ids, int ids_dt, const float* table, float* x, int* lengths, int B, int L, int E, int ldx,
                               int vocab, hipStream_t s);
