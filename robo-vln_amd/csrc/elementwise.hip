@@ -26,14 +26,13 @@ static inline int grid_for(size_t n, int block = 256, int cap = 256 * 16) {
 // ------------------------------------------------------------------------------------------ packed RGB frame (stem)
 // see kernels.h: launch_pack_frame.  One thread per packed pixel (8-byte store).
 template <typename S, typename T>
-__global__ void pack_frame_kernel(const S* __restrict__ x, T* __restrict__ y, int B, int H, int W, float scale) {
-    const int Hp = H + 6, Wp = W + 8;
+__global__ void pack_frame_kernel(const S* __restrict__ x, T* __restrict__ y, int B, int H, int W, float scale, int bt, int Hp, int Wp) {
     const size_t total = (size_t)B * Hp * Wp;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int px = (int)(e % Wp);
         const int py = (int)((e / Wp) % Hp);
         const int b = (int)(e / ((size_t)Wp * Hp));
-        const int ix = px - 3, iy = py - 3;
+        const int ix = px - bt, iy = py - bt;            // bt: border on the top and left
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
         if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
             const S* p = x + ((size_t)(b * H + iy) * W + ix) * 3;
@@ -44,15 +43,16 @@ __global__ void pack_frame_kernel(const S* __restrict__ x, T* __restrict__ y, in
         *reinterpret_cast<uint2*>(y + e * 4) = *reinterpret_cast<const uint2*>(o);
     }
 }
-hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, int H, int W, float scale, hipStream_t s) {
+hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, int H, int W, float scale, hipStream_t s, int border) {
     if ((W & 1) || (dt != DT_BF16 && dt != DT_F16)) return hipErrorInvalidValue;
-    const size_t total = (size_t)B * (H + 6) * (W + 8);
+    const int bt = border ? 3 : 0, Hp = border ? H + 6 : H, Wp = border ? W + 8 : W;
+    const size_t total = (size_t)B * Hp * Wp;
     if (src_dt == DT_F32) {
-        if (dt == DT_BF16) hipLaunchKernelGGL((pack_frame_kernel<float, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (bf16*)y, B, H, W, scale);
-        else hipLaunchKernelGGL((pack_frame_kernel<float, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (f16*)y, B, H, W, scale);
+        if (dt == DT_BF16) hipLaunchKernelGGL((pack_frame_kernel<float, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (bf16*)y, B, H, W, scale, bt, Hp, Wp);
+        else hipLaunchKernelGGL((pack_frame_kernel<float, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (f16*)y, B, H, W, scale, bt, Hp, Wp);
     } else if (src_dt == DT_U8) {
-        if (dt == DT_BF16) hipLaunchKernelGGL((pack_frame_kernel<uint8_t, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)x, (bf16*)y, B, H, W, scale);
-        else hipLaunchKernelGGL((pack_frame_kernel<uint8_t, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)x, (f16*)y, B, H, W, scale);
+        if (dt == DT_BF16) hipLaunchKernelGGL((pack_frame_kernel<uint8_t, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)x, (bf16*)y, B, H, W, scale, bt, Hp, Wp);
+        else hipLaunchKernelGGL((pack_frame_kernel<uint8_t, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)x, (f16*)y, B, H, W, scale, bt, Hp, Wp);
     } else {
         return hipErrorInvalidValue;
     }

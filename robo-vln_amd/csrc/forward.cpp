@@ -236,7 +236,26 @@ struct Fwd {
         const int H = w.hw;
         const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
         void* y0 = alloc_t((size_t)B * h1 * h1 * 32);
-        stem_conv(w.c0, Stem{x, x_dt, scale, H, H, w.cin}, B, 8, 4, 0, y0, h1, h1, ACT_RELU);
+        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        if (w.c0_packed.w && !no_pack && (x_dt == DT_F32 || x_dt == DT_U8) && (w.cin == 3 || x_dt == DT_F32)) {
+            // 16-bit path: convert / pack the frame once ([B][H][W][cp], cp = 4 for RGB, 1 for depth); a kernel row of an output
+            // pixel is then one contiguous run of 8 pixels and the conv an ordinary LDS-DMA implicit GEMM over "virtual
+            // pixels" of 4 real ones (the stride): KH = 8, KW = 1, Cin = 8*cp, pixel stride 4*cp elements
+            const int cp = w.cin == 3 ? 4 : 1;
+            void* pk = alloc_t((size_t)B * H * H * cp + 64);
+            if (!dry) {
+                if (cp == 4) ck(launch_pack_frame(x, x_dt, pk, dt, B, H, H, scale, s, 0), "pack frame");
+                else ck(launch_convert_from_f32((const float*)x, pk, dt, (size_t)B * H * H, s), "depth convert");
+                IGemm g;
+                g.x = pk; g.w = w.c0_packed.w; g.bias = w.c0_packed.bias; g.y = y0;
+                g.B = B; g.H = H; g.W = H / 4; g.Cin = 8 * cp; g.xC = 4 * cp;
+                g.Ho = h1; g.Wo = h1; g.KH = 8; g.KW = 1; g.stride = 4; g.stride_w = 1; g.pad = 0;
+                g.M = B * h1 * h1; g.N = 32; g.K = w.c0_packed.K; g.Kp = w.c0_packed.Kp; g.ldy = 32; g.ldr = 32; g.act = ACT_RELU;
+                ck(launch_igemm(g, dt, s), "simple cnn conv0 (packed)");
+            }
+        } else {
+            stem_conv(w.c0, Stem{x, x_dt, scale, H, H, w.cin}, B, 8, 4, 0, y0, h1, h1, ACT_RELU);
+        }
         void* y1 = alloc_t((size_t)B * h2 * h2 * 64);
         conv(w.c1, Act{y0, B, h1, h1, 32}, y1, 2, 0, nullptr, ACT_RELU, h2, h2);
         void* y2 = alloc_t((size_t)B * h3 * h3 * 32);

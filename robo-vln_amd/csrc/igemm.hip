@@ -1258,7 +1258,9 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         d.x_bytes = (unsigned)xb;
         d.w_bytes = (unsigned)wb;
     }
-    if ((g.Cin % CH) || (d.xC % CH) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
+    // pixel stride: a multiple of the 16-byte chunk, or (LDS-DMA variants only: dword-aligned source addresses suffice) of 4 bytes
+    const bool narrow_stride = (d.xC % CH) != 0;
+    if ((g.Cin % CH) || (narrow_stride && (d.xC * (int)dt_size(dt)) % 4) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
         return hipErrorInvalidValue;
     if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
     if (d.gn_cg) {
@@ -1269,7 +1271,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         return launch_dt(d, dt, ((d.K >= 768 && dt != DT_F32) ? 7 : 4) * 6 + 5, s);
     }
     static const char* force = getenv("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
-    if (force) return launch_dt(d, dt, atoi(force), s);
+    if (force && !(narrow_stride && (atoi(force) / 6 == 0 || atoi(force) / 6 == 3))) return launch_dt(d, dt, atoi(force), s);
     const std::string key = shape_key(d, dt);
     int choice = -1;
     {

@@ -53,7 +53,9 @@ hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEM
 // 8 px x 4 ch = 32 elements (7 real taps + 1 whose weights are zero), so the stem becomes an ordinary LDS-DMA implicit
 // GEMM over "virtual pixels" of 8 elements: H' = H+6, W' = (W+8)/2, xC = 8, Cin = 32, KH = 7, KW = 1, stride 2 down /
 // 1 across, pad 0, K = 7*32 -- no element-wise gather, no conversion in the GEMM, no bounds cases.
-hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, int H, int W, float scale, hipStream_t s);
+hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, int H, int W, float scale, hipStream_t s, int border = 1);
+// border = 0: plain [B][H][W][4] packing (SimpleCNN's un-padded 8x8/4 first conv: a kernel row is 8 px x 4 ch = 32 elements,
+// a "virtual pixel" of the GEMM the 4-pixel stride = 16 elements)
 inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);

@@ -55,6 +55,7 @@ struct TrunkW {
 };
 struct SimpleCnnW {
     ConvW c0, c1, c2;          // 8x8/4 (narrow-channel gather), 4x4/2, 3x3/1
+    ConvW c0_packed;           // 16-bit path: k = kh*KR + kw*cp + ci with cp = 4 (RGB, KR = 32) or 1 (depth, KR = 8)
     LinW fc;
     int cin = 1, hw = 0, h3 = 0;
 };

@@ -560,6 +560,22 @@ static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model,
     SimpleCnnW s;
     s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
     s.c0 = make_conv(dt, up, T_(ctx, model, pre + "cnn.0.weight"), nullptr, &T_(ctx, model, pre + "cnn.0.bias").f);
+    if (dt != DT_F32 && (cin == 1 || cin == 3) && hw % 4 == 0) {
+        // packed-frame layout of the 8x8/4 conv (forward.cpp simple_cnn): a kernel row is one contiguous run of 8 pixels
+        const HostTensor& w0 = T_(ctx, model, pre + "cnn.0.weight");       // (32, cin, 8, 8)
+        const int cp = cin == 3 ? 4 : 1, KR = 8 * cp;
+        ConvW c;
+        c.dt = dt; c.Cout = (int)w0.shape[0]; c.Cin = cin; c.KH = 8; c.KW = 8; c.K = 8 * KR; c.Kp = c.K;
+        std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
+        for (int o = 0; o < c.Cout; ++o)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int kh = 0; kh < 8; ++kh)
+                    for (int kw = 0; kw < 8; ++kw)
+                        r[(size_t)o * c.Kp + kh * KR + kw * cp + ci] = w0.f[(((size_t)o * cin + ci) * 8 + kh) * 8 + kw];
+        c.w = up.typed(r, dt);
+        c.bias = up.f32(T_(ctx, model, pre + "cnn.0.bias").f);
+        s.c0_packed = c;
+    }
     s.c1 = make_conv(dt, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
     s.c2 = make_conv(dt, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
     // Flatten() of the NCHW (B,32,h,w) tensor: source column c*S + s; ours is NHWC: s*32 + c
