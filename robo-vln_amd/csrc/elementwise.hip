@@ -75,6 +75,32 @@ __global__ void avgpool2_kernel(const float* __restrict__ x, T* __restrict__ y, 
         Tr<T>::st(y + e, ((r0.x + r0.y) + (r1.x + r1.y)) * 0.25f);
     }
 }
+// same, written into a zero-bordered frame [B][H/2 + 6][W/2 + 8] (3 px border left / top, 5 right, 3 bottom): the packed input
+// of the depth trunk's 7x7/2 stem (kernels.h: launch_pack_frame describes the RGB counterpart)
+template <typename T>
+__global__ void avgpool2_padded_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, Hp = Ho + 6, Wp = Wo + 8;
+    const size_t total = (size_t)B * Hp * Wp;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(e % Wp) - 3;
+        const int py = (int)((e / Wp) % Hp) - 3;
+        const int b = (int)(e / ((size_t)Wp * Hp));
+        float v = 0.f;
+        if ((unsigned)px < (unsigned)Wo && (unsigned)py < (unsigned)Ho) {
+            const float* p = x + ((size_t)(b * H + 2 * py) * W + 2 * px);
+            const float2 r0 = *reinterpret_cast<const float2*>(p);
+            const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+            v = ((r0.x + r0.y) + (r1.x + r1.y)) * 0.25f;
+        }
+        Tr<T>::st(y + e, v);
+    }
+}
+hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)B * (H / 2 + 6) * (W / 2 + 8);
+    if ((W & 3) || (dt != DT_BF16 && dt != DT_F16)) return hipErrorInvalidValue;
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(avgpool2_padded_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, (T*)y, B, H, W));
+    return hipGetLastError();
+}
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s) {
     const size_t total = (size_t)B * (H / 2) * (W / 2);
     if (W & 1) return hipErrorInvalidValue;

@@ -172,7 +172,19 @@ struct Fwd {
         const bool packed = !t.gn && !no_pack && t.conv1_packed.w != nullptr && st.Cin == 3 && !(st.W & 1) && !(st.H & 1) &&
                             (st.x_dt == DT_F32 || st.x_dt == DT_U8);
         const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
-        if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
+        if (t.gn && st.x_dt == -2) {
+            // depth stem on the packed 1-channel frame: kernel row = 8 contiguous elements (7 taps + a zero-weight slot), the GEMM's
+            // "virtual pixel" = the stride of 2 elements
+            if (!dry) {
+                const ConvW& w = t.conv1_packed;
+                IGemm g;
+                g.x = st.x; g.w = w.w; g.bias = nullptr; g.y = slot[0];
+                g.B = B; g.H = st.H + 6; g.W = (st.W + 8) / 2; g.Cin = 8; g.xC = 2;
+                g.Ho = Ho; g.Wo = Wo; g.KH = 7; g.KW = 1; g.stride = 2; g.stride_w = 1; g.pad = 0;
+                g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = ACT_NONE;
+                ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
+            }
+        } else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
         if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
         tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
@@ -225,9 +237,16 @@ struct Fwd {
     }
     Act depth_trunk(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
         const int H = ctx->cfg.depth_h / 2, W = ctx->cfg.depth_w / 2;
+        const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        if (t.conv1_packed.w && !no_pack && !(W & 1) && !(H & 1)) {
+            // 16-bit trunks: avg_pool2d(2) writes straight into the zero-bordered frame of the packed stem
+            void* pk = alloc_t((size_t)B * (H + 6) * (W + 8) + 64);
+            if (!dry) ck(launch_avgpool2_f32_padded(depth, pk, dt, B, ctx->cfg.depth_h, ctx->cfg.depth_w, s), "avgpool2 (padded)");
+            return trunk(t, Stem{pk, -2, 1.0f, H, W, 1}, B, Ho, Wo, tapname);       // x_dt = -2: already packed
+        }
         void* pooled = alloc_t((size_t)B * H * W);
         if (!dry) ck(launch_avgpool2_f32(depth, pooled, dt, B, ctx->cfg.depth_h, ctx->cfg.depth_w, s), "avgpool2");
-        const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
         return trunk(t, Stem{pooled, dt, 1.0f, H, W, 1}, B, Ho, Wo, tapname);
     }
 

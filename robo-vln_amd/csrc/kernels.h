@@ -58,6 +58,7 @@ hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, 
 // a "virtual pixel" of the GEMM the 4-pixel stride = 16 elements)
 inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
+hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);   // -> [B][H/2+6][W/2+8]
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel
 hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s,

@@ -373,6 +373,22 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     return t;
 }
 
+// 7x7 stem of the 1-channel depth trunk for the packed-frame path: k = kh*8 + kw (slot kw = 7 is zero), K = 56, Kp = 64;
+// the rows of several models are concatenated along Cout (hi|lo pair: shared frame)
+static ConvW make_depth_stem_packed(int dt, Uploader& up, const std::vector<const HostTensor*>& ws) {
+    ConvW c;
+    c.dt = dt;
+    const int Co = (int)ws[0]->shape[0];
+    c.Cout = Co * (int)ws.size(); c.Cin = 1; c.KH = 7; c.KW = 7; c.K = 56; c.Kp = 64;
+    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
+    for (size_t g = 0; g < ws.size(); ++g)
+        for (int o = 0; o < Co; ++o)
+            for (int kh = 0; kh < 7; ++kh)
+                for (int kw = 0; kw < 7; ++kw) r[((size_t)g * Co + o) * c.Kp + kh * 8 + kw] = ws[g]->f[((size_t)o * 7 + kh) * 7 + kw];
+    c.w = up.typed(r, dt);
+    return c;
+}
+
 static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
     const int dt = ctx->dt_depth;
@@ -381,6 +397,7 @@ static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     t.cin1 = 1;
     const std::string bb = pre + "backbone.";
     t.conv1 = make_conv(dt, up, T_(ctx, model, bb + "conv1.0.weight"), nullptr, nullptr);
+    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, model, bb + "conv1.0.weight")});
     t.n_conv1 = make_norm(ctx, up, model, bb + "conv1.1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
@@ -446,6 +463,7 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     auto W2 = [&](const std::string& k, bool cat) { return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat); };
     const std::string bb = pre + "backbone.";
     t.conv1 = W2(bb + "conv1.0.weight", true);
+    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, HCM_HIGH, bb + "conv1.0.weight"), &T_(ctx, HCM_LOW, bb + "conv1.0.weight")});
     t.n_conv1 = make_norm_pair(ctx, up, bb + "conv1.1");
     for (int li = 0; li < 4; ++li)
         for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
