@@ -790,6 +790,103 @@ hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, f
     return hipGetLastError();
 }
 
+// The whole packed (bi)LSTM scan in ONE launch: a workgroup owns SB samples of one direction for all L steps, thread j owns
+// hidden unit j (blockDim.x == H).  h lives in LDS (double-buffered, broadcast reads), c in registers; W_hh is read
+// transposed ([k][4H], so the 4 gate weights of unit j for input k are coalesced across threads) from L2 every step --
+// 4*H*H*4 bytes per step and workgroup, which bounds the step at a few microseconds instead of two launches.
+struct LstmScanArgs {
+    const float* pre[2];       // per direction: x_t W_ih^T + b_ih + b_hh for every token, [B*L][4H]
+    const float* wt[2];        // per direction: W_hh transposed, [H][4H]
+};
+// 1024 threads = 256 hidden units x 4 quarters of the k range: each thread streams a quarter of its unit's recurrent weights
+// (64 k x 4 gates, several loads in flight) for SB samples; the four partial sums per (gate, sample, unit) meet in LDS.
+template <int SB>
+__global__ __launch_bounds__(1024) void instr_lstm_scan_kernel(LstmScanArgs a, const int* __restrict__ lengths, float* __restrict__ out,
+                                                                int B, int L, int H, int ld_out) {
+    extern __shared__ float sm[];          // h [2][SB][H], partials [3][4][SB][H]
+    float* hs = sm;
+    float* ps = sm + 2 * SB * H;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * SB;
+    const int j = threadIdx.x & 255, kq = threadIdx.x >> 8;
+    const int KQ = H / 4;
+    const float* __restrict__ pre = a.pre[dir];
+    const float* __restrict__ wt = a.wt[dir] + (size_t)kq * KQ * 4 * H + j;
+    float c[SB];
+#pragma unroll
+    for (int s_ = 0; s_ < SB; ++s_) c[s_] = 0.f;
+    for (int i = threadIdx.x; i < 2 * SB * H; i += 1024) hs[i] = 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step < L; ++step) {
+        const int t = dir ? L - 1 - step : step;
+        float acc[4][SB];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s_ = 0; s_ < SB; ++s_) acc[g][s_] = 0.f;
+        const float* hc = hs + cur * SB * H + kq * KQ;
+#pragma unroll 8
+        for (int k = 0; k < KQ; ++k) {
+            const float* wr = wt + (size_t)k * 4 * H;
+            const float w0 = wr[0], w1 = wr[H], w2 = wr[2 * H], w3 = wr[3 * H];
+#pragma unroll
+            for (int s_ = 0; s_ < SB; ++s_) {
+                const float hk = hc[s_ * H + k];
+                acc[0][s_] += w0 * hk; acc[1][s_] += w1 * hk; acc[2][s_] += w2 * hk; acc[3][s_] += w3 * hk;
+            }
+        }
+        if (kq > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int s_ = 0; s_ < SB; ++s_) ps[(((kq - 1) * 4 + g) * SB + s_) * H + j] = acc[g][s_];
+        }
+        __syncthreads();
+        float* hn = hs + (cur ^ 1) * SB * H;
+        if (kq == 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < SB; ++s_) {
+                const int b = b0 + s_;
+                const bool valid = b < B;
+                const bool act = valid && t < lengths[valid ? b : 0];
+                float hv = hs[cur * SB * H + s_ * H + j], o = 0.f;
+                if (act) {
+                    const float* p = pre + ((size_t)b * L + t) * 4 * H + j;
+                    float gsum[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        gsum[g] = p[g * H] + ((acc[g][s_] + ps[((0 * 4 + g) * SB + s_) * H + j]) + (ps[((1 * 4 + g) * SB + s_) * H + j] + ps[((2 * 4 + g) * SB + s_) * H + j]));
+                    const float gi = sigmoidf_(gsum[0]), gf = sigmoidf_(gsum[1]), gg = tanhf(gsum[2]), go = sigmoidf_(gsum[3]);
+                    c[s_] = gf * c[s_] + gi * gg;
+                    hv = go * tanhf(c[s_]);
+                    o = hv;
+                }
+                hn[s_ * H + j] = hv;
+                if (valid) out[((size_t)b * L + t) * ld_out + dir * H + j] = o;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+hipError_t launch_instr_lstm_scan(const float* pre0, const float* pre1, const float* wt0, const float* wt1, const int* lengths, float* out,
+                                  int B, int L, int H, int dirs, int ld_out, hipStream_t s) {
+    if (H != 256) return hipErrorInvalidValue;          // 256 hidden units x 4 k-quarters = 1024 threads
+    constexpr int SB = 8;
+    LstmScanArgs a;
+    a.pre[0] = pre0; a.pre[1] = pre1; a.wt[0] = wt0; a.wt[1] = wt1;
+    const size_t lds = (size_t)(2 * SB * H + 3 * 4 * SB * H) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(instr_lstm_scan_kernel<SB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(instr_lstm_scan_kernel<SB>, dim3((B + SB - 1) / SB, dirs), dim3(1024), lds, s, a, lengths, out, B, L, H, ld_out);
+    return hipGetLastError();
+}
+
 // CMANet._attn (models/cma.py:201-209): ONE query per sample over S positions:
 //   logits[s] = q . k[s];  logits -= 1e8 where masked (s >= len_b when lengths != null);  p = softmax(logits * scale);
 //   out = sum_s p[s] v[s].   q [B][D] (ldq), k [B][S][.] (ldk), v [B][S][.] (ldv), out [B][.] (ldo); all f32.

@@ -693,16 +693,22 @@ struct Fwd {
             const int ldx = w.ih[0].Kp;
             float* x = alloc_f((size_t)B * L * ldx);
             if (!dry) ck(launch_instr_embed(ids, ids_dt, w.emb, x, ctx->len_buf, B, L, E, ldx, m.vocab_size, s), "instr embed");
-            float* pre = alloc_f((size_t)B * L * 4 * Hi);
+            float* pre[2] = {alloc_f((size_t)B * L * 4 * Hi), w.dirs > 1 ? alloc_f((size_t)B * L * 4 * Hi) : nullptr};
             float* gh = alloc_f((size_t)B * 4 * Hi);
             float* hc = alloc_f((size_t)2 * B * Hi);
-            for (int d = 0; d < w.dirs; ++d) {
-                linear(w.ih[d], x, B * L, ldx, pre, 4 * Hi, ACT_NONE, true);
-                if (!dry) ck(hipMemsetAsync(hc, 0, (size_t)2 * B * Hi * 4, s), "lstm state reset");
-                for (int k = 0; k < L; ++k) {
-                    const int t = d == 0 ? k : L - 1 - k;
-                    linear(w.hh[d], hc, B, Hi, gh, 4 * Hi, ACT_NONE, true);
-                    if (!dry) ck(launch_instr_lstm_cell(pre, gh, hc, hc + (size_t)B * Hi, ctx->len_buf, ins, t, B, L, Hi, C, d * Hi, s), "instr lstm cell");
+            for (int d = 0; d < w.dirs; ++d) linear(w.ih[d], x, B * L, ldx, pre[d], 4 * Hi, ACT_NONE, true);
+            static const bool no_scan = getenv("HCM_NO_LSTM_SCAN") != nullptr;
+            if (Hi == 256 && !no_scan) {
+                // both directions, all L steps: one launch
+                if (!dry) ck(launch_instr_lstm_scan(pre[0], pre[1], w.hh_t[0], w.hh_t[1], ctx->len_buf, ins, B, L, Hi, w.dirs, C, s), "instr lstm scan");
+            } else {
+                for (int d = 0; d < w.dirs; ++d) {
+                    if (!dry) ck(hipMemsetAsync(hc, 0, (size_t)2 * B * Hi * 4, s), "lstm state reset");
+                    for (int k = 0; k < L; ++k) {
+                        const int t = d == 0 ? k : L - 1 - k;
+                        linear(w.hh[d], hc, B, Hi, gh, 4 * Hi, ACT_NONE, true);
+                        if (!dry) ck(launch_instr_lstm_cell(pre[d], gh, hc, hc + (size_t)B * Hi, ctx->len_buf, ins, t, B, L, Hi, C, d * Hi, s), "instr lstm cell");
+                    }
                 }
             }
             tap("cma.instruction", ins, false, {B, L, C});

@@ -105,6 +105,9 @@ hipError_t launch_instr_embed(const void* ids, int ids_dt, const float* table, f
                               int vocab, hipStream_t s);
 hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, float* c, const int* lengths, float* out, int t, int B,
                                   int L, int Hd, int ld_out, int col0, hipStream_t s);
+// all L steps of both directions in one launch (H == 256): wt = W_hh transposed [H][4H]
+hipError_t launch_instr_lstm_scan(const float* pre0, const float* pre1, const float* wt0, const float* wt1, const int* lengths, float* out,
+                                  int B, int L, int H, int dirs, int ld_out, hipStream_t s);
 hipError_t launch_attn1q(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int* lengths, float* out,
                          int ldo, int B, int S, int D, int Dv, float scale, hipStream_t s);
 // pred[b] = argmax_j logits[b*ld + j] (first max), int64

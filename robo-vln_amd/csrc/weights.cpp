@@ -798,6 +798,14 @@ void prepare_cma(hcm_ctx* ctx) {
         w.ih[d] = make_linear(up, {&T_(ctx, M, p + "weight_ih_l0" + sfx)}, {&b}, DT_F32);
         w.ih[d].K = w.ih[d].Kp;          // the embedded tokens are stored zero-padded to Kp columns (E = 50 is not a vector multiple)
         w.hh[d] = make_linear(up, {&T_(ctx, M, p + "weight_hh_l0" + sfx)}, {}, DT_F32);
+        {
+            const HostTensor& whh = T_(ctx, M, p + "weight_hh_l0" + sfx);       // (4H, H)
+            const int H4 = (int)whh.shape[0], H = (int)whh.shape[1];
+            std::vector<float> t((size_t)H * H4);
+            for (int n = 0; n < H4; ++n)
+                for (int k = 0; k < H; ++k) t[(size_t)k * H4 + n] = whh.f[(size_t)n * H + k];
+            w.hh_t[d] = up.f32(t);
+        }
     }
     w.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
     {
