@@ -36,7 +36,12 @@ def _to_struct(cfg: CMAConfig, max_batch, precision):
 class CMAEngine:
     """Owns one libhcm CMANet handle (weights + workspace) on one GPU."""
 
-    def __init__(self, cfg: CMAConfig, state_dict, max_batch=64, precision="bf16", device=None):
+    def __init__(self, cfg: CMAConfig, state_dict, max_batch=64, precision="bf16", device=None, graph=False):
+        """graph=True: forward() runs on an engine-owned stream with engine-owned static I/O buffers so that libhcm replays one
+        captured hipGraph per step; the returned tensors then alias those buffers and stay valid until the second-next call."""
+        self._graph = bool(graph)
+        self._gstream = None
+        self._static = None
         cfg.validate()
         self.cfg = cfg
         self.max_batch = max_batch
@@ -103,6 +108,8 @@ class CMAEngine:
             if tuple(h_in.shape) != (R, B, c.hidden):
                 raise ValueError(f"rnn_hidden_states must be ({R},{B},{c.hidden}), got {tuple(h_in.shape)}")
             m = self._dev(masks, (torch.float32,)).reshape(B, -1)[:, 0].contiguous()   # masks[:,0] (cma.py:219)
+            if self._graph:
+                return self._forward_graph(rgb, depth, ids, h_in, m, B)
             out = torch.empty(B, c.num_actions, device=self.device, dtype=torch.float32)
             stop = torch.empty(B, 1, device=self.device, dtype=torch.float32)
             h_out = torch.empty_like(h_in)
@@ -111,6 +118,32 @@ class CMAEngine:
                                                  _TORCH_DT[ids.dtype], B, h_in.data_ptr(), m.data_ptr(), out.data_ptr(),
                                                  stop.data_ptr(), h_out.data_ptr(), st), self._h)
         return out, stop, h_out
+
+    def _forward_graph(self, rgb, depth, ids, h_in, m, B):
+        c = self.cfg
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        st = self._static
+        if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype:
+            st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth), "ids": torch.empty_like(ids),
+                  "mask": torch.empty_like(m), "h": [torch.zeros_like(h_in) for _ in range(2)],
+                  "out": [torch.empty(B, c.num_actions, device=self.device) for _ in range(2)],
+                  "stop": [torch.empty(B, 1, device=self.device) for _ in range(2)]}
+            self._static = st
+        cur, gs = torch.cuda.current_stream(), self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            i = st["tick"] & 1
+            for dst, src in ((st["rgb"], rgb), (st["depth"], depth), (st["ids"], ids), (st["mask"], m), (st["h"][1 - i], h_in)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            _lib.check(self._lib.hcm_cma_forward(self._h, st["rgb"].data_ptr(), _TORCH_DT[rgb.dtype], st["depth"].data_ptr(),
+                                                 st["ids"].data_ptr(), _TORCH_DT[ids.dtype], B, st["h"][1 - i].data_ptr(),
+                                                 st["mask"].data_ptr(), st["out"][i].data_ptr(), st["stop"][i].data_ptr(),
+                                                 st["h"][i].data_ptr(), C.c_void_p(gs.cuda_stream)), self._h)
+            st["tick"] += 1
+        cur.wait_stream(gs)
+        return st["out"][i], st["stop"][i], st["h"][i]
 
     # debug taps (tests)
     def enable_taps(self, on=True):

@@ -31,6 +31,56 @@ static int fail(hcm_ctx* h, int code, const std::string& msg) {
 
 #define REQUIRE(cond, code, msg) do { if (!(cond)) return fail(h, code, msg); } while (0)
 
+// hipGraph cache shared by the fused entry points: `key` = every argument that the enqueued work depends on (batch, dtypes,
+// all pointers, the stream); `run` enqueues the work on h->stream.  A key is run eagerly the first time it is seen (that also
+// performs the one-time kernel attribute setup) and captured -- forked side streams included -- the second time; later
+// calls replay the instantiated graph.
+template <typename F>
+static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* stream, F run) {
+    auto eager = [&]() -> int {
+        try { run(); } catch (const std::exception& e) { return fail(h, HCM_ERR_HIP, e.what()); }
+        ++h->eager_launches;
+        return HCM_OK;
+    };
+    // the legacy default stream cannot be captured; taps allocate and synchronise
+    if (!h->use_graph || h->taps_on || stream == nullptr) return eager();
+    for (auto& g : h->graphs)
+        if (g.key == key) {
+            if (hipGraphLaunch(g.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
+            ++h->graph_launches;
+            return HCM_OK;
+        }
+    bool seen = false;
+    for (auto& k : h->seen_keys) seen = seen || k == key;
+    if (!seen) {
+        if (h->seen_keys.size() >= 16) h->seen_keys.erase(h->seen_keys.begin());
+        h->seen_keys.push_back(key);
+        return eager();
+    }
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(); }
+    std::string cap_err;
+    try { run(); } catch (const std::exception& e) { cap_err = e.what(); }
+    hipGraph_t graph = nullptr;
+    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (!cap_err.empty() || ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        h->use_graph = false;                      // do not retry on this handle
+        if (!cap_err.empty()) return fail(h, HCM_ERR_HIP, "graph capture failed: " + cap_err);
+        return eager();
+    }
+    hcm_ctx::GraphEntry ge;
+    ge.key = key;
+    ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ce != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return eager(); }
+    if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+    h->graphs.push_back(ge);
+    if (hipGraphLaunch(ge.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
+    ++h->graph_launches;
+    return HCM_OK;
+}
+
 extern "C" {
 
 int hcm_create(const hcm_config* cfg, hcm_handle* out) {
@@ -134,7 +184,6 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
     h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
     if (h->dt == DT_BF16) h->dt_depth = DT_F16;  // GroupNorm depth trunk on fp16 tiles
-    h->use_graph = false;
     try {
         build_spec_cma(h);
     } catch (const std::exception& e) {
@@ -320,12 +369,9 @@ int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
     REQUIRE(rgb && depth && ids && h_in && mask && out && stop && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     h->stream = (hipStream_t)stream;
-    try {
-        run_cma(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, out, stop, h_out);
-    } catch (const std::exception& e) {
-        return fail(h, HCM_ERR_HIP, e.what());
-    }
-    return HCM_OK;
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
+                                       (uint64_t)h_in, (uint64_t)mask, (uint64_t)out, (uint64_t)stop, (uint64_t)h_out, (uint64_t)stream};
+    return run_graphed(h, key, stream, [&]() { run_cma(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, out, stop, h_out); });
 }
 
 int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int T, int N,
@@ -377,60 +423,13 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, co
     REQUIRE(h->cfg.num_actions + h->cfg.lo_actions + 1 == 7, HCM_ERR_UNSUPPORTED, "record layout assumes 4 + 2 + 1 outputs");
     h->stream = (hipStream_t)stream;
     const int ld = 7;
-    auto eager = [&]() -> int {
-        try {
-            run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
-                     record + 6, ld, hi_h_out, lo_h_out);
-        } catch (const std::exception& e) {
-            return fail(h, HCM_ERR_HIP, e.what());
-        }
-        ++h->eager_launches;
-        return HCM_OK;
-    };
-    // the legacy default stream cannot be captured; taps allocate and synchronise
-    if (!h->use_graph || h->taps_on || stream == nullptr) return eager();
     const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
                                        (uint64_t)hi_h_in, (uint64_t)lo_h_in, (uint64_t)mask, (uint64_t)record, (uint64_t)hi_h_out,
                                        (uint64_t)lo_h_out, (uint64_t)stream};
-    for (auto& g : h->graphs)
-        if (g.key == key) {
-            if (hipGraphLaunch(g.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
-            ++h->graph_launches;
-            return HCM_OK;
-        }
-    bool seen = false;
-    for (auto& k : h->seen_keys) seen = seen || k == key;
-    if (!seen) {                                   // first sight: eager (also performs one-time kernel attribute setup)
-        if (h->seen_keys.size() >= 16) h->seen_keys.erase(h->seen_keys.begin());
-        h->seen_keys.push_back(key);
-        return eager();
-    }
-    // second sight: capture the whole step (the forked side streams join the capture through their events)
-    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(); }
-    std::string cap_err;
-    try {
+    return run_graphed(h, key, stream, [&]() {
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
-    } catch (const std::exception& e) { cap_err = e.what(); }
-    hipGraph_t graph = nullptr;
-    hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-    if (!cap_err.empty() || ce != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        h->use_graph = false;                      // do not retry on this handle
-        if (!cap_err.empty()) return fail(h, HCM_ERR_HIP, "graph capture failed: " + cap_err);
-        return eager();
-    }
-    hcm_ctx::GraphEntry ge;
-    ge.key = key;
-    ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ce != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return eager(); }
-    if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
-    h->graphs.push_back(ge);
-    if (hipGraphLaunch(ge.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
-    ++h->graph_launches;
-    return HCM_OK;
+    });
 }
 
 int hcm_query(hcm_handle h, int what, int64_t* out) {

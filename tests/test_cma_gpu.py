@@ -100,3 +100,23 @@ def test_cma_rejects_bad_input():
     obs = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_cma_observations(cfg, 2).items()}
     with pytest.raises(ValueError):
         eng.forward(obs, torch.zeros(1, 2, cfg.hidden), torch.zeros(2))       # GRU: R = 2 (two encoders), not 1
+
+
+def test_cma_hipgraph_replay_equals_eager():
+    """Engine graph mode (static I/O buffers, captured hipGraph replay) is bitwise equal to the eager calls."""
+    from robo_vln_amd.cma import CMAEngine
+    cfg, B, T = cases.cma_case_config("cma_128_L20")
+    sd = synth.make_cma_weights(cfg, cases.SEED)
+    eager = CMAEngine(cfg, sd, max_batch=B, precision="bf16")
+    graph = CMAEngine(cfg, sd, max_batch=B, precision="bf16", graph=True)
+    he = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda")
+    hg = he.clone()
+    for t in range(5):
+        obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_observations(cfg, B, step=t % 3, seed=cases.SEED).items()}
+        m = torch.from_numpy(cases.step_masks(B, t % 3)).cuda()
+        oe, se, he = eager.forward(obs, he, m)
+        og, sg, hg = graph.forward(obs, hg, m)
+        torch.cuda.synchronize()
+        assert torch.equal(oe, og) and torch.equal(se, sg) and torch.equal(he, hg)
+        hg = hg.clone()
+    assert graph.query(7) >= 3        # HCM_GRAPH_LAUNCHES: steps served by graph replay
