@@ -212,6 +212,10 @@ int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int
                      int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, void* stream);
 int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
                      void* y, int dtype, int rows, int D, float eps, void* stream);
+/* LayerNorm followed by the addition of a row table: y[r] = LN(x[r] (+ residual[r])) + post[r % post_rows]  (the positional
+ * encoding of Visual_Ling_Attn, transformer.py:265-269) */
+int hcm_op_layernorm_post(const void* x, const void* residual, const float* gamma, const float* beta, const float* post, int post_rows,
+                          void* y, int dtype, int rows, int D, float eps, void* stream);
 int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta,
                      int dtype, int B, int HW, int C, int groups, float eps, int relu, void* stream);
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);

@@ -570,6 +570,10 @@ int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, co
                      int D, float eps, void* stream) {
     return op_rc(launch_layernorm(x, residual, gamma, beta, nullptr, 0, y, op_dt(dtype), rows, D, eps, (hipStream_t)stream));
 }
+int hcm_op_layernorm_post(const void* x, const void* residual, const float* gamma, const float* beta, const float* post, int post_rows,
+                          void* y, int dtype, int rows, int D, float eps, void* stream) {
+    return op_rc(launch_layernorm(x, residual, gamma, beta, post, post_rows, y, op_dt(dtype), rows, D, eps, (hipStream_t)stream));
+}
 int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta, int dtype, int B, int HW, int C,
                      int groups, float eps, int relu, void* stream) {
     static float* scratch = nullptr;            // partial-sum scratch of the two-launch path, grown on demand (test entry point)

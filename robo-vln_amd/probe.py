@@ -1,0 +1,116 @@
+"""BASELINE.json configs[3] ("Depth-only SimpleCNN encoder + 1-layer transformer, batch=256: memory-bound path") as SURVEY 8a/8d
+define it: the reference cannot build its high-level model with SimpleCNN encoders, so the configuration is the composition
+of two reference classes used unchanged -- `SimpleDepthCNN(obs, 128)` (models/encoders/simple_cnns.py:104-125) -> one visual
+token (B,1,128) -> `Visual_Ling_Attn(N=1, vis_in_features=128)` (models/transformer/transformer.py:251-281) over a
+pre-computed instruction tensor (B,L,768).  This module runs that composition on the GPU through libhcm's operator entry
+points (every arithmetic step is a HIP kernel; torch only owns the buffers) -- a micro-benchmark and parity target, not part
+of the drop-in model API.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {"bf16": (_lib.HCM_BF16, torch.bfloat16), "fp16": (_lib.HCM_F16, torch.float16), "fp32": (_lib.HCM_F32, torch.float32)}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def sinusoid_table(L, d):
+    """common/utils.py:167-185."""
+    pos = np.arange(L, dtype=np.float32)[:, None]
+    i = np.arange(d // 2, dtype=np.float32)[None]
+    ang = pos / np.power(np.float32(10000.0), 2.0 * i / np.float32(d))
+    pe = np.zeros((L, d), np.float32)
+    pe[:, 0::2] = np.sin(ang)
+    pe[:, 1::2] = np.cos(ang)
+    return pe
+
+
+class DepthCnnVlaProbe:
+    """cnn_sd: SimpleDepthCNN state_dict (keys cnn.{0,2,4,7}.{weight,bias}); vla_sd: Visual_Ling_Attn state_dict (N = 1)."""
+
+    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="bf16", device="cuda"):
+        self.lib = _lib.lib()
+        self.code, self.tdt = _DT[precision]
+        self.dev = torch.device(device)
+        self.hw, self.L, self.heads = depth_hw, instr_len, heads
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+        W = lambda a: t(a).to(self.tdt).to(self.dev)
+        F32 = lambda a: t(a).to(self.dev)
+        g = lambda sd, k: np.asarray(sd[k], dtype=np.float32)
+        # SimpleCNN convs: OIHW -> OHWI rows (k = (kh, kw, ci)), K padded to 32 for the narrow-channel first conv
+        w0 = g(cnn_sd, "cnn.0.weight").transpose(0, 2, 3, 1).reshape(32, -1)
+        k0 = w0.shape[1]
+        w0p = np.zeros((32, (k0 + 31) // 32 * 32), np.float32)
+        w0p[:, :k0] = w0
+        self.c0, self.c0_k, self.c0_kp, self.b0 = W(w0p), k0, w0p.shape[1], F32(g(cnn_sd, "cnn.0.bias"))
+        self.c1, self.b1 = W(g(cnn_sd, "cnn.2.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.2.bias"))
+        self.c2, self.b2 = W(g(cnn_sd, "cnn.4.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.4.bias"))
+        h1 = (depth_hw - 8) // 4 + 1
+        h2 = (h1 - 4) // 2 + 1
+        h3 = h2 - 3 + 1
+        self.h1, self.h2, self.h3 = h1, h2, h3
+        fc = g(cnn_sd, "cnn.7.weight")                                  # (out, 32*h3*h3) over the NCHW flatten: column c*S + s
+        S = h3 * h3
+        self.fc = W(fc.reshape(-1, 32, S).transpose(0, 2, 1).reshape(fc.shape[0], S * 32))   # ours is NHWC: column s*32 + c
+        self.fcb = F32(g(cnn_sd, "cnn.7.bias"))
+        self.out_f = fc.shape[0]
+        d = g(vla_sd, "layer_norm.weight").shape[0]
+        self.d = d
+        lin = lambda p: (W(g(vla_sd, p + ".weight")), F32(g(vla_sd, p + ".bias")))
+        self.vis_fc, self.ins_fc = lin("vis_fc"), lin("ins_fc")
+        self.ln = (F32(g(vla_sd, "layer_norm.weight")), F32(g(vla_sd, "layer_norm.bias")))
+        a = "layers.0.enc_att.attention."
+        self.fq, self.fo = lin(a + "fc_q"), lin(a + "fc_o")
+        self.fkv = (W(np.concatenate([g(vla_sd, a + "fc_k.weight"), g(vla_sd, a + "fc_v.weight")], 0)),
+                    F32(np.concatenate([g(vla_sd, a + "fc_k.bias"), g(vla_sd, a + "fc_v.bias")], 0)))
+        self.ln_att = (F32(g(vla_sd, "layers.0.enc_att.layer_norm.weight")), F32(g(vla_sd, "layers.0.enc_att.layer_norm.bias")))
+        self.f1, self.f2 = lin("layers.0.pwff.fc1"), lin("layers.0.pwff.fc2")
+        self.ln_ff = (F32(g(vla_sd, "layers.0.pwff.layer_norm.weight")), F32(g(vla_sd, "layers.0.pwff.layer_norm.bias")))
+        self.pe = F32(sinusoid_table(instr_len, d))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libhcm operator failed: {rc}")
+
+    def _lin(self, x, wb, M, act=0, res=None):
+        w, b = wb
+        y = torch.empty(M, w.shape[0], device=self.dev, dtype=self.tdt)
+        self._ck(self.lib.hcm_op_linear(_p(x), _p(w), _p(b), _p(res), _p(y), self.code, M, w.shape[0], w.shape[1], act, 0, None))
+        return y
+
+    def _ln(self, x, gb, rows, post=None, post_rows=0):
+        y = torch.empty(rows, self.d, device=self.dev, dtype=self.tdt)
+        self._ck(self.lib.hcm_op_layernorm_post(_p(x), None, _p(gb[0]), _p(gb[1]), _p(post), post_rows, _p(y), self.code, rows, self.d, 1e-5, None))
+        return y
+
+    def forward(self, depth, ins):
+        """depth (B,H,W,1) f32 on the device, ins (B,L,768) in the storage type -> (B,L,d)."""
+        L_, lib, code = _lib, self.lib, self.code
+        B = depth.shape[0]
+        e = lambda *s: torch.empty(*s, device=self.dev, dtype=self.tdt)
+        y0 = e(B, self.h1, self.h1, 32)
+        self._ck(lib.hcm_op_stem_conv(_p(depth), L_.HCM_F32, _p(self.c0), _p(self.b0), _p(y0), code, B, self.hw, self.hw, 1, 32, 8, 8, 4, 0,
+                                      self.c0_k, self.c0_kp, 0, 1.0, L_.ACT_RELU, None))
+        y1 = e(B, self.h2, self.h2, 64)
+        self._ck(lib.hcm_op_conv2d(_p(y0), _p(self.c1), _p(self.b1), None, _p(y1), code, B, self.h1, self.h1, 32, 64, 4, 4, 2, 0, L_.ACT_RELU, None))
+        y2 = e(B, self.h3, self.h3, 32)
+        self._ck(lib.hcm_op_conv2d(_p(y1), _p(self.c2), _p(self.b2), None, _p(y2), code, B, self.h2, self.h2, 64, 32, 3, 3, 1, 0, L_.ACT_NONE, None))
+        tok = self._lin(y2, (self.fc, self.fcb), B, act=L_.ACT_RELU)                 # (B, 128): the one visual token
+        rows = B * self.L
+        V = self._ln(self._lin(tok, self.vis_fc, B, act=L_.ACT_RELU), self.ln, B)     # (B, 1, d)
+        I = self._ln(self._lin(ins.reshape(rows, -1), self.ins_fc, rows, act=L_.ACT_RELU), self.ln, rows, self.pe, self.L)
+        q = self._lin(I, self.fq, rows)
+        kv = self._lin(V, self.fkv, B)                                               # (B, 1, 2d)
+        att = e(rows, self.d)
+        esz = kv.element_size()
+        self._ck(lib.hcm_op_attention(_p(q), _p(kv), C.c_void_p(kv.data_ptr() + self.d * esz), _p(att), code, B, self.heads, self.L, 1,
+                                      self.d, 2 * self.d, 2 * self.d, self.d, None))
+        o = self._ln(self._lin(att, self.fo, rows, res=I), self.ln_att, rows)
+        f = self._lin(self._lin(o, self.f1, rows, act=L_.ACT_RELU), self.f2, rows, res=o)
+        return self._ln(f, self.ln_ff, rows).reshape(B, self.L, self.d)

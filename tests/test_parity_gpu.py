@@ -188,3 +188,34 @@ def test_odd_shapes_vs_oracle(kw, batch, precision):
         ref = torch.cat([logits, vel, stop], 1)
         assert (rec - ref).abs().max().item() <= TOL[precision], (t, (rec - ref).abs().max().item())
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+def test_config3_depthcnn_plus_vla_probe(precision):
+    """BASELINE.json configs[3] as SURVEY 8a/8d define it: SimpleDepthCNN(obs,128) -> one visual token -> Visual_Ling_Attn(N=1,
+    vis_in_features=128) over a pre-computed instruction tensor; per-component parity against the oracle restatements of
+    the two reference classes (simple_cnns.py:104-125, transformer.py:251-281)."""
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import HCMConfig
+    from robo_vln_amd.probe import DepthCnnVlaProbe
+    cfg = HCMConfig(vla_layers=1).validate()
+    B, L = 6, cfg.instr_len
+    cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, cfg.depth_hw, 128), "probe_cnn", 0)
+    vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
+    depth = synth.uniform01("probe/depth", B * 256 * 256, 0).reshape(B, 256, 256, 1)
+    ins = (synth.uniform01("probe/ins", B * L * 768, 0).reshape(B, L, 768) * 2 - 1).astype(np.float32)
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[precision]
+    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=precision)
+    out = probe.forward(torch.from_numpy(depth).cuda(), torch.from_numpy(ins).to(tdt).cuda())
+    torch.cuda.synchronize()
+    tok = hcm_oracle.simple_depth_cnn(torch.from_numpy(depth), hcm_oracle.Weights(cnn_sd))
+    ref = hcm_oracle.visual_ling_attn(torch.from_numpy(ins).to(tdt).float(), tok[:, None, :], hcm_oracle.Weights(vla_sd), 1, cfg.vla_heads)
+    # the output is the (B,L,256) LayerNorm'ed token tensor itself (|values| up to ~4), not a 7-float action record: 16-bit storage
+    # rounds each element to 2^-9 (fp16) / 2^-6 (bf16) at that magnitude, so the 16-bit paths are judged by relative l2 error
+    d = out.float().cpu() - ref
+    err, rel = d.abs().max().item(), (d.norm() / ref.norm()).item()
+    print(f"config3 probe [{precision}]: max-abs {err:.3e}, rel-l2 {rel:.3e}, |ref| max {ref.abs().max().item():.2f}")
+    assert out.shape == (B, L, 256)
+    assert (err <= 1e-3) if precision == "fp32" else (rel <= (2e-3 if precision == "fp16" else 1e-2)), (err, rel)
