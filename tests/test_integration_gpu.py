@@ -55,3 +55,37 @@ def test_checkpoint_stager_rollout_vs_oracle():
     sub, lin, ang, stop_flag = records_to_actions(recs[-1])
     assert sub.shape == (B,) and ang.abs().max().item() <= 1.0 and set(stop_flag.cpu().tolist()) <= {0.0, 1.0}
     eng.close()
+
+
+def test_c_abi_error_codes():
+    """The entry points return status codes instead of crashing: call-order violations, null pointers, wrong handle kind,
+    out-of-range batch (hcm.h: hcm_status)."""
+    import ctypes as C
+    from robo_vln_amd import _lib
+    from robo_vln_amd.policy import _to_struct
+    lib = _lib.lib()
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    st = _to_struct(cfg, 2, "bf16", True, True)
+    h = C.c_void_p()
+    assert lib.hcm_create(C.byref(st), C.byref(h)) == 0
+    d = torch.zeros(64, device="cuda")
+    p = C.c_void_p(d.data_ptr())
+    # forward before finalize -> HCM_ERR_STATE (-2)
+    assert lib.hcm_act(h, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -2
+    assert b"finalize" in lib.hcm_last_error(h)
+    # finalize with missing tensors -> HCM_ERR_KEY (-3), message names a key
+    assert lib.hcm_finalize(h) == -3 and b"Missing key" in lib.hcm_last_error(h)
+    lib.hcm_destroy(h)
+    # a finalized engine: null pointer / bad batch / wrong handle kind
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=0)
+    from robo_vln_amd.policy import HCMEngine
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=2, precision="bf16")
+    hh = eng._h
+    assert lib.hcm_act(hh, None, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -1          # null rgb
+    assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 3, p, p, p, p, p, p, None) == -1             # B > max_batch
+    assert lib.hcm_act(hh, p, _lib.HCM_BF16, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -1            # bad rgb dtype
+    assert lib.hcm_cma_forward(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, None) == -2        # not a CMANet handle
+    out = C.c_int64()
+    assert lib.hcm_query(hh, 99, C.byref(out)) == -1
+    assert lib.hcm_query(hh, _lib.HCM_RECORD_WIDTH, C.byref(out)) == 0 and out.value == 7
+    eng.close()
