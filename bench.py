@@ -63,14 +63,17 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
 
 
 def dominant_kernel_probe(batch):
-    """The dominant kernel is the bf16 MFMA implicit-GEMM (igemm_kernel<bf16,128,128>); time it live with HIP
-    events (torch events on the launch stream) on the heaviest layer shape of the step: the 3x3/1 conv of
-    ResNet-50 layer1 (64->64 ch at 64x64, per-launch algorithmic FLOPs = 2*M*N*K)."""
+    """The dominant kernel is the 16-bit MFMA implicit GEMM `igemm_dma_kernel`; time it live with HIP events (torch events on
+    the launch stream) on the heaviest layer shape of the step: the 3x3/1 conv of ResNet-50 layer1 (64 -> 64 channels at
+    64x64).  In the step that layer is ONE launch over the hi|lo pair (2 groups x B images); the probe runs the same amount of
+    work as a single group over 2*B images (same tile count, same per-tile work), so its duration is comparable with the
+    2048x2-workgroup rows of `igemm_dma_kernel<bf16, 128, 64, 2, 8, ...>` in profiles/r1_kernel_trace_bench.md (64.8 us).
+    Per-launch algorithmic FLOPs = 2*M*N*K."""
     import ctypes as C
     import torch
     from robo_vln_amd import _lib
     lib = _lib.lib()
-    B, H, W, Cin, Cout = batch, 64, 64, 64, 64
+    B, H, W, Cin, Cout = 2 * batch, 64, 64, 64, 64
     x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
     w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.05).to(torch.bfloat16)
     b = torch.randn(Cout, device="cuda")
@@ -92,7 +95,7 @@ def dominant_kernel_probe(batch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * B * H * W * Cout * 9 * Cin
-    return {"kernel": "igemm_dma_kernel<bf16,128,64,2> conv3x3 64->64 @64x64 (M=B*4096, N=64, K=576)", "us_per_launch": round(ms * 1e3, 2),
+    return {"kernel": "igemm_dma_kernel<bf16,128,64,2,8> conv3x3 64->64 @64x64, hi|lo pair workload (M=2*B*4096, N=64, K=576)", "us_per_launch": round(ms * 1e3, 2),
             "tflops": round(flops / ms / 1e9, 1)}
 
 
