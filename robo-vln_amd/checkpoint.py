@@ -5,7 +5,6 @@
 `load_state_dict` (:343-345).  The pickled `config` is a yacs `CfgNode`; yacs is not needed here: unknown classes
 un-pickle as plain dict/object stand-ins.
 """
-import io
 import pickle
 
 import torch

@@ -15,7 +15,7 @@ Appendix B).  `oracle/gen_golden.py` checks them with
 import math
 import numpy as np
 
-from .config import HCMConfig, CMAConfig
+from .config import HCMConfig
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 

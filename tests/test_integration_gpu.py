@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import cases, hcm_oracle
+from oracle import hcm_oracle
 from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig
 

@@ -2,7 +2,6 @@
 op it replaces, on the GPU, for both storage types."""
 import ctypes as C
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

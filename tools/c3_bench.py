@@ -1,6 +1,6 @@
 """The write-dominated bottleneck expansion conv as it runs in the step: 1x1 conv + bias + residual + ReLU, bf16,
 M = B*H*H pixels.  usage: [HCM_IGEMM_FORCE=c] python tools/c3_bench.py [B H Cin Cout]"""
-import ctypes as C, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hcm_pkg; hcm_pkg.load()

@@ -3,7 +3,7 @@ at B=256, depth 256x256, L=80, pre-computed instruction tensor.  GPU time by HIP
 (ctypes launch overhead overlaps: the chain is enqueued asynchronously), algorithmic bytes per SURVEY 8d."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import hcm_pkg; hcm_pkg.load()
 from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig

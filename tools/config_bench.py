@@ -3,7 +3,7 @@ configs[3] low-level model with SimpleCNN encoders at B=256 (memory-bound), conf
 at B=128 (MFMA-bound).  usage: python tools/config_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import hcm_pkg; hcm_pkg.load()
 from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig

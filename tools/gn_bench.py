@@ -1,4 +1,4 @@
-import ctypes as C, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hcm_pkg; hcm_pkg.load()

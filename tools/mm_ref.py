@@ -1,4 +1,4 @@
-import torch, time
+import torch
 def bench(M,N,K,dt=torch.bfloat16):
     a=torch.randn(M,K,device='cuda',dtype=dt); b=torch.randn(N,K,device='cuda',dtype=dt)
     for _ in range(5): c=a@b.t()

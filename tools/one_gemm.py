@@ -1,6 +1,6 @@
 """Run one igemm shape N times (for rocprofv3 --pmc / kernel-trace probes).
 usage: one_gemm.py lin M N K [reps] | conv H Cin Cout K stride pad [reps]   (B=64, bf16)"""
-import ctypes as C, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hcm_pkg; hcm_pkg.load()
