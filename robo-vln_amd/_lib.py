@@ -13,6 +13,7 @@ HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
  HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES) = range(9)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+HCM_ACT_REUSE_INSTRUCTION = 1
 
 STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: KeyError, -4: ValueError, -5: RuntimeError, -6: ValueError,
               -7: MemoryError}
@@ -52,6 +53,8 @@ EXPORTS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "hcm_last_error": (C.c_char_p, [C.c_void_p]),
     "hcm_destroy": (None, [C.c_void_p]),

@@ -412,24 +412,36 @@ int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const floa
     return HCM_OK;
 }
 
-int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
-            const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
-            void* stream) {
+int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+               const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+               int flags, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
     REQUIRE(h->cfg.build_high && h->cfg.build_low, HCM_ERR_STATE, "hcm_act needs both models in the handle");
     REQUIRE(rgb && depth && ids && hi_h_in && lo_h_in && mask && record && hi_h_out && lo_h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     REQUIRE(h->cfg.num_actions + h->cfg.lo_actions + 1 == 7, HCM_ERR_UNSUPPORTED, "record layout assumes 4 + 2 + 1 outputs");
+    const bool reuse = (flags & HCM_ACT_REUSE_INSTRUCTION) != 0;
+    REQUIRE(!reuse || h->last_hi_batch == B, HCM_ERR_STATE, "HCM_ACT_REUSE_INSTRUCTION: no previous step with this batch size");
     h->stream = (hipStream_t)stream;
+    h->reuse_instruction = reuse;
     const int ld = 7;
     const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
                                        (uint64_t)hi_h_in, (uint64_t)lo_h_in, (uint64_t)mask, (uint64_t)record, (uint64_t)hi_h_out,
-                                       (uint64_t)lo_h_out, (uint64_t)stream};
-    return run_graphed(h, key, stream, [&]() {
+                                       (uint64_t)lo_h_out, (uint64_t)stream, (uint64_t)flags};
+    rc = run_graphed(h, key, stream, [&]() {
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
     });
+    h->reuse_instruction = false;
+    if (rc == HCM_OK) h->last_hi_batch = B;
+    return rc;
+}
+
+int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+            const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+            void* stream) {
+    return hcm_act_ex(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, record, hi_h_out, lo_h_out, 0, stream);
 }
 
 int hcm_query(hcm_handle h, int what, int64_t* out) {

@@ -821,7 +821,9 @@ struct Fwd {
         // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
         // chain 3: BERT
         on(a2);
-        if (do_hi && !(skip & 8)) hi_bert(ids, ids_dt, B, hb);
+        // (the workspace layout is identical from step to step, so hb.I / hb.Q of the previous step are still in place when the
+        //  caller declares the instructions unchanged)
+        if (do_hi && !(skip & 8) && !(ctx->reuse_instruction && !dry)) hi_bert(ids, ids_dt, B, hb);
         // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
         on(a1);
         const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;

@@ -181,4 +181,8 @@ struct hcm_ctx {
     bool use_graph = true;
     int64_t graph_launches = 0, eager_launches = 0;
     bool failed = false;            // a launch failed during the current forward
+    // hcm_act_ex(HCM_ACT_REUSE_INSTRUCTION): skip BERT + the instruction stream of Visual_Ling_Attn and reuse the tensors the
+    // previous step left in the workspace (same batch size required); set per call
+    bool reuse_instruction = false;
+    int last_hi_batch = 0;
 };

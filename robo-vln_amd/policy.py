@@ -188,7 +188,7 @@ class HCMEngine:
                                                  stop.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
-    def _act_graph(self, observations, hi_hidden, lo_hidden, masks):
+    def _act_graph(self, observations, hi_hidden, lo_hidden, masks, flags=0):
         with torch.cuda.device(self.device):
             rgb, depth, ids, B = self._obs(observations, True)
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
@@ -209,10 +209,10 @@ class HCMEngine:
                                  (st["hh"][1 - i], hh), (st["lh"][1 - i], lh)):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src, non_blocking=True)
-                _lib.check(self._lib.hcm_act(self._h, st["rgb"].data_ptr(), _TORCH_DT[rgb.dtype], st["depth"].data_ptr(),
-                                             st["ids"].data_ptr(), _TORCH_DT[ids.dtype], B, st["hh"][1 - i].data_ptr(),
-                                             st["lh"][1 - i].data_ptr(), st["mask"].data_ptr(), st["rec"][i].data_ptr(),
-                                             st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), C.c_void_p(gs.cuda_stream)), self._h)
+                _lib.check(self._lib.hcm_act_ex(self._h, st["rgb"].data_ptr(), _TORCH_DT[rgb.dtype], st["depth"].data_ptr(),
+                                                st["ids"].data_ptr(), _TORCH_DT[ids.dtype], B, st["hh"][1 - i].data_ptr(),
+                                                st["lh"][1 - i].data_ptr(), st["mask"].data_ptr(), st["rec"][i].data_ptr(),
+                                                st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
                 st["tick"] += 1
             cur.wait_stream(gs)
         return st["rec"][i], st["hh"][i], st["lh"][i]
@@ -250,9 +250,13 @@ class HCMEngine:
                                                      h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
-    def act(self, observations, hi_hidden, lo_hidden, masks, out=None):
+    def act(self, observations, hi_hidden, lo_hidden, masks, out=None, reuse_instruction=False):
+        """reuse_instruction=True: the caller asserts that every environment's instruction is the one of the previous act() call
+        (no episode ended): BERT and the instruction stream of the cross-modal block are not recomputed (hcm_act_ex).  Off in
+        every parity test and in bench.py's headline number."""
+        flags = _lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0
         if self._graph:
-            rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks)
+            rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks, flags)
             if out is not None:
                 out.copy_(rec)
                 rec = out
@@ -262,9 +266,9 @@ class HCMEngine:
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
             hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)
-            _lib.check(self._lib.hcm_act(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
-                                         _TORCH_DT[ids.dtype], B, hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
-                                         rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), self._stream()), self._h)
+            _lib.check(self._lib.hcm_act_ex(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
+                                            _TORCH_DT[ids.dtype], B, hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
+                                            rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
         return rec, hh2, lh2
 
     # ---- debug taps

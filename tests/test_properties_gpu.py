@@ -170,3 +170,19 @@ def test_cma_rows_independent_and_length_extremes():
     assert (p[1] - a[1][perm]).abs().max().item() <= 1e-6
     assert (p[2] - a[2][:, perm]).abs().max().item() <= 1e-6
     eng.close()
+
+
+def test_reuse_instruction_equals_recompute(full):
+    """hcm_act_ex(HCM_ACT_REUSE_INSTRUCTION): with unchanged instructions the step is bitwise the step that recomputes BERT."""
+    cfg, eng, obs, hh, lh, mask = full
+    a0 = _act(eng, obs, hh, lh, mask)                          # establishes the instruction stream
+    obs2 = dict(obs)
+    obs2["rgb"] = obs["rgb"].flip(0).contiguous()              # new frames, same instructions
+    ref = _act(eng, obs2, a0[1], a0[2], torch.ones(B, device="cuda"))
+    _act(eng, obs, hh, lh, mask)
+    rec, h2, l2 = eng.act(dict(obs2), a0[1], a0[2], torch.ones(B, device="cuda"), reuse_instruction=True)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, ref[0]) and torch.equal(h2, ref[1]) and torch.equal(l2, ref[2])
+    with pytest.raises(RuntimeError):
+        sub = {k: v[:3].contiguous() for k, v in obs.items()}
+        eng.act(sub, hh[:, :3].contiguous(), lh[:, :3].contiguous(), mask[:3].contiguous(), reuse_instruction=True)   # no previous B=3 step
