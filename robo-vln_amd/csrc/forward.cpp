@@ -541,6 +541,41 @@ struct Fwd {
         tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
         hi_vis_pre(0, B, hb);
     }
+    // Trunk weights identical in both models (HighW::rgb_shared / depth_shared): one trunk pass, both models' heads
+    void rgb_shared(const void* rgb, int rgb_dt, int B, HiBufs& hb, LoBufs& lb) {
+        const HighW& w = ctx->hi;
+        const int rC = 2048 + 64;
+        use(ctx->dt_rgb);
+        Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "hi.rgb");
+        void* tok = ctx->dt_rgb == ctx->dt_vla ? hb.rgb_tok : alloc_t((size_t)B * 16 * rC);
+        void* pooled = alloc_t((size_t)B * o.C);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, 4, 4, rC, s), "rgb tokens");
+            ck(launch_fill_cols(w.rgb_pe, (char*)tok + (size_t)2048 * esz, dt, B, 16, 64, rC, s), "rgb pe");
+            if (tok != hb.rgb_tok) ck(launch_convert(tok, ctx->dt_rgb, hb.rgb_tok, ctx->dt_vla, (size_t)B * 16 * rC, s), "rgb tokens convert");
+            ck(launch_adaptive_avgpool(o.p, pooled, dt, B, o.H, o.W, o.C, 1, 1, o.C, s), "global avgpool (low-level head)");
+        }
+        linear(ctx->lo.rgb_fc, pooled, B, o.C, lb.xh + ctx->cfg.depth_out, lb.ldx, ACT_RELU, true);
+        use(ctx->dt_vla);
+        tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
+        hi_vis_pre(0, B, hb);
+    }
+    void depth_shared(const float* depth, int B, HiBufs& hb, LoBufs& lb) {
+        const HighW& w = ctx->hi;
+        const int dS = w.depth_S, dC = w.depth_C;
+        use(ctx->dt_depth);
+        Act o = depth_trunk(w.depth, depth, B, "hi.depth");
+        void* tok = ctx->dt_depth == ctx->dt_vla ? hb.dep_tok : alloc_t((size_t)B * dS * dC);
+        if (!dry) {
+            ck(launch_adaptive_avgpool(o.p, tok, dt, B, o.H, o.W, o.C, o.H, o.W, dC, s), "depth tokens");
+            ck(launch_fill_cols(w.depth_pe, (char*)tok + (size_t)o.C * esz, dt, B, dS, 64, dC, s), "depth pe");
+            if (tok != hb.dep_tok) ck(launch_convert(tok, ctx->dt_depth, hb.dep_tok, ctx->dt_vla, (size_t)B * dS * dC, s), "depth tokens convert");
+        }
+        linear(ctx->lo.depth_fc, o.p, B, o.H * o.W * o.C, lb.xh, lb.ldx, ACT_RELU, true);     // visual_fc of the low-level model
+        use(ctx->dt_vla);
+        tap("hi.depth_spatial", hb.dep_tok, true, {B, dS, dC});
+        hi_vis_pre(1, B, hb);
+    }
     // rgb_encoder (:180-181): ResNet50 trunk, adaptive_avg_pool2d(4,4), pos-emb channels -> rgb_tok
     void hi_rgb(const void* rgb, int rgb_dt, int B, HiBufs& hb) {
         const HighW& w = ctx->hi;
@@ -826,21 +861,26 @@ struct Fwd {
         if (do_hi && !(skip & 8) && !(ctx->reuse_instruction && !dry)) hi_bert(ids, ids_dt, B, hb);
         // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
         on(a1);
+        const bool dshare = do_hi && do_lo && ctx->hi.depth_shared && !ctx->lo.depth_simple;
         const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;
-        if (pair) {
+        if (dshare) {
+            if (!(skip & 4)) depth_shared(depth, B, hb, lb);
+        } else if (pair) {
             if (!(skip & 4)) depth_pair(depth, B, hb, lb);
         } else if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
         on(a1);
-        if (do_lo && !pair && !(skip & 4)) lo_depth(depth, B, lb);
+        if (do_lo && !pair && !dshare && !(skip & 4)) lo_depth(depth, B, lb);
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
+        const bool rshare = do_hi && do_lo && ctx->hi.rgb_shared && !ctx->lo.rgb_simple;
         const bool rpair = do_hi && do_lo && ctx->hi.has_rgb_pair && !ctx->lo.rgb_simple;
-        if (rpair) { if (!(skip & 1)) rgb_pair(rgb, rgb_dt, B, hb, lb); }
+        if (rshare) { if (!(skip & 1)) rgb_shared(rgb, rgb_dt, B, hb, lb); }
+        else if (rpair) { if (!(skip & 1)) rgb_pair(rgb, rgb_dt, B, hb, lb); }
         else if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
         static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
         on(rgb_serial ? main_s : a0);
-        if (do_hi && do_lo && !rpair && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
+        if (do_hi && do_lo && !rpair && !rshare && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);
         if (do_hi && do_lo && T == 1) { lo_early = &lb; lo_h_in_early = lo_h_in; }

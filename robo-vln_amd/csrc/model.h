@@ -96,6 +96,9 @@ struct HighW {
     bool has_depth_pair = false;
     TrunkW rgb_pair;           // likewise for the two BatchNorm-folded RGB ResNet-50s (shared frame, 2x64-channel stem)
     bool has_rgb_pair = false;
+    // the low-level model's trunk weights are bit-identical to the high-level model's (frozen pretrained encoders in both
+    // state_dicts): the trunk runs ONCE per step and feeds both models' heads -- bit-identical to running it twice
+    bool rgb_shared = false, depth_shared = false;
     BertW bert;
     LinW rgb_kv, depth_kv, rgb_linear, depth_linear;
     VlaW vla;

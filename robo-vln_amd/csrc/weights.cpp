@@ -723,11 +723,25 @@ void prepare_high(hcm_ctx* ctx) {
             }
         v.pe = up.f32(pe);
     }
-    if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !(getenv("HCM_NO_DEPTH_PAIR") && atoi(getenv("HCM_NO_DEPTH_PAIR")))) {
+    // identical trunk weights in both state_dicts (the reference freezes the pretrained encoders of both models)?
+    auto same_trunk = [&](const std::string& prefix) {
+        if (!c.build_low || getenv("HCM_NO_SHARE")) return false;
+        size_t n = 0;
+        for (const auto& kv : ctx->sd[HCM_HIGH]) {
+            if (kv.first.compare(0, prefix.size(), prefix) != 0) continue;
+            auto it = ctx->sd[HCM_LOW].find(kv.first);
+            if (it == ctx->sd[HCM_LOW].end() || it->second.f != kv.second.f) return false;
+            ++n;
+        }
+        return n > 0;
+    };
+    h.rgb_shared = c.rgb_encoder == HCM_ENC_RESNET && same_trunk("rgb_encoder.cnn.");
+    h.depth_shared = c.depth_encoder == HCM_ENC_RESNET && same_trunk("depth_encoder.visual_encoder.");
+    if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !h.depth_shared && !(getenv("HCM_NO_DEPTH_PAIR") && atoi(getenv("HCM_NO_DEPTH_PAIR")))) {
         h.depth_pair = make_gn_trunk_pair(ctx, up, "depth_encoder.visual_encoder.");
         h.has_depth_pair = true;
     }
-    if (c.build_low && c.rgb_encoder == HCM_ENC_RESNET && !(getenv("HCM_NO_RGB_PAIR") && atoi(getenv("HCM_NO_RGB_PAIR")))) {
+    if (c.build_low && c.rgb_encoder == HCM_ENC_RESNET && !h.rgb_shared && !(getenv("HCM_NO_RGB_PAIR") && atoi(getenv("HCM_NO_RGB_PAIR")))) {
         h.rgb_pair = make_tv_trunk_pair(ctx, up, "rgb_encoder.cnn.");
         h.has_rgb_pair = true;
     }

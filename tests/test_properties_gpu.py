@@ -9,6 +9,7 @@ import torch
 from oracle import cases
 from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig
+from robo_vln_amd import _lib as _lib_mod
 
 pytestmark = pytest.mark.gpu
 B = 64
@@ -186,3 +187,39 @@ def test_reuse_instruction_equals_recompute(full):
     with pytest.raises(RuntimeError):
         sub = {k: v[:3].contiguous() for k, v in obs.items()}
         eng.act(sub, hh[:, :3].contiguous(), lh[:, :3].contiguous(), mask[:3].contiguous(), reuse_instruction=True)   # no previous B=3 step
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_identical_trunk_weights_are_shared(precision):
+    """When the low-level model's trunk weights equal the high-level model's (frozen pretrained encoders in both state_dicts,
+    as in the reference's released checkpoint) each trunk runs once per step; the result must be what two runs give (the two
+    executions differ only in GroupNorm's reduction order, which depends on the channel-slab width: 1e-5 in fp32; in the 16-bit
+    path a last-bit difference in a statistic flips roundings that 50 layers amplify to the path's own noise level, 5e-3)."""
+    import os
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    n = 4
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=6)
+    lo_sd = dict(lo_sd)
+    for k, v in hi_sd.items():
+        if k.startswith(("rgb_encoder.cnn.", "depth_encoder.visual_encoder.")):
+            lo_sd[k] = v
+    shared = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision)
+    os.environ["HCM_NO_SHARE"] = "1"
+    try:
+        twice = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision)
+    finally:
+        del os.environ["HCM_NO_SHARE"]
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, n, seed=6, rgb_uint8=True).items()}
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, n, cfg.hidden, device="cuda"); lh = torch.zeros(R, n, cfg.hidden, device="cuda")
+    m = torch.zeros(n, device="cuda")
+    for _ in range(2):
+        a = shared.act(dict(obs), hh, lh, m)
+        b = twice.act(dict(obs), hh, lh, m)
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            assert (x - y).abs().max().item() <= (1e-5 if precision == "fp32" else 1e-2)
+        hh, lh, m = a[1].clone(), a[2].clone(), torch.ones(n, device="cuda")
+    assert shared.query(_lib_mod.HCM_WEIGHT_BYTES) < twice.query(_lib_mod.HCM_WEIGHT_BYTES)      # no pair trunks were built
+    shared.close(); twice.close()
