@@ -146,6 +146,11 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
                const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                int flags, void* stream);
 
+/* Companion of HCM_ACT_REUSE_INSTRUCTION for batched rollouts in which a few environments start a new episode: recomputes
+ * the cached instruction stream of the n listed environments (HOST array of indices into the batch) from ids (B,L) (device),
+ * leaving the other environments' cached tensors untouched.  Needs a previous hcm_act / hcm_act_ex step at this batch size. */
+int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, int B, const int32_t* env_indices, int n, void* stream);
+
 int hcm_query(hcm_handle h, int what, int64_t* out);
 
 /* Message of the last failing call on this handle (or on creation when h is NULL). */

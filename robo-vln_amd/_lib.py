@@ -55,6 +55,7 @@ EXPORTS = {
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "hcm_last_error": (C.c_char_p, [C.c_void_p]),
     "hcm_destroy": (None, [C.c_void_p]),

@@ -13,6 +13,7 @@ void prepare_high(hcm_ctx* ctx);
 void prepare_low(hcm_ctx* ctx);
 void build_spec_cma(hcm_ctx* ctx);
 void prepare_cma(hcm_ctx* ctx);
+void run_refresh_instruction(hcm_ctx* ctx, const void* ids, int ids_dt, int B, const int32_t* idx, int n);
 void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
              const float* mask, float* out, float* stop, float* h_out);
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
@@ -436,6 +437,24 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
     h->reuse_instruction = false;
     if (rc == HCM_OK) h->last_hi_batch = B;
     return rc;
+}
+
+int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, int B, const int32_t* env_indices, int n, void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
+    REQUIRE(ids && (env_indices || n == 0) && n >= 0 && n <= B, HCM_ERR_ARG, "bad argument");
+    REQUIRE(ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported ids dtype");
+    REQUIRE(h->last_hi_batch == B, HCM_ERR_STATE, "hcm_refresh_instruction: no previous step with this batch size");
+    for (int i = 0; i < n; ++i) REQUIRE(env_indices[i] >= 0 && env_indices[i] < B, HCM_ERR_ARG, "environment index out of range");
+    if (n == 0) return HCM_OK;
+    h->stream = (hipStream_t)stream;
+    try {
+        run_refresh_instruction(h, ids, ids_dtype, B, env_indices, n);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, e.what());
+    }
+    return HCM_OK;
 }
 
 int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,

@@ -700,6 +700,36 @@ struct Fwd {
         tap_rnn_in("lo.rnn_in", w.rnn, lb.xh, lb.ldx, B);
     }
 
+    // hcm_refresh_instruction: recompute the cached instruction stream (hb.I, hb.Q of the last B-sized step) for the listed
+    // environments only -- BERT + ins_fc/LN/PE + fc_q at batch n, rows copied into place
+    void refresh_instruction(const void* ids, int ids_dt, int B, const int32_t* idx, int n) {
+        const hcm_config& c = ctx->cfg;
+        ar.reset();
+        HiBufs hb = hi_alloc(B);                                  // same offsets as in step(): the persistent tensors
+        const int L = c.instr_len, d = c.d_model;
+        const size_t idsz = ids_dt == DT_I64 ? 8 : 4;
+        char* sub_ids = (char*)ar.alloc((size_t)n * L * idsz);
+        HiBufs hn;
+        use(ctx->dt_bert);
+        hn.emb = alloc_t((size_t)n * L * c.bert_hidden);
+        use(ctx->dt_vla);
+        hn.I = alloc_t((size_t)n * L * d);
+        hn.Q.resize(hb.Q.size());
+        for (auto& q : hn.Q) q = alloc_t((size_t)n * L * d);
+        for (int i = 0; i < n; ++i)
+            ck(hipMemcpyAsync(sub_ids + (size_t)i * L * idsz, (const char*)ids + (size_t)idx[i] * L * idsz, (size_t)L * idsz, hipMemcpyDeviceToDevice, s), "ids gather");
+        use(ctx->dt_bert);
+        bert(ctx->hi.bert, sub_ids, ids_dt, n, hn.emb);
+        hi_ins_pre(n, hn);
+        use(ctx->dt_vla);
+        const size_t row = (size_t)L * d * esz;
+        for (int i = 0; i < n; ++i) {
+            ck(hipMemcpyAsync((char*)hb.I + idx[i] * row, (char*)hn.I + i * row, row, hipMemcpyDeviceToDevice, s), "I scatter");
+            for (size_t l = 0; l < hb.Q.size(); ++l)
+                ck(hipMemcpyAsync((char*)hb.Q[l] + idx[i] * row, (char*)hn.Q[l] + i * row, row, hipMemcpyDeviceToDevice, s), "Q scatter");
+        }
+    }
+
     // ---------------------------------------------------------------- CMANet.forward (models/cma.py:211-333)
     void cma_step(const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
                   const float* mask, float* out, float* stop, float* h_out) {
@@ -908,6 +938,10 @@ void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt,
 }  // namespace hcm
 
 namespace hcm {
+void run_refresh_instruction(hcm_ctx* ctx, const void* ids, int ids_dt, int B, const int32_t* idx, int n) {
+    Fwd f(ctx);
+    f.refresh_instruction(ids, ids_dt, B, idx, n);
+}
 void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
              const float* mask, float* out, float* stop, float* h_out) {
     Fwd f(ctx);

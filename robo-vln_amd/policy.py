@@ -271,6 +271,25 @@ class HCMEngine:
                                             rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
         return rec, hh2, lh2
 
+    def refresh_instruction(self, instruction, env_indices):
+        """Recompute the cached instruction stream of the listed environments (those that started a new episode) from
+        `instruction` (B, L); afterwards act(..., reuse_instruction=True) is valid again (hcm_refresh_instruction)."""
+        idx = np.ascontiguousarray(np.asarray(env_indices, dtype=np.int32).reshape(-1))
+        with torch.cuda.device(self.device):
+            ids = self._dev(instruction, (torch.int64, torch.int32, torch.float32))
+            B = ids.shape[0]
+            if self._graph and self._static is not None and self._static["B"] == B and self._static["ids"].dtype == ids.dtype:
+                gs = self._gstream
+                gs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(gs):
+                    self._static["ids"].copy_(ids, non_blocking=True)
+                    _lib.check(self._lib.hcm_refresh_instruction(self._h, self._static["ids"].data_ptr(), _TORCH_DT[ids.dtype], B,
+                                                                 idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, C.c_void_p(gs.cuda_stream)), self._h)
+                torch.cuda.current_stream().wait_stream(gs)
+            else:
+                _lib.check(self._lib.hcm_refresh_instruction(self._h, ids.data_ptr(), _TORCH_DT[ids.dtype], B,
+                                                             idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, self._stream()), self._h)
+
     # ---- debug taps
     def enable_taps(self, on=True):
         _lib.check(self._lib.hcm_debug_enable_taps(self._h, int(on)), self._h)

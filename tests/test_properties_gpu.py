@@ -223,3 +223,23 @@ def test_identical_trunk_weights_are_shared(precision):
         hh, lh, m = a[1].clone(), a[2].clone(), torch.ones(n, device="cuda")
     assert shared.query(_lib_mod.HCM_WEIGHT_BYTES) < twice.query(_lib_mod.HCM_WEIGHT_BYTES)      # no pair trunks were built
     shared.close(); twice.close()
+
+
+def test_partial_instruction_refresh(full):
+    """Two environments start a new episode: hcm_refresh_instruction recomputes only their cached instruction stream; the next
+    reuse step equals the step that recomputes BERT for everybody."""
+    cfg, eng, obs, hh, lh, mask = full
+    a0 = _act(eng, obs, hh, lh, mask)
+    new = dict(obs)
+    ids = obs["instruction"].clone()
+    g = torch.Generator().manual_seed(9)
+    for e in (5, 41):
+        ids[e] = torch.randint(1000, cfg.bert_vocab, (cfg.instr_len,), generator=g).cuda()
+    new["instruction"] = ids
+    m = torch.ones(B, device="cuda"); m[5] = 0; m[41] = 0
+    ref = _act(eng, new, a0[1], a0[2], m)                       # full recompute with the new instructions
+    _act(eng, obs, hh, lh, mask)                                # back to the old cached state
+    eng.refresh_instruction(ids, [5, 41])
+    rec, h2, l2 = eng.act(dict(new), a0[1], a0[2], m, reuse_instruction=True)
+    torch.cuda.synchronize()
+    assert torch.equal(rec, ref[0]) and torch.equal(h2, ref[1]) and torch.equal(l2, ref[2])
