@@ -51,21 +51,30 @@ class RolloutState:
         self.masks = (~dones.to(self.masks.device)).to(self.masks.dtype)                      # :1103 / :1147
 
 
-def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidden, device, world=1, rank=0):
+def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidden, device, world=1, rank=0, cache_instruction=False):
     """Drive `policy.act` for `steps` steps over this rank's environments.
     obs_fn(t, lo, hi) -> observations dict for global envs [lo, hi); done_fn(t, lo, hi) -> (hi-lo,) bool.
-    Returns the (steps, global_envs, 7) records (gathered when world > 1)."""
+    Returns the (steps, global_envs, 7) records (gathered when world > 1).
+    cache_instruction=True (HIP engine only): an instruction is fixed for an episode, so BERT runs only for the environments
+    whose episode ended in the previous step (hcm_refresh_instruction) and every other step reuses the cached stream."""
     global_envs = num_envs * world
     lo, hi = shard_range(global_envs, world, rank)
     st = RolloutState(num_envs, num_recurrent_layers, hidden, device)
     out = []
+    prev_done = None
     for t in range(steps):
-        rec, hh, lh = policy.act(obs_fn(t, lo, hi), st.hi_hidden, st.lo_hidden, None, st.masks)
+        obs = obs_fn(t, lo, hi)
+        reuse = cache_instruction and t > 0
+        if reuse and prev_done is not None and bool(prev_done.any()):
+            policy.engine.refresh_instruction(obs["instruction"], torch.nonzero(prev_done).flatten().cpu().numpy())
+        rec, hh, lh = (policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, reuse_instruction=True) if reuse
+                       else policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks))
         if world > 1:
             full = torch.empty(global_envs, RECORD_WIDTH, device=rec.device, dtype=rec.dtype)
             gather_records(rec, full)
         else:
             full = rec
         out.append(full.clone())
-        st.after_step(hh, lh, done_fn(t, lo, hi))
+        prev_done = done_fn(t, lo, hi)
+        st.after_step(hh, lh, prev_done)
     return torch.stack(out)

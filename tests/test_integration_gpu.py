@@ -89,3 +89,33 @@ def test_c_abi_error_codes():
     assert lib.hcm_query(hh, 99, C.byref(out)) == -1
     assert lib.hcm_query(hh, _lib.HCM_RECORD_WIDTH, C.byref(out)) == 0 and out.value == 7
     eng.close()
+
+
+def test_rollout_with_cached_instructions_equals_recomputing():
+    """rollout(cache_instruction=True): BERT only for the environments whose episode just ended -- same records, bit for bit."""
+    from robo_vln_amd.policy import HCMEngine, Policy
+    from robo_vln_amd.rollout import rollout
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, vla_layers=1, bert_layers=2).validate()
+    n, T = 6, 5
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=8)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision="bf16")
+    pol = Policy(eng)
+    frames = [synth.make_observations(cfg, n, step=t, seed=8, rgb_uint8=True) for t in range(T)]
+    dones = [torch.tensor([t == 1 and e in (1, 4) or t == 3 and e == 0 for e in range(n)]) for t in range(T)]
+    # an environment whose episode ended gets a new instruction from the next step on
+    instr = [frames[0]["instruction"].copy()]
+    for t in range(1, T):
+        cur = instr[-1].copy()
+        for e in torch.nonzero(dones[t - 1]).flatten().tolist():
+            cur[e] = frames[t]["instruction"][(e + 1) % n]
+        instr.append(cur)
+
+    def obs_fn(t, lo, hi):
+        return {"rgb": torch.from_numpy(frames[t]["rgb"][lo:hi]).cuda(), "depth": torch.from_numpy(frames[t]["depth"][lo:hi]).cuda(),
+                "instruction": torch.from_numpy(instr[t][lo:hi]).cuda()}
+    args = (pol, obs_fn, lambda t, lo, hi: dones[t][lo:hi], n, T, cfg.num_recurrent_layers, cfg.hidden, torch.device("cuda"))
+    a = rollout(*args)
+    b = rollout(*args, cache_instruction=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    eng.close()
