@@ -194,6 +194,11 @@ def main():
     # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is
     step(mask0)
     step(mask1)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.25:          # ... and a quarter second of untimed steps so that the clocks have ramped
+        step(mask1)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(mask1)
     if use_dist:
