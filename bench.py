@@ -194,11 +194,8 @@ def main():
     # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is
     step(mask0)
     step(mask1)
-    torch.cuda.synchronize()
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.25:          # ... and a quarter second of untimed steps so that the clocks have ramped
-        step(mask1)
-        torch.cuda.synchronize()
+    for _ in range(40):                                # ... and ~0.25 s of untimed steps so that the clocks have ramped (a fixed
+        step(mask1)                                    # count: every rank must issue the same number of all-gathers)
     for _ in range(args.warmup):
         step(mask1)
     if use_dist:
