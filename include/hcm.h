@@ -213,6 +213,13 @@ int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const vo
 int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
                      int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
                      int relu, void* stream);
+/* Tail of a BatchNorm-folded ResNet bottleneck in ONE launch (16-bit dtypes, C1 = 64 or 128):
+ *   y = relu(conv1x1(relu(conv3x3(x, w2, stride, pad 1) + b2), w3) + b3 + identity)
+ * x (B,H,W,C1), w2 [C1][3][3][C1], w3 [4*C1][C1], identity and y (B,Ho,Wo,4*C1).  Bit-identical to hcm_op_conv2d applied
+ * twice (reference: torchvision Bottleneck.forward conv2/bn2/relu/conv3/bn3/+identity/relu as used by
+ * resnet_encoders.py:196-225 TorchVisionResNet50). */
+int hcm_op_bottleneck_tail(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
+                           void* y, int dtype, int B, int H, int W, int C1, int stride, void* stream);
 /* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,

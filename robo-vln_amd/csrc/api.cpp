@@ -545,6 +545,13 @@ int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const vo
     g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = act;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_bottleneck_tail(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
+                           void* y, int dtype, int B, int H, int W, int C1, int stride, void* stream) {
+    Bneck23 b;
+    b.x = x; b.w2 = w2; b.b2 = b2; b.w3 = w3; b.b3 = b3; b.res = identity; b.y = y;
+    b.B = B; b.H = H; b.W = W; b.C1 = C1; b.stride = stride;
+    return op_rc(launch_bneck23(b, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
                      int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
                      int relu, void* stream) {

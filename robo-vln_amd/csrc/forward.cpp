@@ -201,6 +201,35 @@ struct Fwd {
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
             if (t.gn) conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
             else conv(b.c1, x, sa, 1, 0, nullptr, ACT_RELU, x.H, x.W);
+            // BN-folded trunks, 64 / 128 mid channels (layer1, layer2), 16-bit storage: 3x3 conv + 1x1 expansion + identity in ONE
+            // launch, the mid tensor stays in LDS (igemm.hip: bneck23_kernel; bit-identical to the two launches)
+            static const bool no_tail = getenv("HCM_NO_BNECK_FUSE") != nullptr;
+            if (!t.gn && !no_tail && (b.c2.dt == DT_BF16 || b.c2.dt == DT_F16) && (b.c2.Cout == 64 || b.c2.Cout == 128) && b.c2.KH == 3 &&
+                b.c2.Cin == b.c2.Cout && b.c2.Kp == 9 * b.c2.Cin && b.c3.Cout == 4 * b.c2.Cout && b.c3.Kp == b.c2.Cout && b.c2.bias && b.c3.bias &&
+                b.c3.groups == b.c2.groups) {
+                const void* idt = x.p;
+                if (b.has_ds) {
+                    conv(b.ds, x, sb, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);
+                    idt = sb;
+                }
+                if (!dry) {
+                    Bneck23 q;
+                    q.x = sa; q.w2 = b.c2.w; q.b2 = b.c2.bias; q.w3 = b.c3.w; q.b3 = b.c3.bias; q.res = idt; q.y = sc;
+                    q.B = B; q.H = x.H; q.W = x.W; q.C1 = b.c2.Cout; q.xC = o1.C; q.stride = b.stride;
+                    q.ldy = q.ldr = CO(b.c3);
+                    if (b.c2.groups > 1) {
+                        q.groups = b.c2.groups; q.g_x = b.c2.Cin; q.g_w2 = (long long)b.c2.Cout * b.c2.Kp; q.g_b2 = b.c2.Cout;
+                        q.g_w3 = (long long)b.c3.Cout * b.c3.Kp; q.g_b3 = b.c3.Cout; q.g_y = b.c3.Cout;
+                    }
+                    ck(launch_bneck23(q, b.c2.dt, s), "bottleneck tail");
+                }
+                x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
+                xi = fr[2];
+                ++bidx;
+                if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16)
+                    tap(tapname + "_layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4), x.p, true, {B, x.H, x.W, x.C});
+                continue;
+            }
             Act o2{sb, B, Ho2, Wo2, CO(b.c2)};
             if (t.gn) conv_gn(b.c2, o1, sb, b.stride, 1, nullptr, b.n2, G, true, Ho2, Wo2);
             else conv(b.c2, o1, sb, b.stride, 1, nullptr, ACT_RELU, Ho2, Wo2);

@@ -26,6 +26,7 @@
 // convs, and every nn.Linear / Conv1d(k=1) on the path.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 #include <algorithm>
@@ -247,6 +248,174 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
             }
         }
     }
+}
+
+// The same epilogue with the f32 image processed in SPLIT row slabs (fused bottleneck kernel: one slab of LDS instead of the
+// whole tile).  A separate function: a run-time slab loop in the shared epilogue costs every kernel ~60 VGPRs.
+template <typename T, int BM, int BN, int NW, int WMc, int NPRE, int SPLIT>
+__device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], char* smem, int m0, int n0,
+                                               int tid, int wm, int wn, int fr, int fg, const uint4 (&rpre)[NPRE], bool have_pre) {
+    constexpr int WNc = NW / WMc;          // waves along the channel axis (WMc along the pixel axis)
+    constexpr int TM = BM / WMc / 16;
+    constexpr int TN = BN / WNc / 16;
+    // ---- epilogue ----
+    // Phase 1: every lane parks its accumulators (4 consecutive channels of one pixel) in an f32 LDS image of the
+    // output tile (the A/B tiles are dead: the K loop ended with a barrier).  Phase 2: each thread takes 8
+    // consecutive channels of a row, applies bias + residual + activation in f32, rounds once, and stores 16 B --
+    // a row of the tile leaves as one contiguous BN*sizeof(T)-byte run (the accumulator layout alone would store
+    // 32-byte fragments).  Row stride BN+4 floats keeps the ds_write_b128 of phase 1 conflict free.
+    // SPLIT = 2 / 4: the image holds BM/2 or BM/4 rows at a time and the two phases run once
+    // per slab, so the launch needs one slab of LDS instead of the whole f32 tile.
+    constexpr int LDC = BN + 4;
+    float* sc = reinterpret_cast<float*>(smem);
+    constexpr int split = SPLIT;
+    constexpr int slab_rows = BM / split;
+    constexpr int TPR = BN / 8;            // threads per tile row
+    constexpr int RPP = 64 * NW / TPR;     // rows per pass
+    const int c8 = (tid % TPR) * 8;
+    const int n = n0 + c8;
+    const bool n_ok = n < p.N;
+    const bool hi_ok = (n + 4) < p.N;      // N % 4 == 0: the second group of four is all-valid or all-invalid
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n_ok) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        if (hi_ok) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+    }
+    const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
+    const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
+#pragma unroll
+  for (int slab = 0; slab < split; ++slab) {
+    const int row0 = slab * slab_rows;
+    if (slab) __syncthreads();             // the previous slab's rows have been read
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int rb = wm * (BM / WMc) + j * 16;       // wave-uniform: a 16-row fragment lies inside one slab
+        if (rb < row0 || rb >= row0 + slab_rows) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int r = rb + fr - row0;
+            const int cc = wn * (BN / WNc) + i * 16 + fg * 4;
+            *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+    __syncthreads();
+    // Fused GroupNorm (habitat GN-ResNet layers whose map has <= 64 pixels): the tile holds BM / hw whole samples and BN / cg
+    // whole groups; one wave per (sample, group) reduces its hw x cg block of the f32 image (fixed order), then the
+    // normalisation rides in phase 2.  The un-normalised conv output is never written.
+    float* gst = sc + BM * LDC;            // [sample][group][mean, rstd]
+    const int gn_ng = p.gn_cg ? BN / p.gn_cg : 0;
+    if (p.gn_cg) {
+        const int hw = p.gn_hw, cg = p.gn_cg;
+        const int pairs = (BM / hw) * gn_ng;
+        const int lane_ = tid & 63;
+        for (int pr = tid >> 6; pr < pairs; pr += NW) {
+            const int sidx = pr / gn_ng, g = pr - sidx * gn_ng;
+            const int ne = hw * cg;
+            float a = 0.f, q = 0.f;
+            for (int e = lane_; e < ne; e += 64) {
+                const int r = sidx * hw + e / cg, cix = g * cg + e % cg;
+                const float v = sc[r * LDC + cix];
+                a += v; q += v * v;
+            }
+            a = wave_sum(a); q = wave_sum(q);
+            if (lane_ == 0) {
+                const float inv = 1.0f / (float)ne;
+                const float mean = a * inv;
+                gst[pr * 2] = mean;
+                gst[pr * 2 + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
+            }
+        }
+        __syncthreads();
+    }
+    if (!n_ok) continue;
+#pragma unroll
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        if (pass * RPP < row0 || pass * RPP >= row0 + slab_rows) continue;
+        const int r = pass * RPP + tid / TPR;
+        const int m = m0 + r;
+        if (m >= p.M) continue;
+        float v[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(sc + (r - row0) * LDC + c8);
+            const float4 a1 = *reinterpret_cast<const float4*>(sc + (r - row0) * LDC + c8 + 4);
+            v[0] = a0.x + bias8[0]; v[1] = a0.y + bias8[1]; v[2] = a0.z + bias8[2]; v[3] = a0.w + bias8[3];
+            v[4] = a1.x + bias8[4]; v[5] = a1.y + bias8[5]; v[6] = a1.z + bias8[6]; v[7] = a1.w + bias8[7];
+        }
+        if (p.gn_cg) {                     // cg is a multiple of 8: the thread's 8 channels share one group
+            const float* ms = gst + ((r / p.gn_hw) * gn_ng + c8 / p.gn_cg) * 2;
+            const float mean = ms[0], rstd = ms[1];
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gn_gamma + n), g1 = *reinterpret_cast<const float4*>(p.gn_gamma + n + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.gn_beta + n), b1 = *reinterpret_cast<const float4*>(p.gn_beta + n + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+        }
+        if (p.res) {
+            const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
+            if constexpr (sizeof(T) == 2) {
+                if (have_pre) {                 // residual chunk prefetched at kernel start (see igemm_dma_kernel)
+                    float rr[8];
+                    cvt_chunk<T>(rpre[pass < NPRE ? pass : 0], rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                } else if (wide16r) {
+                    float rr[8];
+                    ld_chunk(rp, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += Tr<T>::ld(rp + e);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 4; e < 8; ++e) v[e] += Tr<T>::ld(rp + e);
+                    }
+                }
+            } else {
+                const float4 r0 = *reinterpret_cast<const float4*>(rp);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (hi_ok) {
+                    const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+            }
+        }
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.out_f32 || sizeof(T) == 4) {
+            float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (hi_ok) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            if constexpr (sizeof(T) == 2) {
+                T* yp = reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n;
+                if (wide16) {
+                    st_chunk(yp, v);
+                } else {
+                    T o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    *reinterpret_cast<uint2*>(yp) = *reinterpret_cast<const uint2*>(o4);
+                    if (hi_ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[4 + e]);
+                        *reinterpret_cast<uint2*>(yp + 4) = *reinterpret_cast<const uint2*>(o4);
+                    }
+                }
+            }
+        }
+    }
+  }
 }
 
 // S = void: activations are T with Cin a multiple of the 16-byte chunk (the general path).
@@ -912,6 +1081,233 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused tail of a BatchNorm-folded ResNet bottleneck (RGB trunk, layer1 / layer2): the 3x3 conv (C1 -> C1, + bias + ReLU) and the
+// 1x1 expansion (C1 -> 4*C1, + bias + identity + ReLU) in ONE launch.  A workgroup computes BM pixels x all C1 channels of
+// the 3x3 conv (phase A: the ordinary LDS-DMA K loop, 2-deep ring), rounds them to the storage type exactly as the stand-alone conv's
+// epilogue would, and parks them in LDS in the swizzled operand layout -- the C1-channel intermediate never goes to HBM (a
+// full write + read of the M x C1 tensor per block, and one launch).  Phase B multiplies that tile with the expansion weights, 128
+// output channels at a time (weights streamed by LDS-DMA, the next slice requested while the current one's epilogue runs),
+// through the shared epilogue in two row slabs.  Same MFMA instruction and k order as the two stand-alone launches: bit-identical.
+struct BneckDev {
+    IGemmDev a;                  // phase A: x, w (3x3), bias, geometry, M, N = C1, K = Kp = 9*C1, groups / g_x / g_w / g_b
+    const char* w3; const float* b3; const char* res; char* y;
+    int C3, Kp3, ldy3, ldr3;
+    unsigned w3_bytes;
+    long long g_w3, g_b3, g_y3;  // per-group element offsets of the expansion weights / bias / (y, res)
+};
+
+template <typename T, int BM, int C1>
+__global__ __launch_bounds__(512) void bneck23_kernel(BneckDev q) {
+    constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64;
+    constexpr int TM = BM / WMc / 16;              // both phases: BM / 2 pixel rows per wave
+    constexpr int TN1 = C1 / WNc / 16;             // phase A: C1 / 4 channels per wave
+    constexpr int TN2 = 128 / WNc / 16;            // phase B: 32 of the slice's 128 channels per wave
+    constexpr int A_IT = BM / 8 / NW, B_IT = C1 / 8 / NW;
+    constexpr int TILE_BYTES = (BM + C1) * 128;
+    constexpr int KT1 = C1 / BK;                   // K tiles of phase B
+    constexpr int NT = 4 * C1 / 128;               // 128-channel output slices
+    constexpr int T_BYTES = KT1 * BM * 128, W3_BYTES = KT1 * 128 * 128;
+    constexpr int E_RPP = 64 * NW / (128 / 8), E_NP = BM / E_RPP;
+    static_assert(A_IT >= 1 && B_IT >= 1 && TN1 >= 1 && sizeof(T) == 2, "bneck23 tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    IGemmDev& p = q.a;
+    if (p.groups > 1) {
+        const long long g = blockIdx.y;
+        p.x += g * p.g_x * 2;
+        p.w += g * p.g_w * 2;
+        p.bias += g * p.g_b;
+        q.w3 += g * q.g_w3 * 2;
+        q.b3 += g * q.g_b3;
+        q.res += g * q.g_y3 * 2;
+        q.y += g * q.g_y3 * 2;
+    }
+    const int m0 = blockIdx.x * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNc, wn = wave % WNc;
+    const int rin = lane >> 3;
+    const int c = (lane & 7) ^ rin;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // identity rows of every output slice, requested first: they arrive while phase A runs
+    uint4 rpre[NT][E_NP];
+    {
+        const int n = (tid % 16) * 8;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pass = 0; pass < E_NP; ++pass) {
+                const int m = m0 + pass * E_RPP + tid / 16;
+                rpre[nt][pass] = make_uint4(0u, 0u, 0u, 0u);
+                if (m < p.M) rpre[nt][pass] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * 128 + n);
+            }
+    }
+
+    int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + rin;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_pix[i] = b * p.H * p.W;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+        } else {
+            a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+        }
+    }
+    const v4i_t rx = make_rsrc(p.x, p.x_bytes);
+    const v4i_t rw = make_rsrc(p.w, p.w_bytes);
+    const v4i_t rw3 = make_rsrc(q.w3, q.w3_bytes);
+
+    auto stage = [&](int kt, int buf) {
+        const unsigned sa = lds_base + buf * TILE_BYTES;
+        const unsigned sb = sa + BM * 128;
+        const int k = kt * BK + c * CH;
+        const int khw = k >> p.cin_shift;
+        const int ci = k & (p.Cin - 1);
+        const int kh = (khw * p.kw_rcp) >> 16;
+        const int kw = khw - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * 2u;
+            dma16(sa + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = (wave + NW * i) * 8 + rin;
+            const unsigned off = (unsigned)(n * p.Kp + k) * 2u;
+            dma16(sb + (wave + NW * i) * 1024, (k < p.Kp) ? off : 0xFFFFFFFFu, rw);
+        }
+    };
+    // expansion weights of output slice nt: KT1 blocks of [128 channels][64 k] behind the parked tile
+    auto stage_w3 = [&](int nt) {
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = nt * 128 + (wave + NW * i) * 8 + rin;
+                const unsigned off = (unsigned)(n * q.Kp3 + kt * BK + c * CH) * 2u;
+                dma16(lds_base + T_BYTES + kt * (128 * 128) + (wave + NW * i) * 1024, off, rw3);
+            }
+    };
+
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+    // ---- phase A: 3x3 conv, BM x C1
+    f32x4 acc1[TN1][TM];
+#pragma unroll
+    for (int i = 0; i < TN1; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + BK - 1) / BK;
+    stage(0, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[TM], wb[TN1];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / WMc) + j * 16 + fr;
+                xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i) {
+                const int r = wn * (C1 / WNc) + i * 16 + fr;
+                wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
+        }
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    // the ring is dead (the loop ended with a barrier): first weight slice on its way, then park relu(conv + bias) as the
+    // phase-B operand: row r, channel cc -> block cc / 64, 16-byte chunk (cc % 64) / 8 swizzled by the row like a DMA'd tile
+    stage_w3(0);
+#pragma unroll
+    for (int i = 0; i < TN1; ++i) {
+        const int cc = wn * (C1 / WNc) + i * 16 + fg * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cc);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * (BM / WMc) + j * 16 + fr;
+            T o4[4];
+            Tr<T>::st(&o4[0], fmaxf(acc1[i][j][0] + b4.x, 0.f));
+            Tr<T>::st(&o4[1], fmaxf(acc1[i][j][1] + b4.y, 0.f));
+            Tr<T>::st(&o4[2], fmaxf(acc1[i][j][2] + b4.z, 0.f));
+            Tr<T>::st(&o4[3], fmaxf(acc1[i][j][3] + b4.w, 0.f));
+            char* dst = smem + (cc >> 6) * (BM * 128) + r * 128 + ((((cc & 63) >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2;
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o4);
+        }
+    }
+    // ---- phase B: 1x1 expansion, NT slices of BM x 128
+    IGemmDev pe = p;
+    pe.bias = q.b3; pe.res = q.res; pe.y = q.y; pe.N = q.C3; pe.ldy = q.ldy3; pe.ldr = q.ldr3;
+    pe.act = ACT_RELU; pe.out_f32 = 0; pe.gn_cg = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        wait_vmcnt<0>();                                   // this slice's weights have landed
+        __syncthreads();                                   // ... for every wave; the parked tile is complete; the image is free
+        f32x4 acc2[TN2][TM];
+#pragma unroll
+        for (int i = 0; i < TN2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+            const char* sa = smem + kt * (BM * 128);
+            const char* sb = smem + T_BYTES + kt * (128 * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TM], wb[TN2];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int r = wm * (BM / WMc) + j * 16 + fr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i) {
+                    const int r = wn * 32 + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<T>::run(acc2[i][j], wb[i], xa[j]);
+            }
+        }
+        if (nt + 1 < NT) {
+            __syncthreads();                               // every wave has read this slice's weights
+            stage_w3(nt + 1);
+        }
+        igemm_epilogue_split<T, BM, 128, NW, WMc, E_NP, 2>(pe, acc2, smem + T_BYTES + W3_BYTES, m0, nt * 128, tid, wm, wn, fr, fg, rpre[nt], true);
+    }
+}
+
+
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset) {
     std::vector<unsigned long long> h((size_t)kProfSlots * 8);
     hipError_t e = hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_igemm_prof), h.size() * 8);
@@ -1290,6 +1686,47 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         }
     }
     return launch_dt(d, dt, choice, s);
+}
+
+
+hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
+    if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
+    if ((b.C1 != 64 && b.C1 != 128) || !b.res || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
+    const int C3 = 4 * b.C1;
+    const int ldy = b.ldy ? b.ldy : C3, ldr = b.ldr ? b.ldr : C3, xC = b.xC ? b.xC : b.C1;
+    if ((ldy % 8) || (ldr % 8) || (xC % 8)) return hipErrorInvalidValue;
+    BneckDev q;
+    IGemmDev& d = q.a;
+    memset((void*)&q, 0, sizeof(q));
+    d.x = (const char*)b.x; d.w = (const char*)b.w2; d.bias = b.b2;
+    d.B = b.B; d.H = b.H; d.W = b.W; d.Cin = b.C1; d.xC = xC;
+    d.Ho = (b.H + 2 - 3) / b.stride + 1; d.Wo = (b.W + 2 - 3) / b.stride + 1;
+    d.KH = 3; d.KW = 3; d.stride = b.stride; d.stride_w = b.stride; d.pad = 1;
+    d.M = b.B * d.Ho * d.Wo; d.N = b.C1; d.K = 9 * b.C1; d.Kp = 9 * b.C1;
+    d.cin_shift = b.C1 == 64 ? 6 : 7;
+    d.kw_rcp = (65536 + 3 - 1) / 3;
+    d.groups = b.groups > 1 ? b.groups : 1;
+    d.g_x = b.g_x; d.g_w = b.g_w2; d.g_b = b.g_b2;
+    {
+        const size_t xb = (((size_t)d.B * d.H * d.W - 1) * d.xC + d.Cin) * 2, wb = (size_t)d.N * d.Kp * 2, w3b = (size_t)C3 * b.C1 * 2;
+        if (xb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+        d.x_bytes = (unsigned)xb; d.w_bytes = (unsigned)wb; q.w3_bytes = (unsigned)w3b;
+    }
+    q.w3 = (const char*)b.w3; q.b3 = b.b3; q.res = (const char*)b.res; q.y = (char*)b.y;
+    q.C3 = C3; q.Kp3 = b.C1; q.ldy3 = ldy; q.ldr3 = ldr;
+    q.g_w3 = b.g_w3; q.g_b3 = b.g_b3; q.g_y3 = b.g_y;
+    const int BM = b.C1 == 64 ? 128 : 64;
+    const int KT1 = b.C1 / 64;
+    size_t lds = (size_t)KT1 * BM * 128 + (size_t)KT1 * 128 * 128 + (size_t)(BM / 2) * (128 + 4) * 4;
+    const size_t ring = 2 * (size_t)(BM + b.C1) * 128;
+    if (ring > lds) lds = ring;
+    const void* fn;
+    if (dt == DT_BF16) fn = b.C1 == 64 ? reinterpret_cast<const void*>(bneck23_kernel<bf16, 128, 64>) : reinterpret_cast<const void*>(bneck23_kernel<bf16, 64, 128>);
+    else fn = b.C1 == 64 ? reinterpret_cast<const void*>(bneck23_kernel<f16, 128, 64>) : reinterpret_cast<const void*>(bneck23_kernel<f16, 64, 128>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    void* args[] = {&q};
+    return hipLaunchKernel(fn, dim3((d.M + BM - 1) / BM, d.groups), dim3(512), args, lds, s);
 }
 
 }  // namespace hcm

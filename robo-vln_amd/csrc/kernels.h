@@ -41,6 +41,20 @@ struct IGemm {
     int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
+// Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,
+// C1 = 64 or 128 (igemm.hip: bneck23_kernel).  Weights as for launch_igemm: w2 [C1][9*C1] (k = (kh*3+kw)*C1 + ci), w3 [4*C1][C1].
+struct Bneck23 {
+    const void* x = nullptr;     // [B,H,W,*] C1 channels at pixel stride xC
+    const void* w2 = nullptr; const float* b2 = nullptr;
+    const void* w3 = nullptr; const float* b3 = nullptr;
+    const void* res = nullptr;   // identity [M][ldr]
+    void* y = nullptr;           // [M][ldy]
+    int B = 1, H = 1, W = 1, C1 = 0, xC = 0, stride = 1, ldy = 0, ldr = 0;
+    int groups = 1;              // hi|lo pair: element offsets per group
+    long long g_x = 0, g_w2 = 0, g_b2 = 0, g_w3 = 0, g_b3 = 0, g_y = 0;
+};
+hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
+
 // While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real
 // operands and caches the fastest (process-wide); hcm_finalize() runs one tuning step at max_batch.
 void igemm_set_tuning(bool on);

@@ -289,3 +289,36 @@ def test_conv2d_groupnorm_fused(prec, cfg):
     torch.cuda.synchronize()
     err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err <= 2 * tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 1), (3, 17, 15, 64, 1), (2, 16, 16, 128, 2), (1, 24, 20, 128, 1), (5, 9, 11, 64, 2), (2, 64, 64, 64, 1)])
+def test_bottleneck_tail_fused(prec, cfg):
+    """3x3 conv + ReLU + 1x1 expansion + identity + ReLU in one launch (RGB ResNet-50 layer1 / layer2): BIT-identical to the two
+    stand-alone conv launches it replaces, and within storage-type tolerance of the torch fp32 ops."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, C1, stride = cfg
+    C3 = 4 * C1
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = _rnd(B, H, W, C1).cuda().to(tdt)
+    w2 = _rnd(C1, 3, 3, C1, scale=(9 * C1) ** -0.5 * 1.7, seed=1).cuda().to(tdt)
+    b2 = _rnd(C1, scale=0.2, seed=2).cuda()
+    w3 = _rnd(C3, 1, 1, C1, scale=C1 ** -0.5 * 1.7, seed=3).cuda().to(tdt)
+    b3 = _rnd(C3, scale=0.2, seed=4).cuda()
+    idt = _rnd(B, Ho, Wo, C3, seed=5).cuda().to(tdt)
+    y = torch.full((B, Ho, Wo, C3), float("nan"), device="cuda", dtype=tdt)
+    assert lib.hcm_op_bottleneck_tail(_p(x), _p(w2), _p(b2), _p(w3), _p(b3), _p(idt), _p(y), code, B, H, W, C1, stride, None) == 0
+    # the two launches it replaces
+    mid = torch.empty(B, Ho, Wo, C1, device="cuda", dtype=tdt)
+    y2 = torch.empty_like(y)
+    assert lib.hcm_op_conv2d(_p(x), _p(w2), _p(b2), None, _p(mid), code, B, H, W, C1, C1, 3, 3, stride, 1, L.ACT_RELU, None) == 0
+    assert lib.hcm_op_conv2d(_p(mid), _p(w3), _p(b3), _p(idt), _p(y2), code, B, Ho, Wo, C1, C3, 1, 1, 1, 0, L.ACT_RELU, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    # torch fp32 reference of the same ops (intermediate rounded to the storage type like the kernels do)
+    xr = x.float().permute(0, 3, 1, 2)
+    m = F.relu(F.conv2d(xr, w2.float().permute(0, 3, 1, 2), b2, stride=stride, padding=1)).to(tdt).float()
+    ref = F.relu(F.conv2d(m, w3.float().permute(0, 3, 1, 2), b3) + idt.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    err = (y.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < tol, err

@@ -15,10 +15,12 @@ for res in (None, r):
     run = lambda: lib.hcm_op_conv2d(x.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
                                     _lib.HCM_BF16, B, H, H, Cin, Cout, 1, 1, 1, 0, 1, None)
     for _ in range(3): assert run() == 0
+    for _ in range(int(os.environ.get('C3_WARM', '0'))): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): run()
+    NIT = int(os.environ.get('C3_ITERS', '20'))
+    for _ in range(NIT): run()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
+    us = e0.elapsed_time(e1) / NIT * 1e3
     mb = (x.numel() + y.numel() + (r.numel() if res is not None else 0)) * 2 / 1e6
-    print(f"force={os.environ.get('HCM_IGEMM_FORCE')} B={B} {Cin}->{Cout}@{H} residual={res is not None}: {us:.1f} us, {mb:.0f} MB -> {mb / us / 1e6 * 1e6 / 1e6:.2f} TB/s")
+    print(f"force={os.environ.get('HCM_IGEMM_FORCE')} B={B} {Cin}->{Cout}@{H} residual={res is not None}: {us:.1f} us, {mb:.0f} MB -> {mb / us:.2f} TB/s")

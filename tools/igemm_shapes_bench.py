@@ -80,8 +80,10 @@ for key, cnt in shapes.items():
         name = f"linear {KK}->{N}"
     for _ in range(3):
         assert run() == 0
+    for _ in range(60):
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10
+    n = 50
     e0.record()
     for _ in range(n):
         run()
@@ -89,12 +91,13 @@ for key, cnt in shapes.items():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     fl = 2.0 * M * N * KK
-    rows_out.append((us * cnt, name, M, N, KK, cnt, us, fl / us / 1e6))
+    mb = (x.numel() + w.numel() + y.numel()) * 2 / 1e6
+    rows_out.append((us * cnt, name, M, N, KK, cnt, us, fl / us / 1e6, mb / us))
 rows_out.sort(reverse=True)
 tot = sum(r[0] for r in rows_out)
 totf = sum(2.0 * r[2] * r[3] * r[4] * r[5] for r in rows_out)
 print(f"# igemm per-shape timing, B={B}, {prec}: total {tot/1e3:.3f} ms per step for {totf/1e9:.1f} GFLOP -> {totf/tot/1e6:.1f} TFLOP/s\n")
-print("| layer | M | N | K | count/step | us/launch | TFLOP/s | ms/step |")
-print("|---|---|---|---|---|---|---|---|")
-for t, name, M, N, KK, cnt, us, tf in rows_out:
-    print(f"| {name} | {M} | {N} | {KK} | {cnt} | {us:.1f} | {tf:.0f} | {t/1e3:.3f} |")
+print("| layer | M | N | K | count/step | us/launch | TFLOP/s | TB/s (x+w+y) | ms/step |")
+print("|---|---|---|---|---|---|---|---|---|")
+for t, name, M, N, KK, cnt, us, tf, tb in rows_out:
+    print(f"| {name} | {M} | {N} | {KK} | {cnt} | {us:.1f} | {tf:.0f} | {tb:.2f} | {t/1e3:.3f} |")
