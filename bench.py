@@ -63,40 +63,49 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
 
 
 def dominant_kernel_probe(batch):
-    """The dominant kernel is the 16-bit MFMA implicit GEMM `igemm_dma_kernel`; time it live with HIP events (torch events on
-    the launch stream) on the heaviest layer shape of the step: the 3x3/1 conv of ResNet-50 layer1 (64 -> 64 channels at
-    64x64).  In the step that layer is ONE launch over the hi|lo pair (2 groups x B images); the probe runs the same amount of
-    work as a single group over 2*B images (same tile count, same per-tile work), so its duration is comparable with the
-    2048x2-workgroup rows of `igemm_dma_kernel<bf16, 128, 64, 2, 8, ...>` in profiles/r1_kernel_trace_bench.md (64.8 us).
-    Per-launch algorithmic FLOPs = 2*M*N*K."""
+    """The kernel with the largest share of the step is the fused bottleneck tail of the RGB ResNet-50 pair, `bneck23_kernel`
+    (3x3 conv 64->64 + ReLU, 1x1 expansion 64->256 + identity + ReLU in one launch; three launches per step at 64x64, four at
+    32x32); time its layer1 shape live with HIP events (torch events on the launch stream).  In the step that layer is ONE
+    launch over the hi|lo pair (2 groups x B images); the probe runs the same amount of work as a single group over 2*B
+    images (same tile count, same per-tile work), so its duration is comparable with the bneck23_kernel<bf16,128,64> rows of
+    profiles/r1_kernel_trace_bench.md.  The launch is HBM-bound: algorithmic bytes = 2 B/elem * M * (64 in + 256 identity +
+    256 out); algorithmic FLOPs = 2 * M * (576*64 + 64*256)."""
     import ctypes as C
     import torch
     from robo_vln_amd import _lib
     lib = _lib.lib()
-    B, H, W, Cin, Cout = 2 * batch, 64, 64, 64, 64
-    x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
-    w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.05).to(torch.bfloat16)
-    b = torch.randn(Cout, device="cuda")
-    y = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    B, H, W, C1 = 2 * batch, 64, 64, 64
+    C3 = 4 * C1
+    bf = torch.bfloat16
+    x = torch.randn(B, H, W, C1, device="cuda").to(bf)
+    w2 = (torch.randn(C1, 3, 3, C1, device="cuda") * 0.05).to(bf)
+    b2 = torch.randn(C1, device="cuda")
+    w3 = (torch.randn(C3, 1, 1, C1, device="cuda") * 0.05).to(bf)
+    b3 = torch.randn(C3, device="cuda")
+    idt = torch.randn(B, H, W, C3, device="cuda").to(bf)
+    y = torch.empty_like(idt)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run():
-        rc = lib.hcm_op_conv2d(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), _lib.HCM_BF16, B, H, W, Cin, Cout,
-                               3, 3, 1, 1, _lib.ACT_RELU, st)
+        rc = lib.hcm_op_bottleneck_tail(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
+                                        y.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, st)
         assert rc == 0
-    for _ in range(3):
+    for _ in range(20):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = 50
     e0.record()
     for _ in range(n):
         run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * B * H * W * Cout * 9 * Cin
-    return {"kernel": "igemm_dma_kernel<bf16,128,64,2,8> conv3x3 64->64 @64x64, hi|lo pair workload (M=2*B*4096, N=64, K=576)", "us_per_launch": round(ms * 1e3, 2),
-            "tflops": round(flops / ms / 1e9, 1)}
+    M = B * H * W
+    flops = 2.0 * M * (9 * C1 * C1 + C1 * C3)
+    gbytes = 2.0 * M * (C1 + 2 * C3) / 1e9
+    return {"kernel": "bneck23_kernel<bf16,128,64>: conv3x3 64->64 + conv1x1 64->256 + identity @64x64, hi|lo pair workload (M=2*B*4096)",
+            "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": 8.0,
+            "frac": round(gbytes / ms / 8.0, 4), "tflops": round(flops / ms / 1e9, 1)}
 
 
 def main():

@@ -166,6 +166,15 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
     }
     const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
     const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
+    // The bias and the prefetched identity chunks must be IN registers before the pass loop.  Left to be waited for inside the
+    // conditionally executed passes, every pass gets an `s_waitcnt vmcnt(0)` (the skipped-pass path has nothing younger in
+    // flight, so the merged wait is 0) -- which also drains the previous pass's stores: four serialized HBM round trips per tile.
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bias8[e]));
+    if (have_pre) {
+#pragma unroll
+        for (int pass = 0; pass < NPRE; ++pass) asm volatile("" ::"v"(rpre[pass].x));
+    }
 #pragma unroll
     for (int pass = 0; pass < BM / RPP; ++pass) {
         const int r = pass * RPP + tid / TPR;
@@ -287,6 +296,13 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
     }
     const bool wide16 = sizeof(T) == 2 && !p.out_f32 && hi_ok && (p.ldy % 8 == 0);
     const bool wide16r = sizeof(T) == 2 && hi_ok && (p.ldr % 8 == 0);
+    // (see igemm_epilogue: keeps per-pass s_waitcnt vmcnt(0) -- and with it the drain of the previous pass's stores -- out of the loop)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bias8[e]));
+    if (have_pre) {
+#pragma unroll
+        for (int pass = 0; pass < NPRE; ++pass) asm volatile("" ::"v"(rpre[pass].x));
+    }
 #pragma unroll
   for (int slab = 0; slab < split; ++slab) {
     const int row0 = slab * slab_rows;
@@ -1085,7 +1101,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // Fused tail of a BatchNorm-folded ResNet bottleneck (RGB trunk, layer1 / layer2): the 3x3 conv (C1 -> C1, + bias + ReLU) and the
 // 1x1 expansion (C1 -> 4*C1, + bias + identity + ReLU) in ONE launch.  A workgroup computes BM pixels x all C1 channels of
-// the 3x3 conv (phase A: the ordinary LDS-DMA K loop, 2-deep ring), rounds them to the storage type exactly as the stand-alone conv's
+// the 3x3 conv (phase A: the ordinary LDS-DMA K loop, 3-deep ring), rounds them to the storage type exactly as the stand-alone conv's
 // epilogue would, and parks them in LDS in the swizzled operand layout -- the C1-channel intermediate never goes to HBM (a
 // full write + read of the M x C1 tensor per block, and one launch).  Phase B multiplies that tile with the expansion weights, 128
 // output channels at a time (weights streamed by LDS-DMA, the next slice requested while the current one's epilogue runs),
@@ -1211,12 +1227,14 @@ __global__ __launch_bounds__(512) void bneck23_kernel(BneckDev q) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (p.K + BK - 1) / BK;
+    constexpr int LPT = A_IT + B_IT;               // DMA instructions per wave per K tile
     stage(0, 0);
-    wait_vmcnt<0>();
+    if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const bool more = kt + 2 < nk;
+        if (more) stage(kt + 2, cur == 0 ? 2 : cur - 1);       // 3-deep ring: tile kt+2 goes where tile kt-1 was
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -1238,10 +1256,10 @@ __global__ __launch_bounds__(512) void bneck23_kernel(BneckDev q) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
         }
-        wait_vmcnt<0>();
+        if (more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();     // tile kt+1 complete; the one just requested may stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur ^= 1;
+        cur = cur == 2 ? 0 : cur + 1;
     }
     // the ring is dead (the loop ended with a barrier): first weight slice on its way, then park relu(conv + bias) as the
     // phase-B operand: row r, channel cc -> block cc / 64, 16-byte chunk (cc % 64) / 8 swizzled by the row like a DMA'd tile
@@ -1718,7 +1736,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     const int BM = b.C1 == 64 ? 128 : 64;
     const int KT1 = b.C1 / 64;
     size_t lds = (size_t)KT1 * BM * 128 + (size_t)KT1 * 128 * 128 + (size_t)(BM / 2) * (128 + 4) * 4;
-    const size_t ring = 2 * (size_t)(BM + b.C1) * 128;
+    const size_t ring = 3 * (size_t)(BM + b.C1) * 128;     // phase A: 3-deep ring
     if (ring > lds) lds = ring;
     const void* fn;
     if (dt == DT_BF16) fn = b.C1 == 64 ? reinterpret_cast<const void*>(bneck23_kernel<bf16, 128, 64>) : reinterpret_cast<const void*>(bneck23_kernel<bf16, 64, 128>);
