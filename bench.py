@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=int, default=40, help="untimed clock-ramp steps before the W warm-up steps (0 for profiler runs)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="environments per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--reuse-instruction", action="store_true",
@@ -203,7 +204,7 @@ def main():
     # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is
     step(mask0)
     step(mask1)
-    for _ in range(40):                                # ... and ~0.25 s of untimed steps so that the clocks have ramped (a fixed
+    for _ in range(args.prewarm):                      # ... and ~0.25 s of untimed steps so that the clocks have ramped (a fixed
         step(mask1)                                    # count: every rank must issue the same number of all-gathers)
     for _ in range(args.warmup):
         step(mask1)

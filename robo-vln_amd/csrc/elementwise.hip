@@ -120,20 +120,25 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
         const int ox = (int)(pix % Wo);
         const int oy = (int)((pix / Wo) % Ho);
         const int b = (int)(pix / ((size_t)Wo * Ho));
+        // branch-free: an out-of-range tap is clamped onto the nearest valid one, which lies inside the same window (pad 1, stride 2),
+        // so the maximum is unchanged -- and all nine 16-byte loads are in flight together
+        int iy[3], ix[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            iy[d] = min(max(2 * oy - 1 + d, 0), H - 1);
+            ix[d] = min(max(2 * ox - 1 + d, 0), W - 1);
+        }
+        float v[9][CH];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) ld_chunk(x + ((size_t)(b * H + iy[dy]) * W + ix[dx]) * C + c, v[dy * 3 + dx]);
         float m[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) m[j] = -3.0e38f;
-        for (int dy = 0; dy < 3; ++dy) {
-            const int iy = 2 * oy - 1 + dy;
-            if ((unsigned)iy >= (unsigned)H) continue;
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = 2 * ox - 1 + dx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                float v[CH];
-                ld_chunk(x + ((size_t)(b * H + iy) * W + ix) * C + c, v);
+        for (int j = 0; j < CH; ++j) {
+            m[j] = v[0][j];
 #pragma unroll
-                for (int j = 0; j < CH; ++j) m[j] = fmaxf(m[j], v[j]);
-            }
+            for (int t = 1; t < 9; ++t) m[j] = fmaxf(m[j], v[t][j]);
         }
         st_chunk(y + pix * C + c, m);
     }
