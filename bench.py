@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-kernel-probe", action="store_true", help="skip the dominant-kernel timing (profiler runs: keeps the trace to the step's own launches)")
     ap.add_argument("--prewarm", type=int, default=40, help="untimed clock-ramp steps before the W warm-up steps (0 for profiler runs)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="environments per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -241,11 +242,11 @@ def main():
                          "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
                          # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
                          # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
-                         "traffic": 18.51 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
+                         "traffic": 17.37 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
                          "traffic_source": "profiles/r1_pmc_traffic_bench.md",
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s",
                          # the same step seen from the memory side: measured HBM bytes per step / step time vs the 8 TB/s peak
-                         "hbm_view": ({"achieved_TBps": round(18.51 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(18.51 / ms / 8.0, 4)}
+                         "hbm_view": ({"achieved_TBps": round(17.37 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(17.37 / ms / 8.0, 4)}
                                       if B == 64 else None)},
         }
         if args.reuse_instruction:
@@ -254,7 +255,7 @@ def main():
             out["roofline"]["frac"] = round(out["roofline"]["achieved"] / (PEAK_BF16_TFLOPS * world), 4)
             out["roofline"]["basis"] = "cached-instruction variant: 36.9 - 13.83 (BERT) GFLOP per env-step x env-steps/s"
         out["config"]["hipgraph"] = {"enabled": not args.no_graph, "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
-        if args.precision == "bf16":
+        if args.precision == "bf16" and not args.no_kernel_probe:
             try:
                 out["roofline"]["dominant_kernel"] = dominant_kernel_probe(B)
             except Exception as e:       # never lose the headline number to the probe
