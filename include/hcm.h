@@ -220,6 +220,12 @@ int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, cons
  * resnet_encoders.py:196-225 TorchVisionResNet50). */
 int hcm_op_bottleneck_tail(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
                            void* y, int dtype, int B, int H, int W, int C1, int stride, void* stream);
+/* hcm_op_bottleneck_tail plus the NEXT block's 1x1 reduction from the output tile, still one launch:
+ *   o1 = relu(conv1x1(y, w1) + b1),  w1 [CN][4*C1], CN = 64 or 128 (128 only when C1 = 128 ... or C1 = 64), o1 (B,Ho,Wo,CN).
+ * Bit-identical to hcm_op_conv2d applied three times. */
+int hcm_op_bottleneck_tail_next(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
+                                void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int C1, int stride,
+                                int CN, void* stream);
 /* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,

@@ -552,6 +552,16 @@ int hcm_op_bottleneck_tail(const void* x, const void* w2, const float* b2, const
     b.B = B; b.H = H; b.W = W; b.C1 = C1; b.stride = stride;
     return op_rc(launch_bneck23(b, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_bottleneck_tail_next(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
+                                void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int C1, int stride,
+                                int CN, void* stream) {
+    Bneck23 b;
+    b.x = x; b.w2 = w2; b.b2 = b2; b.w3 = w3; b.b3 = b3; b.res = identity; b.y = y;
+    b.B = B; b.H = H; b.W = W; b.C1 = C1; b.stride = stride;
+    b.w1 = w1; b.b1 = b1; b.o1 = o1; b.CN = CN;
+    if (!w1) return HCM_ERR_ARG;
+    return op_rc(launch_bneck23(b, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
                      int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
                      int relu, void* stream) {

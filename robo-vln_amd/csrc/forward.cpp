@@ -193,13 +193,19 @@ struct Fwd {
         Act x{slot[1], B, Hp, Wp, c1};
         int xi = 1;
         int bidx = 0;
-        for (const BottleneckW& b : t.blocks) {
+        int pre = -1;          // slot already holding THIS block's 1x1 reduction output (computed by the previous block's fused launch)
+        for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
+            const BottleneckW& b = t.blocks[bi];
             int fr[3], nf = 0;
-            for (int i = 0; i < 4; ++i) if (i != xi) fr[nf++] = i;
+            if (pre >= 0) fr[nf++] = pre;
+            for (int i = 0; i < 4; ++i) if (i != xi && i != pre) fr[nf++] = i;
             void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
             const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
-            if (t.gn) conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
+            const bool have_o1 = pre >= 0;
+            pre = -1;
+            if (have_o1) {}
+            else if (t.gn) conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
             else conv(b.c1, x, sa, 1, 0, nullptr, ACT_RELU, x.H, x.W);
             // BN-folded trunks, 64 / 128 mid channels (layer1, layer2), 16-bit storage: 3x3 conv + 1x1 expansion + identity in ONE
             // launch, the mid tensor stays in LDS (igemm.hip: bneck23_kernel; bit-identical to the two launches)
@@ -212,6 +218,14 @@ struct Fwd {
                     conv(b.ds, x, sb, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);
                     idt = sb;
                 }
+                // ... and the NEXT block's 1x1 reduction from the output tile in the same launch (bneck231_kernel), into a slot this
+                // launch does not read: the block input's when the identity is the down-sample conv's output, else the spare one
+                static const bool no_next = getenv("HCM_NO_BNECK_NEXT") != nullptr;
+                const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
+                const bool next = nb && !no_next && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
+                                  nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
+                                  (nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128));
+                const int pre_slot = b.has_ds ? xi : fr[1];
                 if (!dry) {
                     Bneck23 q;
                     q.x = sa; q.w2 = b.c2.w; q.b2 = b.c2.bias; q.w3 = b.c3.w; q.b3 = b.c3.bias; q.res = idt; q.y = sc;
@@ -221,8 +235,13 @@ struct Fwd {
                         q.groups = b.c2.groups; q.g_x = b.c2.Cin; q.g_w2 = (long long)b.c2.Cout * b.c2.Kp; q.g_b2 = b.c2.Cout;
                         q.g_w3 = (long long)b.c3.Cout * b.c3.Kp; q.g_b3 = b.c3.Cout; q.g_y = b.c3.Cout;
                     }
+                    if (next) {
+                        q.w1 = nb->c1.w; q.b1 = nb->c1.bias; q.o1 = slot[pre_slot]; q.CN = nb->c1.Cout; q.ldo = CO(nb->c1);
+                        if (b.c2.groups > 1) { q.g_w1 = (long long)nb->c1.Cout * nb->c1.Kp; q.g_b1 = nb->c1.Cout; q.g_o1 = nb->c1.Cout; }
+                    }
                     ck(launch_bneck23(q, b.c2.dt, s), "bottleneck tail");
                 }
+                if (next) pre = pre_slot;
                 x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
                 xi = fr[2];
                 ++bidx;

@@ -263,7 +263,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
 // whole tile).  A separate function: a run-time slab loop in the shared epilogue costs every kernel ~60 VGPRs.
 template <typename T, int BM, int BN, int NW, int WMc, int NPRE, int SPLIT>
 __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], char* smem, int m0, int n0,
-                                               int tid, int wm, int wn, int fr, int fg, const uint4 (&rpre)[NPRE], bool have_pre) {
+                                               int tid, int wm, int wn, int fr, int fg, const uint4 (&rpre)[NPRE], bool have_pre,
+                                                     char* ytile = nullptr) {
     constexpr int WNc = NW / WMc;          // waves along the channel axis (WMc along the pixel axis)
     constexpr int TM = BM / WMc / 16;
     constexpr int TN = BN / WNc / 16;
@@ -417,6 +418,12 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
                 T* yp = reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n;
                 if (wide16) {
                     st_chunk(yp, v);
+                    if (ytile) {        // the same 16 bytes, parked as an MFMA operand row chunk (swizzled like a DMA'd tile; BN <= 64)
+                        T o8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) Tr<T>::st(&o8[e], v[e]);
+                        *reinterpret_cast<uint4*>(ytile + r * 128 + (((c8 >> 3) ^ (r & 7)) << 4)) = *reinterpret_cast<const uint4*>(o8);
+                    }
                 } else {
                     T o4[4];
 #pragma unroll
@@ -1326,6 +1333,285 @@ __global__ __launch_bounds__(512) void bneck23_kernel(BneckDev q) {
 }
 
 
+
+// bneck23_kernel plus the NEXT block's 1x1 reduction (4*C1 -> CN channels, + bias + ReLU) computed from the output tile while it is
+// still on the CU: that conv would otherwise be a launch of its own whose only HBM-heavy operand is the map this kernel has just
+// written.  Phase B runs in 64-channel output slices here: the slice's final (rounded) values are also parked in LDS as an
+// MFMA operand block, and acc3 += slice x W1[:, slice] after every slice -- the same k order as the stand-alone conv, whose input
+// is exactly those rounded values: bit-identical.  LDS: parked tile + weight slice + image slab + slice block + W1 slice = 65-74 KB.
+struct Bneck231Dev {
+    BneckDev t;
+    const char* w1; const float* b1; char* o1;     // next block's reduction: w1 [CN][4*C1], output [M][ldo]
+    int ldo; unsigned w1_bytes;
+    long long g_w1, g_b1, g_o1;
+};
+
+template <typename T, int BM, int C1, int CN>
+__global__ __launch_bounds__(512) void bneck231_kernel(Bneck231Dev qq) {
+    BneckDev& q = qq.t;
+    constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
+    constexpr int TM = BM / WMc / 16;
+    constexpr int TN1 = C1 / WNc / 16;
+    constexpr int TN2 = SW / WNc / 16;             // 1: 16 of the slice's 64 channels per wave
+    constexpr int TN3 = CN / WNc / 16;             // reduction output: CN / 4 channels per wave
+    constexpr int A_IT = BM / 8 / NW, B_IT = C1 / 8 / NW;
+    constexpr int TILE_BYTES = (BM + C1) * 128;
+    constexpr int KT1 = C1 / BK;
+    constexpr int NT = 4 * C1 / SW;
+    constexpr int T_BYTES = KT1 * BM * 128, W3_BYTES = KT1 * SW * 128;
+    constexpr int E_RPP = 64 * NW / (SW / 8), E_NP = BM / E_RPP;          // 64 rows per pass
+    constexpr int ESPLIT = BM / E_RPP;                                     // image slab = one pass = 64 rows
+    constexpr int IMG_BYTES = 64 * (128 + 4) * 4 / 2 + 1024;               // >= 64 x (64+4) f32 and >= the reduction's slabs
+    constexpr int YS_OFF = T_BYTES + W3_BYTES + IMG_BYTES, YS_BYTES = BM * 128;
+    constexpr int W1_OFF = YS_OFF + YS_BYTES;
+    constexpr int R_RPP = 64 * NW / (CN / 8), R_SPLIT = BM / R_RPP;        // reduction epilogue: image slabs of one pass
+    static_assert(A_IT >= 1 && B_IT >= 1 && TN1 >= 1 && TN3 >= 1 && sizeof(T) == 2, "bneck231 tile");
+    static_assert(R_RPP * (CN + 4) * 4 <= IMG_BYTES && 64 * (SW + 4) * 4 <= IMG_BYTES, "image slab");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    IGemmDev& p = q.a;
+    if (p.groups > 1) {
+        const long long g = blockIdx.y;
+        p.x += g * p.g_x * 2;
+        p.w += g * p.g_w * 2;
+        p.bias += g * p.g_b;
+        q.w3 += g * q.g_w3 * 2;
+        q.b3 += g * q.g_b3;
+        q.res += g * q.g_y3 * 2;
+        q.y += g * q.g_y3 * 2;
+        qq.w1 += g * qq.g_w1 * 2;
+        qq.b1 += g * qq.g_b1;
+        qq.o1 += g * qq.g_o1 * 2;
+    }
+    const int m0 = blockIdx.x * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNc, wn = wave % WNc;
+    const int rin = lane >> 3;
+    const int c = (lane & 7) ^ rin;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    uint4 rpre[NT][E_NP];
+    {
+        const int n = (tid % (SW / 8)) * 8;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pass = 0; pass < E_NP; ++pass) {
+                const int m = m0 + pass * E_RPP + tid / (SW / 8);
+                rpre[nt][pass] = make_uint4(0u, 0u, 0u, 0u);
+                if (m < p.M) rpre[nt][pass] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + n);
+            }
+    }
+
+    int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + rin;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_pix[i] = b * p.H * p.W;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+        } else {
+            a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+        }
+    }
+    const v4i_t rx = make_rsrc(p.x, p.x_bytes);
+    const v4i_t rw = make_rsrc(p.w, p.w_bytes);
+    const v4i_t rw3 = make_rsrc(q.w3, q.w3_bytes);
+    const v4i_t rw1 = make_rsrc(qq.w1, qq.w1_bytes);
+
+    auto stage = [&](int kt, int buf) {
+        const unsigned sa = lds_base + buf * TILE_BYTES;
+        const unsigned sb = sa + BM * 128;
+        const int k = kt * BK + c * CH;
+        const int khw = k >> p.cin_shift;
+        const int ci = k & (p.Cin - 1);
+        const int kh = (khw * p.kw_rcp) >> 16;
+        const int kw = khw - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * 2u;
+            dma16(sa + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = (wave + NW * i) * 8 + rin;
+            const unsigned off = (unsigned)(n * p.Kp + k) * 2u;
+            dma16(sb + (wave + NW * i) * 1024, (k < p.Kp) ? off : 0xFFFFFFFFu, rw);
+        }
+    };
+    // slice nt: expansion weights (KT1 blocks of [64 channels][64 k]) and the reduction's K slice ([CN channels][64 k])
+    auto stage_w3 = [&](int nt) {
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+            const int n = nt * SW + wave * 8 + rin;                        // 64 rows = 8 waves x 8
+            const unsigned off = (unsigned)(n * q.Kp3 + kt * BK + c * CH) * 2u;
+            dma16(lds_base + T_BYTES + kt * (SW * 128) + wave * 1024, off, rw3);
+        }
+    };
+    auto stage_w1 = [&](int nt) {
+#pragma unroll
+        for (int i = 0; i < CN / 8 / NW; ++i) {
+            const int n = (wave + NW * i) * 8 + rin;
+            const unsigned off = (unsigned)(n * (4 * C1) + nt * SW + c * CH) * 2u;
+            dma16(lds_base + W1_OFF + (wave + NW * i) * 1024, off, rw1);
+        }
+    };
+
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+    // ---- phase A: 3x3 conv, BM x C1 (as in bneck23_kernel)
+    f32x4 acc1[TN1][TM];
+#pragma unroll
+    for (int i = 0; i < TN1; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + BK - 1) / BK;
+    constexpr int LPT = A_IT + B_IT;
+    stage(0, 0);
+    if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[TM], wb[TN1];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / WMc) + j * 16 + fr;
+                xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i) {
+                const int r = wn * (C1 / WNc) + i * 16 + fr;
+                wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
+        }
+        if (more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    stage_w3(0);
+    stage_w1(0);
+#pragma unroll
+    for (int i = 0; i < TN1; ++i) {
+        const int cc = wn * (C1 / WNc) + i * 16 + fg * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cc);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * (BM / WMc) + j * 16 + fr;
+            T o4[4];
+            Tr<T>::st(&o4[0], fmaxf(acc1[i][j][0] + b4.x, 0.f));
+            Tr<T>::st(&o4[1], fmaxf(acc1[i][j][1] + b4.y, 0.f));
+            Tr<T>::st(&o4[2], fmaxf(acc1[i][j][2] + b4.z, 0.f));
+            Tr<T>::st(&o4[3], fmaxf(acc1[i][j][3] + b4.w, 0.f));
+            char* dst = smem + (cc >> 6) * (BM * 128) + r * 128 + ((((cc & 63) >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2;
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o4);
+        }
+    }
+    // ---- phase B: NT slices of BM x 64 output channels, each followed by its K slice of the next block's reduction
+    IGemmDev pe = p;
+    pe.bias = q.b3; pe.res = q.res; pe.y = q.y; pe.N = q.C3; pe.ldy = q.ldy3; pe.ldr = q.ldr3;
+    pe.act = ACT_RELU; pe.out_f32 = 0; pe.gn_cg = 0;
+    f32x4 acc3[TN3][TM];
+#pragma unroll
+    for (int i = 0; i < TN3; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        wait_vmcnt<0>();                                   // this slice's weights (both matrices) have landed
+        __syncthreads();                                   // ... for every wave; parked tile complete; image and slice block free
+        f32x4 acc2[TN2][TM];
+#pragma unroll
+        for (int i = 0; i < TN2; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) {
+            const char* sa = smem + kt * (BM * 128);
+            const char* sb = smem + T_BYTES + kt * (SW * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TM], wb[TN2];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int r = wm * (BM / WMc) + j * 16 + fr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i) {
+                    const int r = wn * (SW / WNc) + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<T>::run(acc2[i][j], wb[i], xa[j]);
+            }
+        }
+        // epilogue of the slice: to HBM and, rounded, into the slice block (its first barrier also says: every wave is done with the weights)
+        igemm_epilogue_split<T, BM, SW, NW, WMc, E_NP, ESPLIT>(pe, acc2, smem + T_BYTES + W3_BYTES, m0, nt * SW, tid, wm, wn, fr, fg, rpre[nt], true,
+                                                               smem + YS_OFF);
+        if (nt + 1 < NT) stage_w3(nt + 1);                 // (after the epilogue's barriers: the expansion weights are dead)
+        __syncthreads();                                   // slice block complete
+        {
+            const char* sa = smem + YS_OFF;
+            const char* sb = smem + W1_OFF;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TM], wb[TN3];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int r = wm * (BM / WMc) + j * 16 + fr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN3; ++i) {
+                    const int r = wn * (CN / WNc) + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN3; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<T>::run(acc3[i][j], wb[i], xa[j]);
+            }
+        }
+        if (nt + 1 < NT) {
+            __syncthreads();                               // every wave has read this K slice of the reduction weights
+            stage_w1(nt + 1);
+        }
+    }
+    // the reduction's own epilogue (bias + ReLU), through the same image region
+    IGemmDev pr = p;
+    pr.bias = qq.b1; pr.res = nullptr; pr.y = qq.o1; pr.N = CN; pr.ldy = qq.ldo; pr.ldr = qq.ldo;
+    pr.act = ACT_RELU; pr.out_f32 = 0; pr.gn_cg = 0;
+    __syncthreads();
+    const uint4 none[1] = {make_uint4(0u, 0u, 0u, 0u)};
+    igemm_epilogue_split<T, BM, CN, NW, WMc, 1, R_SPLIT>(pr, acc3, smem + T_BYTES + W3_BYTES, m0, 0, tid, wm, wn, fr, fg, none, false);
+}
+
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset) {
     std::vector<unsigned long long> h((size_t)kProfSlots * 8);
     hipError_t e = hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_igemm_prof), h.size() * 8);
@@ -1735,6 +2021,28 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     q.g_w3 = b.g_w3; q.g_b3 = b.g_b3; q.g_y3 = b.g_y;
     const int BM = b.C1 == 64 ? 128 : 64;
     const int KT1 = b.C1 / 64;
+    if (b.w1) {
+        if (!b.b1 || !b.o1 || (b.CN != 64 && b.CN != 128) || (b.C1 == 128 && b.CN != 128)) return hipErrorInvalidValue;
+        const int ldo = b.ldo ? b.ldo : b.CN;
+        if (ldo % 8) return hipErrorInvalidValue;
+        Bneck231Dev qq;
+        qq.t = q;
+        qq.w1 = (const char*)b.w1; qq.b1 = b.b1; qq.o1 = (char*)b.o1; qq.ldo = ldo;
+        qq.w1_bytes = (unsigned)((size_t)b.CN * C3 * 2);
+        qq.g_w1 = b.g_w1; qq.g_b1 = b.g_b1; qq.g_o1 = b.g_o1;
+        size_t lds1 = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128;
+        const size_t ring1 = 3 * (size_t)(BM + b.C1) * 128;
+        if (ring1 > lds1) lds1 = ring1;
+        const void* f1;
+        if (dt == DT_BF16) f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 128, 128>)
+                              : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 128>);
+        else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 128, 128>)
+                : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 128>);
+        hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess) return e1;
+        void* a1[] = {&qq};
+        return hipLaunchKernel(f1, dim3((d.M + BM - 1) / BM, d.groups), dim3(512), a1, lds1, s);
+    }
     size_t lds = (size_t)KT1 * BM * 128 + (size_t)KT1 * 128 * 128 + (size_t)(BM / 2) * (128 + 4) * 4;
     const size_t ring = 3 * (size_t)(BM + b.C1) * 128;     // phase A: 3-deep ring
     if (ring > lds) lds = ring;

@@ -52,6 +52,11 @@ struct Bneck23 {
     int B = 1, H = 1, W = 1, C1 = 0, xC = 0, stride = 1, ldy = 0, ldr = 0;
     int groups = 1;              // hi|lo pair: element offsets per group
     long long g_x = 0, g_w2 = 0, g_b2 = 0, g_w3 = 0, g_b3 = 0, g_y = 0;
+    // optional: the NEXT block's 1x1 reduction relu(y @ w1^T + b1) from the output tile in the same launch (bneck231_kernel):
+    // w1 [CN][4*C1], CN = 64 or 128, o1 [M][ldo]
+    const void* w1 = nullptr; const float* b1 = nullptr; void* o1 = nullptr;
+    int CN = 0, ldo = 0;
+    long long g_w1 = 0, g_b1 = 0, g_o1 = 0;
 };
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 

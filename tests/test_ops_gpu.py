@@ -322,3 +322,36 @@ def test_bottleneck_tail_fused(prec, cfg):
     ref = F.relu(F.conv2d(m, w3.float().permute(0, 3, 1, 2), b3) + idt.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     err = (y.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
     assert err < tol, err
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 1, 64), (3, 17, 15, 64, 1, 64), (2, 16, 16, 128, 2, 128), (1, 24, 20, 128, 1, 128), (2, 16, 16, 64, 1, 128),
+                                 (5, 9, 11, 64, 2, 64), (2, 64, 64, 64, 1, 64)])
+def test_bottleneck_tail_next_fused(prec, cfg):
+    """Bottleneck tail + the next block's 1x1 reduction in one launch: both outputs BIT-identical to the three stand-alone convs."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, C1, stride, CN = cfg
+    C3 = 4 * C1
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = _rnd(B, H, W, C1).cuda().to(tdt)
+    w2 = _rnd(C1, 3, 3, C1, scale=(9 * C1) ** -0.5 * 1.7, seed=1).cuda().to(tdt)
+    b2 = _rnd(C1, scale=0.2, seed=2).cuda()
+    w3 = _rnd(C3, 1, 1, C1, scale=C1 ** -0.5 * 1.7, seed=3).cuda().to(tdt)
+    b3 = _rnd(C3, scale=0.2, seed=4).cuda()
+    w1 = _rnd(CN, 1, 1, C3, scale=C3 ** -0.5 * 1.7, seed=6).cuda().to(tdt)
+    b1 = _rnd(CN, scale=0.2, seed=7).cuda()
+    idt = _rnd(B, Ho, Wo, C3, seed=5).cuda().to(tdt)
+    y = torch.full((B, Ho, Wo, C3), float("nan"), device="cuda", dtype=tdt)
+    o1 = torch.full((B, Ho, Wo, CN), float("nan"), device="cuda", dtype=tdt)
+    assert lib.hcm_op_bottleneck_tail_next(_p(x), _p(w2), _p(b2), _p(w3), _p(b3), _p(idt), _p(y), _p(w1), _p(b1), _p(o1), code, B, H, W, C1,
+                                           stride, CN, None) == 0
+    mid = torch.empty(B, Ho, Wo, C1, device="cuda", dtype=tdt)
+    y2 = torch.empty_like(y)
+    o2 = torch.empty_like(o1)
+    assert lib.hcm_op_conv2d(_p(x), _p(w2), _p(b2), None, _p(mid), code, B, H, W, C1, C1, 3, 3, stride, 1, L.ACT_RELU, None) == 0
+    assert lib.hcm_op_conv2d(_p(mid), _p(w3), _p(b3), _p(idt), _p(y2), code, B, Ho, Wo, C1, C3, 1, 1, 1, 0, L.ACT_RELU, None) == 0
+    assert lib.hcm_op_conv2d(_p(y2), _p(w1), _p(b1), None, _p(o2), code, B, Ho, Wo, C3, CN, 1, 1, 1, 0, L.ACT_RELU, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
