@@ -224,7 +224,7 @@ struct Fwd {
                 const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
                 const bool next = nb && !no_next && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
                                   nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
-                                  (nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128));
+                                  ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
                 const int pre_slot = b.has_ds ? xi : fr[1];
                 if (!dry) {
                     Bneck23 q;

@@ -1347,7 +1347,7 @@ struct Bneck231Dev {
 };
 
 template <typename T, int BM, int C1, int CN>
-__global__ __launch_bounds__(512) void bneck231_kernel(Bneck231Dev qq) {
+__global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     // 4 waves per SIMD = two workgroups per CU
     BneckDev& q = qq.t;
     constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
     constexpr int TM = BM / WMc / 16;

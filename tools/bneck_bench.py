@@ -20,7 +20,7 @@ for B, H, C1, stride in cases:
     def two():
         lib.hcm_op_conv2d(P(x), P(w2), P(b2), None, P(mid), _lib.HCM_BF16, B, H, H, C1, C1, 3, 3, stride, 1, 1, None)
         return lib.hcm_op_conv2d(P(mid), P(w3), P(b3), P(r), P(y), _lib.HCM_BF16, B, Ho, Ho, C1, C3, 1, 1, 1, 0, 1, None)
-    CN = C1
+    CN = int(os.environ.get('BNECK_CN', C1))
     w1 = (torch.randn(CN, 1, 1, C3, device="cuda") * 0.05).to(tdt); b1 = torch.randn(CN, device="cuda"); o1 = torch.empty(B, Ho, Ho, CN, device="cuda", dtype=tdt)
     fused3 = lambda: lib.hcm_op_bottleneck_tail_next(P(x), P(w2), P(b2), P(w3), P(b3), P(r), P(y), P(w1), P(b1), P(o1), _lib.HCM_BF16, B, H, H, C1, stride, CN, None)
     def three():
