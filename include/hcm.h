@@ -226,6 +226,12 @@ int hcm_op_bottleneck_tail(const void* x, const void* w2, const float* b2, const
 int hcm_op_bottleneck_tail_next(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* identity,
                                 void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int C1, int stride,
                                 int CN, void* stream);
+/* A ResNet stage's FIRST bottleneck (C1 = 64 mid channels, 64-channel block input xd): as hcm_op_bottleneck_tail_next with CN = 64,
+ * but the identity is the block's own 1x1 down-sample conv, folded into the expansion GEMM: w3ds [256][128] = [W3 | Wds],
+ * b3ds = b3 + bds;  y = relu(conv1x1(t, W3) + conv1x1_stride(xd, Wds) + b3ds),  t = relu(conv3x3_stride(x, w2) + b2). */
+int hcm_op_bottleneck_tail_ds(const void* x, const void* w2, const float* b2, const void* w3ds, const float* b3ds, const void* xd,
+                              void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int stride,
+                              void* stream);
 /* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,

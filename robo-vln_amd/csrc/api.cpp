@@ -562,6 +562,17 @@ int hcm_op_bottleneck_tail_next(const void* x, const void* w2, const float* b2, 
     if (!w1) return HCM_ERR_ARG;
     return op_rc(launch_bneck23(b, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_bottleneck_tail_ds(const void* x, const void* w2, const float* b2, const void* w3ds, const float* b3ds, const void* xd,
+                              void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int stride,
+                              void* stream) {
+    if (!xd || !w1) return HCM_ERR_ARG;
+    Bneck23 b;
+    b.x = x; b.w2 = w2; b.b2 = b2; b.w3 = w3ds; b.b3 = b3ds; b.y = y;
+    b.B = B; b.H = H; b.W = W; b.C1 = 64; b.stride = stride;
+    b.w1 = w1; b.b1 = b1; b.o1 = o1; b.CN = 64;
+    b.xd = xd; b.xdC = 64; b.KD = 1;
+    return op_rc(launch_bneck23(b, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_conv2d_gn(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
                      int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
                      int relu, void* stream) {

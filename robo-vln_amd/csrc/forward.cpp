@@ -214,18 +214,24 @@ struct Fwd {
                 b.c2.Cin == b.c2.Cout && b.c2.Kp == 9 * b.c2.Cin && b.c3.Cout == 4 * b.c2.Cout && b.c3.Kp == b.c2.Cout && b.c2.bias && b.c3.bias &&
                 b.c3.groups == b.c2.groups) {
                 const void* idt = x.p;
-                if (b.has_ds) {
+                static const bool no_next = getenv("HCM_NO_BNECK_NEXT") != nullptr;
+                static const bool no_dsfold = getenv("HCM_NO_BNECK_DSFOLD") != nullptr;
+                const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
+                const bool next = nb && !no_next && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
+                                  nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
+                                  ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
+                // layer1's first block: its 1x1 down-sample conv (64 -> 256, same stride) rides in the expansion GEMM as 64 more K columns
+                // ([W3 | Wds], bias b3 + bds): no down-sample launch, no identity tensor.  One rounding instead of two on that path, so
+                // not bit-identical to the separate launches (closer to the fp32 oracle)
+                const bool dsfold = b.has_ds && !no_dsfold && next && b.c3ds.w && b.c2.Cout == 64 && nb->c1.Cout == 64 && b.ds.Cin == 64 &&
+                                    b.c3ds.Kp == 128 && b.c3ds.groups == b.c2.groups && x.C == b.c2.groups * 64;
+                if (b.has_ds && !dsfold) {
                     conv(b.ds, x, sb, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);
                     idt = sb;
                 }
                 // ... and the NEXT block's 1x1 reduction from the output tile in the same launch (bneck231_kernel), into a slot this
                 // launch does not read: the block input's when the identity is the down-sample conv's output, else the spare one
-                static const bool no_next = getenv("HCM_NO_BNECK_NEXT") != nullptr;
-                const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
-                const bool next = nb && !no_next && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
-                                  nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
-                                  ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
-                const int pre_slot = b.has_ds ? xi : fr[1];
+                const int pre_slot = (b.has_ds && !dsfold) ? xi : fr[1];
                 if (!dry) {
                     Bneck23 q;
                     q.x = sa; q.w2 = b.c2.w; q.b2 = b.c2.bias; q.w3 = b.c3.w; q.b3 = b.c3.bias; q.res = idt; q.y = sc;
@@ -238,6 +244,11 @@ struct Fwd {
                     if (next) {
                         q.w1 = nb->c1.w; q.b1 = nb->c1.bias; q.o1 = slot[pre_slot]; q.CN = nb->c1.Cout; q.ldo = CO(nb->c1);
                         if (b.c2.groups > 1) { q.g_w1 = (long long)nb->c1.Cout * nb->c1.Kp; q.g_b1 = nb->c1.Cout; q.g_o1 = nb->c1.Cout; }
+                    }
+                    if (dsfold) {
+                        q.w3 = b.c3ds.w; q.b3 = b.c3ds.bias; q.res = nullptr;
+                        q.xd = x.p; q.xdC = x.C; q.KD = 1;
+                        if (b.c2.groups > 1) { q.g_w3 = (long long)b.c3ds.Cout * b.c3ds.Kp; q.g_xd = 64; }
                     }
                     ck(launch_bneck23(q, b.c2.dt, s), "bottleneck tail");
                 }

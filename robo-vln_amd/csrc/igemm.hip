@@ -1344,9 +1344,12 @@ struct Bneck231Dev {
     const char* w1; const float* b1; char* o1;     // next block's reduction: w1 [CN][4*C1], output [M][ldo]
     int ldo; unsigned w1_bytes;
     long long g_w1, g_b1, g_o1;
+    // KD > 0: the block's 1x1 down-sample conv folded into the expansion GEMM (weights K-concatenated [W3 | Wds], bias b3 + bds): the
+    // block input xd [B,H,W,*] (KD*64 channels at pixel stride xdC) is a second operand block, no identity tensor exists
+    const char* xd; int xdC; unsigned xd_bytes; long long g_xd;
 };
 
-template <typename T, int BM, int C1, int CN>
+template <typename T, int BM, int C1, int CN, int KD = 0>
 __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     // 4 waves per SIMD = two workgroups per CU
     BneckDev& q = qq.t;
     constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
@@ -1358,7 +1361,8 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     constexpr int TILE_BYTES = (BM + C1) * 128;
     constexpr int KT1 = C1 / BK;
     constexpr int NT = 4 * C1 / SW;
-    constexpr int T_BYTES = KT1 * BM * 128, W3_BYTES = KT1 * SW * 128;
+    constexpr int KTB = KT1 + KD;                  // K blocks of phase B: the parked tile, then the down-sample input
+    constexpr int T_BYTES = KTB * BM * 128, W3_BYTES = KTB * SW * 128;
     constexpr int E_RPP = 64 * NW / (SW / 8), E_NP = BM / E_RPP;          // 64 rows per pass
     constexpr int ESPLIT = BM / E_RPP;                                     // image slab = one pass = 64 rows
     constexpr int IMG_BYTES = 64 * (128 + 4) * 4 / 2 + 1024;               // >= 64 x (64+4) f32 and >= the reduction's slabs
@@ -1382,6 +1386,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
         qq.w1 += g * qq.g_w1 * 2;
         qq.b1 += g * qq.g_b1;
         qq.o1 += g * qq.g_o1 * 2;
+        if (KD) qq.xd += g * qq.g_xd * 2;
     }
     const int m0 = blockIdx.x * BM;
     const int tid = threadIdx.x;
@@ -1392,8 +1397,8 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     const int c = (lane & 7) ^ rin;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    uint4 rpre[NT][E_NP];
-    {
+    uint4 rpre[NT][E_NP] = {};
+    if constexpr (KD == 0) {
         const int n = (tid % (SW / 8)) * 8;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1426,6 +1431,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     const v4i_t rw = make_rsrc(p.w, p.w_bytes);
     const v4i_t rw3 = make_rsrc(q.w3, q.w3_bytes);
     const v4i_t rw1 = make_rsrc(qq.w1, qq.w1_bytes);
+    const v4i_t rxd = make_rsrc(qq.xd, KD ? qq.xd_bytes : 0u);
 
     auto stage = [&](int kt, int buf) {
         const unsigned sa = lds_base + buf * TILE_BYTES;
@@ -1450,9 +1456,19 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
         }
     };
     // slice nt: expansion weights (KT1 blocks of [64 channels][64 k]) and the reduction's K slice ([CN channels][64 k])
+    // the 1x1 down-sample conv's input rows: pixel (oy * stride, ox * stride) of the block input, KD blocks of 64 channels
+    auto stage_xd = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < KD; ++kt)
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const unsigned off = (unsigned)((a_pix[i] + (a_iy0[i] + p.pad) * p.W + a_ix0[i] + p.pad) * qq.xdC + kt * BK + c * CH) * 2u;
+                dma16(lds_base + (KT1 + kt) * (BM * 128) + (wave + NW * i) * 1024, a_pix[i] >= 0 ? off : 0xFFFFFFFFu, rxd);
+            }
+    };
     auto stage_w3 = [&](int nt) {
 #pragma unroll
-        for (int kt = 0; kt < KT1; ++kt) {
+        for (int kt = 0; kt < KTB; ++kt) {
             const int n = nt * SW + wave * 8 + rin;                        // 64 rows = 8 waves x 8
             const unsigned off = (unsigned)(n * q.Kp3 + kt * BK + c * CH) * 2u;
             dma16(lds_base + T_BYTES + kt * (SW * 128) + wave * 1024, off, rw3);
@@ -1512,6 +1528,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     }
     stage_w3(0);
     stage_w1(0);
+    if constexpr (KD > 0) stage_xd();
 #pragma unroll
     for (int i = 0; i < TN1; ++i) {
         const int cc = wn * (C1 / WNc) + i * 16 + fg * 4;
@@ -1530,7 +1547,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     }
     // ---- phase B: NT slices of BM x 64 output channels, each followed by its K slice of the next block's reduction
     IGemmDev pe = p;
-    pe.bias = q.b3; pe.res = q.res; pe.y = q.y; pe.N = q.C3; pe.ldy = q.ldy3; pe.ldr = q.ldr3;
+    pe.bias = q.b3; pe.res = KD ? nullptr : q.res; pe.y = q.y; pe.N = q.C3; pe.ldy = q.ldy3; pe.ldr = q.ldr3;
     pe.act = ACT_RELU; pe.out_f32 = 0; pe.gn_cg = 0;
     f32x4 acc3[TN3][TM];
 #pragma unroll
@@ -1547,7 +1564,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < KT1; ++kt) {
+        for (int kt = 0; kt < KTB; ++kt) {
             const char* sa = smem + kt * (BM * 128);
             const char* sb = smem + T_BYTES + kt * (SW * 128);
 #pragma unroll
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
             }
         }
         // epilogue of the slice: to HBM and, rounded, into the slice block (its first barrier also says: every wave is done with the weights)
-        igemm_epilogue_split<T, BM, SW, NW, WMc, E_NP, ESPLIT>(pe, acc2, smem + T_BYTES + W3_BYTES, m0, nt * SW, tid, wm, wn, fr, fg, rpre[nt], true,
+        igemm_epilogue_split<T, BM, SW, NW, WMc, E_NP, ESPLIT>(pe, acc2, smem + T_BYTES + W3_BYTES, m0, nt * SW, tid, wm, wn, fr, fg, rpre[nt], KD == 0,
                                                                smem + YS_OFF);
         if (nt + 1 < NT) stage_w3(nt + 1);                 // (after the epilogue's barriers: the expansion weights are dead)
         __syncthreads();                                   // slice block complete
@@ -1995,7 +2012,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
 
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
-    if ((b.C1 != 64 && b.C1 != 128) || !b.res || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
+    if ((b.C1 != 64 && b.C1 != 128) || (!b.res && !b.xd) || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
+    if (b.xd && (b.C1 != 64 || b.KD != 1 || !b.w1 || b.CN != 64 || (b.xdC % 8))) return hipErrorInvalidValue;   // the one folded-down-sample shape built
     const int C3 = 4 * b.C1;
     const int ldy = b.ldy ? b.ldy : C3, ldr = b.ldr ? b.ldr : C3, xC = b.xC ? b.xC : b.C1;
     if ((ldy % 8) || (ldr % 8) || (xC % 8)) return hipErrorInvalidValue;
@@ -2017,7 +2035,8 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
         d.x_bytes = (unsigned)xb; d.w_bytes = (unsigned)wb; q.w3_bytes = (unsigned)w3b;
     }
     q.w3 = (const char*)b.w3; q.b3 = b.b3; q.res = (const char*)b.res; q.y = (char*)b.y;
-    q.C3 = C3; q.Kp3 = b.C1; q.ldy3 = ldy; q.ldr3 = ldr;
+    q.C3 = C3; q.Kp3 = b.C1 + (b.xd ? b.KD * 64 : 0); q.ldy3 = ldy; q.ldr3 = ldr;
+    q.w3_bytes = (unsigned)((size_t)C3 * q.Kp3 * 2);
     q.g_w3 = b.g_w3; q.g_b3 = b.g_b3; q.g_y3 = b.g_y;
     const int BM = b.C1 == 64 ? 128 : 64;
     const int KT1 = b.C1 / 64;
@@ -2030,6 +2049,21 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
         qq.w1 = (const char*)b.w1; qq.b1 = b.b1; qq.o1 = (char*)b.o1; qq.ldo = ldo;
         qq.w1_bytes = (unsigned)((size_t)b.CN * C3 * 2);
         qq.g_w1 = b.g_w1; qq.g_b1 = b.g_b1; qq.g_o1 = b.g_o1;
+        qq.xd = nullptr; qq.xdC = 0; qq.xd_bytes = 0; qq.g_xd = 0;
+        if (b.xd) {
+            const size_t xdb = (((size_t)d.B * d.H * d.W - 1) * b.xdC + b.KD * 64) * 2;
+            if (xdb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+            qq.xd = (const char*)b.xd; qq.xdC = b.xdC; qq.xd_bytes = (unsigned)xdb; qq.g_xd = b.g_xd;
+            const int BMd = 64;
+            size_t ldsd = (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BMd * 128 + (size_t)b.CN * 128;
+            const size_t ringd = 3 * (size_t)(BMd + b.C1) * 128;
+            if (ringd > ldsd) ldsd = ringd;
+            const void* fd = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 64, 64, 1>);
+            hipError_t ed = hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (ed != hipSuccess) return ed;
+            void* ad[] = {&qq};
+            return hipLaunchKernel(fd, dim3((d.M + BMd - 1) / BMd, d.groups), dim3(512), ad, ldsd, s);
+        }
         size_t lds1 = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128;
         const size_t ring1 = 3 * (size_t)(BM + b.C1) * 128;
         if (ring1 > lds1) lds1 = ring1;

@@ -57,6 +57,9 @@ struct Bneck23 {
     const void* w1 = nullptr; const float* b1 = nullptr; void* o1 = nullptr;
     int CN = 0, ldo = 0;
     long long g_w1 = 0, g_b1 = 0, g_o1 = 0;
+    // optional (with w1): the block's own 1x1 down-sample conv folded into the expansion GEMM -- w3 is then [4*C1][C1 + 64*KD] = [W3 | Wds],
+    // b3 = b3 + bds, res is unused; xd = block input [B,H,W,*] (64*KD channels at pixel stride xdC), same stride as the 3x3 conv
+    const void* xd = nullptr; int xdC = 0, KD = 0; long long g_xd = 0;
 };
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 

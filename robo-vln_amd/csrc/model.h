@@ -35,6 +35,7 @@ struct LinW {                  // [N][Kp]; dt = compute dtype or f32 (recurrent 
 
 struct BottleneckW {
     ConvW c1, c2, c3, ds;
+    ConvW c3ds;                // layer1 block 0 of a 16-bit BN-folded trunk: [W3 | Wds] K-concatenated, bias b3 + bds (bneck231_kernel, KD = 1)
     NormW n1, n2, n3, nds;     // GroupNorm variant only
     bool has_ds = false;
     int stride = 1;

@@ -350,6 +350,7 @@ static ConvW make_stem_packed(hcm_ctx* ctx, int dt, Uploader& up, int model, con
     return c;
 }
 
+static ConvW make_c3ds(hcm_ctx* ctx, int dt, Uploader& up, const std::vector<int>& models, const std::string& p);
 static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
     const int dt = ctx->dt_rgb;
@@ -367,6 +368,7 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
             b.c2 = make_conv_bn(ctx, dt, up, model, p + "conv2.weight", p + "bn2");
             b.c3 = make_conv_bn(ctx, dt, up, model, p + "conv3.weight", p + "bn3");
             if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn(ctx, dt, up, model, p + "downsample.0.weight", p + "downsample.1"); }
+            if (li == 0 && bi == 0 && dt != DT_F32) b.c3ds = make_c3ds(ctx, dt, up, {model}, p);
             t.blocks.push_back(b);
         }
     t.out_c = 2048;
@@ -499,6 +501,34 @@ static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::
         bias[o] = b.f[o] - m.f[o] * s;
     }
 }
+// Expansion conv3 and the block's 1x1 down-sample conv (both BN-folded) K-concatenated for the fused bottleneck launch that folds the
+// down-sample into the expansion GEMM: rows [W3 * s3 | Wds * sds] of K = C1 + Cd, bias b3 + bds, one block per model (group).
+static ConvW make_c3ds(hcm_ctx* ctx, int dt, Uploader& up, const std::vector<int>& models, const std::string& p) {
+    ConvW c;
+    c.dt = dt;
+    c.groups = (int)models.size();
+    const HostTensor& w3 = T_(ctx, models[0], p + "conv3.weight");
+    const HostTensor& wd = T_(ctx, models[0], p + "downsample.0.weight");
+    const int C3 = (int)w3.shape[0], C1 = (int)w3.shape[1], Cd = (int)wd.shape[1];
+    c.Cout = C3; c.Cin = C1 + Cd; c.KH = c.KW = 1; c.K = c.Kp = C1 + Cd;
+    std::vector<float> r((size_t)models.size() * C3 * c.Kp, 0.f), bias_all;
+    for (size_t g = 0; g < models.size(); ++g) {
+        const HostTensor& a = T_(ctx, models[g], p + "conv3.weight");
+        const HostTensor& d = T_(ctx, models[g], p + "downsample.0.weight");
+        std::vector<float> s3, b3, sd, bd;
+        bn_fold(ctx, models[g], p + "bn3", C3, s3, b3);
+        bn_fold(ctx, models[g], p + "downsample.1", C3, sd, bd);
+        for (int o = 0; o < C3; ++o) {
+            float* row = &r[(g * C3 + o) * c.Kp];
+            for (int i = 0; i < C1; ++i) row[i] = a.f[(size_t)o * C1 + i] * s3[o];
+            for (int i = 0; i < Cd; ++i) row[C1 + i] = d.f[(size_t)o * Cd + i] * sd[o];
+            bias_all.push_back(b3[o] + bd[o]);
+        }
+    }
+    c.w = up.typed(r, dt);
+    c.bias = up.f32(bias_all);
+    return c;
+}
 static ConvW make_conv_bn_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string& wkey, const std::string& bn) {
     const HostTensor* ws[2] = {&T_(ctx, HCM_HIGH, wkey), &T_(ctx, HCM_LOW, wkey)};
     ConvW c;
@@ -568,6 +598,7 @@ static TrunkW make_tv_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
             b.c2 = make_conv_bn_pair(ctx, dt, up, p + "conv2.weight", p + "bn2");
             b.c3 = make_conv_bn_pair(ctx, dt, up, p + "conv3.weight", p + "bn3");
             if (bi == 0) { b.has_ds = true; b.ds = make_conv_bn_pair(ctx, dt, up, p + "downsample.0.weight", p + "downsample.1"); }
+            if (li == 0 && bi == 0 && dt != DT_F32) b.c3ds = make_c3ds(ctx, dt, up, {HCM_HIGH, HCM_LOW}, p);
             t.blocks.push_back(b);
         }
     t.out_c = 2048;

@@ -355,3 +355,47 @@ def test_bottleneck_tail_next_fused(prec, cfg):
     torch.cuda.synchronize()
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
     assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 1), (3, 17, 15, 1), (2, 16, 16, 2), (5, 9, 11, 2), (2, 64, 64, 1)])
+def test_bottleneck_tail_downsample_folded(prec, cfg):
+    """First bottleneck of a stage in one launch: the 1x1 down-sample conv rides in the expansion GEMM (K-concatenated weights) and the
+    next block's reduction is computed from the output tile.  The identity is no longer rounded to the storage type before the add, so
+    the comparison with the separate launches is to storage-type tolerance, not bitwise."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, stride = cfg
+    C1, Cd, C3, CN = 64, 64, 256, 64
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    xd = _rnd(B, H, W, Cd, seed=8).cuda().to(tdt)
+    x = _rnd(B, H, W, C1).cuda().to(tdt)
+    w2 = _rnd(C1, 3, 3, C1, scale=(9 * C1) ** -0.5 * 1.7, seed=1).cuda().to(tdt)
+    b2 = _rnd(C1, scale=0.2, seed=2).cuda()
+    w3 = _rnd(C3, 1, 1, C1, scale=C1 ** -0.5 * 1.2, seed=3).cuda().to(tdt)
+    b3 = _rnd(C3, scale=0.2, seed=4).cuda()
+    wd = _rnd(C3, 1, 1, Cd, scale=Cd ** -0.5 * 1.2, seed=9).cuda().to(tdt)
+    bd = _rnd(C3, scale=0.2, seed=10).cuda()
+    w1 = _rnd(CN, 1, 1, C3, scale=C3 ** -0.5 * 1.7, seed=6).cuda().to(tdt)
+    b1 = _rnd(CN, scale=0.2, seed=7).cuda()
+    w3ds = torch.cat([w3.reshape(C3, C1), wd.reshape(C3, Cd)], dim=1).contiguous()
+    b3ds = (b3 + bd).contiguous()
+    y = torch.full((B, Ho, Wo, C3), float("nan"), device="cuda", dtype=tdt)
+    o1 = torch.full((B, Ho, Wo, CN), float("nan"), device="cuda", dtype=tdt)
+    assert lib.hcm_op_bottleneck_tail_ds(_p(x), _p(w2), _p(b2), _p(w3ds), _p(b3ds), _p(xd), _p(y), _p(w1), _p(b1), _p(o1), code, B, H, W,
+                                         stride, None) == 0
+    torch.cuda.synchronize()
+    nchw = lambda t: t.float().permute(0, 3, 1, 2)
+    cw = lambda w: w.float().permute(0, 3, 1, 2)
+    m = F.relu(F.conv2d(nchw(x), cw(w2), b2, stride=stride, padding=1)).to(tdt).float()
+    ref = F.relu(F.conv2d(m, cw(w3), b3) + F.conv2d(nchw(xd), cw(wd), bd, stride=stride))
+    refq = ref.to(tdt).float()
+    r1 = F.relu(F.conv2d(refq, cw(w1), b1)).permute(0, 2, 3, 1)
+    ref = ref.permute(0, 2, 3, 1)
+    err = (y.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    assert err < tol, err
+    # the reduction is computed from the kernel's own rounded y
+    r1k = F.relu(F.conv2d(nchw(y), cw(w1), b1)).permute(0, 2, 3, 1)
+    err1 = (o1.float() - r1k).abs().max().item() / max(r1k.abs().max().item(), 1e-6)
+    assert err1 < tol, err1
+    assert (o1.float() - r1).abs().max().item() / max(r1.abs().max().item(), 1e-6) < 3 * tol
