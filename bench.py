@@ -63,18 +63,18 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
 
 
 def dominant_kernel_probe(batch):
-    """The kernel with the largest share of the step is the fused bottleneck tail of the RGB ResNet-50 pair, `bneck23_kernel`
-    (3x3 conv 64->64 + ReLU, 1x1 expansion 64->256 + identity + ReLU in one launch; three launches per step at 64x64, four at
-    32x32); time its layer1 shape live with HIP events (torch events on the launch stream).  In the step that layer is ONE
-    launch over the hi|lo pair (2 groups x B images); the probe runs the same amount of work as a single group over 2*B
-    images (same tile count, same per-tile work), so its duration is comparable with the bneck23_kernel<bf16,128,64> rows of
-    profiles/r1_kernel_trace_bench.md.  The launch is HBM-bound: algorithmic bytes = 2 B/elem * M * (64 in + 256 identity +
-    256 out); algorithmic FLOPs = 2 * M * (576*64 + 64*256)."""
+    """The launch type with the largest share of the step is the fused bottleneck kernel of the RGB ResNet-50 pair, `bneck231_kernel`
+    (3x3 conv 64->64 + ReLU, 1x1 expansion 64->256 + identity + ReLU, and the next block's 1x1 reduction 256->64 + ReLU in one
+    launch; six launches per step in four shapes).  Time its layer1 middle-block shape live with HIP events (torch events on the
+    launch stream).  In the step that layer is ONE launch over the hi|lo pair (2 groups x B images); the probe runs the same amount
+    of work as a single group over 2*B images (same tile count, same per-tile work), so its duration is comparable with the
+    bneck231_kernel<bf16,128,64,64,0> row of profiles/r1_kernel_trace_bench.md.  The launch is HBM-bound: algorithmic bytes =
+    2 B/elem * M * (64 in + 256 identity + 256 out + 64 next-reduction out); algorithmic FLOPs = 2 * M * (576*64 + 64*256 + 256*64)."""
     import ctypes as C
     import torch
     from robo_vln_amd import _lib
     lib = _lib.lib()
-    B, H, W, C1 = 2 * batch, 64, 64, 64
+    B, H, W, C1, CN = 2 * batch, 64, 64, 64, 64
     C3 = 4 * C1
     bf = torch.bfloat16
     x = torch.randn(B, H, W, C1, device="cuda").to(bf)
@@ -82,13 +82,16 @@ def dominant_kernel_probe(batch):
     b2 = torch.randn(C1, device="cuda")
     w3 = (torch.randn(C3, 1, 1, C1, device="cuda") * 0.05).to(bf)
     b3 = torch.randn(C3, device="cuda")
+    w1 = (torch.randn(CN, 1, 1, C3, device="cuda") * 0.05).to(bf)
+    b1 = torch.randn(CN, device="cuda")
     idt = torch.randn(B, H, W, C3, device="cuda").to(bf)
     y = torch.empty_like(idt)
+    o1 = torch.empty(B, H, W, CN, device="cuda", dtype=bf)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run():
-        rc = lib.hcm_op_bottleneck_tail(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
-                                        y.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, st)
+        rc = lib.hcm_op_bottleneck_tail_next(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
+                                             y.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, CN, st)
         assert rc == 0
     for _ in range(20):
         run()
@@ -101,9 +104,9 @@ def dominant_kernel_probe(batch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     M = B * H * W
-    flops = 2.0 * M * (9 * C1 * C1 + C1 * C3)
-    gbytes = 2.0 * M * (C1 + 2 * C3) / 1e9
-    return {"kernel": "bneck23_kernel<bf16,128,64>: conv3x3 64->64 + conv1x1 64->256 + identity @64x64, hi|lo pair workload (M=2*B*4096)",
+    flops = 2.0 * M * (9 * C1 * C1 + C1 * C3 + C3 * CN)
+    gbytes = 2.0 * M * (C1 + 2 * C3 + CN) / 1e9
+    return {"kernel": "bneck231_kernel<bf16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair workload (M=2*B*4096)",
             "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": 8.0,
             "frac": round(gbytes / ms / 8.0, 4), "tflops": round(flops / ms / 1e9, 1)}
 
@@ -242,11 +245,11 @@ def main():
                          "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
                          # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
                          # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
-                         "traffic": 17.37 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
+                         "traffic": 15.79 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
                          "traffic_source": "profiles/r1_pmc_traffic_bench.md",
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s",
                          # the same step seen from the memory side: measured HBM bytes per step / step time vs the 8 TB/s peak
-                         "hbm_view": ({"achieved_TBps": round(17.37 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(17.37 / ms / 8.0, 4)}
+                         "hbm_view": ({"achieved_TBps": round(15.79 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(15.79 / ms / 8.0, 4)}
                                       if B == 64 else None)},
         }
         if args.reuse_instruction:
