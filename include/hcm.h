@@ -240,6 +240,12 @@ int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bia
  * HCM_U8, H and W even), w is [Cout][224] with k = kh*32 + kw*4 + ci, scratch holds hcm_op_stem_scratch_bytes(B,H,W). */
 int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                             int Cout, float scale, int act, void* scratch, void* stream);
+/* The same stem followed by ReLU and MaxPool2d(3, 2, 1) (torchvision resnet50 conv1/bn1/relu/maxpool), with the horizontal half of
+ * the pool fused into the conv's epilogue and a vertical-only pool kernel after it: y is (B, H/4, W/4, Cout), bit-identical to
+ * hcm_op_stem_conv_packed(act = ReLU) + hcm_op_maxpool3x3s2.  W/2 must be a power of two <= 128, Cout a multiple of 64; half_map holds
+ * B * (H/2) * (W/4) * Cout elements of `dtype`. */
+int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                                 int Cout, float scale, void* scratch, void* half_map, void* stream);
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);

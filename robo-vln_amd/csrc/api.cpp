@@ -614,6 +614,24 @@ int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const flo
     g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = 224; g.Kp = 224; g.ldy = Cout; g.ldr = Cout; g.act = act;
     return op_rc(launch_igemm(g, dt, (hipStream_t)stream));
 }
+int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                                 int Cout, float scale, void* scratch, void* half_map, void* stream) {
+    const int dt = op_dt(dtype);
+    if (!scratch || !half_map || (H & 1) || (W & 1)) return HCM_ERR_ARG;
+    const int sdt = x_dtype == HCM_U8 ? DT_U8 : x_dtype == HCM_F32 ? DT_F32 : -1;
+    if (sdt < 0) return HCM_ERR_ARG;
+    int rc = op_rc(launch_pack_frame(x, sdt, scratch, dt, B, H, W, scale, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    IGemm g;
+    g.x = scratch; g.w = w; g.bias = bias; g.y = half_map;
+    g.B = B; g.H = H + 6; g.W = (W + 8) / 2; g.Cin = 32; g.xC = 8;
+    g.Ho = H / 2; g.Wo = W / 2; g.KH = 7; g.KW = 1; g.stride = 2; g.stride_w = 1; g.pad = 0;
+    g.M = B * g.Ho * g.Wo; g.N = Cout; g.K = 224; g.Kp = 224; g.ldy = Cout; g.ldr = Cout; g.act = ACT_RELU;
+    g.hpool = 1;
+    rc = op_rc(launch_igemm(g, dt, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    return op_rc(launch_vpool3s2(half_map, y, dt, B, g.Ho, g.Wo / 2, Cout, (hipStream_t)stream));
+}
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y, int dtype, int M, int N, int K,
                   int act, int out_f32, void* stream) {
     IGemm g;

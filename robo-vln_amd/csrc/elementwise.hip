@@ -151,6 +151,39 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int
     return hipGetLastError();
 }
 
+// vertical half of MaxPool2d(3, 2, 1) (the horizontal half is fused into the stem conv's epilogue, igemm.hip)
+template <typename T>
+__global__ void vpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho) {
+    constexpr int CH = Tr<T>::CH;
+    const int cv = C / CH;
+    const size_t rowv = (size_t)W * cv;                 // 16-byte vectors per row
+    const size_t total = (size_t)B * Ho * rowv;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t in_row = e % rowv;
+        const size_t rowi = e / rowv;
+        const int oy = (int)(rowi % Ho);
+        const int b = (int)(rowi / Ho);
+        float v[3][CH];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int iy = min(max(2 * oy - 1 + d, 0), H - 1);      // clamped taps stay inside the window
+            ld_chunk(x + ((size_t)(b * H + iy) * rowv + in_row) * CH, v[d]);
+        }
+        float m[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), v[2][j]);
+        st_chunk(y + e * CH, m);
+    }
+}
+hipError_t launch_vpool3s2(const void* x, void* y, int dt, int B, int H, int W, int C, hipStream_t s) {
+    const int CH = dt_chunk(dt);
+    if (C % CH) return hipErrorInvalidValue;
+    const int Ho = (H + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * W * (C / CH);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(vpool3s2_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, B, H, W, C, Ho));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ adaptive_avg_pool2d NHWC
 // F.adaptive_avg_pool2d(x,(OH,OW)) (resnet_encoders.py:160-166) / AdaptiveAvgPool2d(1): window [floor(i*H/OH), ceil((i+1)*H/OH)).
 template <typename T>

@@ -147,7 +147,7 @@ struct Fwd {
     }
 
     // 16-bit RGB trunks: pack the frame once, then the stem is an ordinary LDS-DMA implicit GEMM (kernels.h: launch_pack_frame)
-    void stem_conv_packed(const ConvW& w, const Stem& st, int B, void* out, int Ho, int Wo, int act) {
+    void stem_conv_packed(const ConvW& w, const Stem& st, int B, void* out, int Ho, int Wo, int act, int hpool = 0) {
         void* pk = alloc_t(pack_frame_elems(B, st.H, st.W));
         if (dry) return;
         ck(launch_pack_frame(st.x, st.x_dt, pk, w.dt, B, st.H, st.W, st.scale, s), "pack frame");
@@ -156,6 +156,7 @@ struct Fwd {
         g.B = B; g.H = st.H + 6; g.W = (st.W + 8) / 2; g.Cin = 32; g.xC = 8;
         g.Ho = Ho; g.Wo = Wo; g.KH = 7; g.KW = 1; g.stride = 2; g.stride_w = 1; g.pad = 0;
         g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
+        g.hpool = hpool;
         ck(launch_igemm(g, w.dt, s), "stem conv (packed)");
     }
 
@@ -172,6 +173,10 @@ struct Fwd {
         const bool packed = !t.gn && !no_pack && t.conv1_packed.w != nullptr && st.Cin == 3 && !(st.W & 1) && !(st.H & 1) &&
                             (st.x_dt == DT_F32 || st.x_dt == DT_U8);
         const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
+        // packed RGB stem: the horizontal half of the 3x3/2 max-pool rides in the conv's epilogue (the 128-channel pair map is written at
+        // half width), a vertical-only pool follows; exact.  Not while taps are captured: `_conv1` is the full-width map.
+        static const bool no_hpool = getenv("HCM_NO_STEM_HPOOL") != nullptr;
+        const bool hpool = packed && !no_hpool && !ctx->taps_on && Wo >= 2 && Wo <= 128 && !(Wo & (Wo - 1)) && (c1 % 64) == 0;
         if (t.gn && st.x_dt == -2) {
             // depth stem on the packed 1-channel frame: kernel row = 8 contiguous elements (7 taps + a zero-weight slot), the GEMM's
             // "virtual pixel" = the stride of 2 elements
@@ -184,12 +189,15 @@ struct Fwd {
                 g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = ACT_NONE;
                 ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
             }
-        } else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
+        } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
+        else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
         if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
-        tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
+        if (!hpool) tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
-        if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
+        if (hpool) {
+            if (!dry) ck(launch_vpool3s2(slot[0], slot[1], dt, B, Ho, Wo / 2, c1, s), "maxpool (vertical half)");
+        } else if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
         Act x{slot[1], B, Hp, Wp, c1};
         int xi = 1;
         int bidx = 0;

@@ -54,6 +54,7 @@ struct IGemmDev {
     int groups; long long g_x, g_w, g_b, g_y;
     // fused GroupNorm epilogue (small maps: a 64-row tile holds whole samples): y = GN(conv) * gamma + beta (+ res) (ReLU)
     const float* gn_gamma; const float* gn_beta; int gn_cg, gn_hw; float gn_eps;
+    int hpool;         // horizontal half of MaxPool2d(3, 2, 1) in the epilogue (igemm_epilogue_hpool)
 };
 
 template <typename T> struct Mma;
@@ -256,6 +257,64 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
                 }
             }
         }
+    }
+}
+
+// Epilogue with the HORIZONTAL half of MaxPool2d(3, 2, 1) fused (7x7 stem -> max-pool): a tile holds whole rows of the conv's
+// output map (BM % Wo == 0), so the three horizontal neighbours of a pooled pixel sit in the f32 image; the conv map is written
+// at half width, max(relu(x + b)) == relu(max(x) + b) exactly (monotonic adds and rounding), and the stand-alone pool that follows
+// only has the vertical half left (vpool3s2_kernel).  y is [M / Wo][Wo / 2][ldy].
+template <typename T, int BM, int BN, int NW, int WMc>
+__device__ __forceinline__ void igemm_epilogue_hpool(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], char* smem, int m0, int n0,
+                                                     int tid, int wm, int wn, int fr, int fg) {
+    constexpr int WNc = NW / WMc;
+    constexpr int TM = BM / WMc / 16;
+    constexpr int TN = BN / WNc / 16;
+    constexpr int LDC = BN + 4;
+    float* sc = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int r = wm * (BM / WMc) + j * 16 + fr;
+            const int cc = wn * (BN / WNc) + i * 16 + fg * 4;
+            *reinterpret_cast<float4*>(sc + r * LDC + cc) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 8;
+    constexpr int QPP = 64 * NW / TPR;                 // pooled pixels per pass
+    const int c8 = (tid % TPR) * 8;
+    const int n = n0 + c8;
+    if (n + 8 > p.N) return;
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+    const int Wq = p.Wo >> 1;
+#pragma unroll
+    for (int pass = 0; pass < (BM / 2) / QPP; ++pass) {
+        const int q = pass * QPP + tid / TPR;          // pooled pixel of the tile
+        const int row = q / Wq, pc = q - row * Wq;
+        const int r1 = row * p.Wo + 2 * pc;            // centre tap; left neighbour clamped onto it at the map's edge
+        if (m0 + r1 >= p.M) continue;
+        const int r0 = pc ? r1 - 1 : r1, r2 = r1 + 1;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(sc + r0 * LDC + c8 + 4 * h);
+            const float4 b = *reinterpret_cast<const float4*>(sc + r1 * LDC + c8 + 4 * h);
+            const float4 c = *reinterpret_cast<const float4*>(sc + r2 * LDC + c8 + 4 * h);
+            v[4 * h + 0] = fmaxf(fmaxf(a.x, b.x), c.x); v[4 * h + 1] = fmaxf(fmaxf(a.y, b.y), c.y);
+            v[4 * h + 2] = fmaxf(fmaxf(a.z, b.z), c.z); v[4 * h + 3] = fmaxf(fmaxf(a.w, b.w), c.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] += bias8[e];
+            if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+        const size_t pix = (size_t)((m0 / p.Wo) + row) * Wq + pc;
+        if constexpr (sizeof(T) == 2) st_chunk(reinterpret_cast<T*>(p.y) + pix * p.ldy + n, v);
     }
 }
 
@@ -739,7 +798,7 @@ __device__ __forceinline__ unsigned long long prof_now() {
 // ILV = 1: the DMA instructions of the next tile are not issued in one burst at the top of an iteration (where all waves
 // of the workgroup queue 16-32 KB on the CU's one texture-address path at once and then sit in the issue stall) but
 // one at a time between groups of MFMAs; both K halves' fragments are read up front.
-template <typename T, int BM, int BN, int NBUF, int NW = 4, int WMc = 2, bool PROF = false, int ILV = 0>
+template <typename T, int BM, int BN, int NBUF, int NW = 4, int WMc = 2, bool PROF = false, int ILV = 0, bool HPOOL = false>
 __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
     if constexpr (PROF) t_prev = prof_now();
@@ -1091,6 +1150,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         lap(4);
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
+    if constexpr (HPOOL) igemm_epilogue_hpool<T, BM, BN, NW, WMc>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
+    else
     igemm_epilogue<T, BM, BN, NW, WMc, E_NP>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, rpre, have_pre);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1947,6 +2008,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipErrorInvalidValue;
     d.x_scale = g.x_scale;
     d.rowrun = 0;
+    d.hpool = 0;
     d.groups = g.groups > 1 ? g.groups : 1;
     d.g_x = g.g_x; d.g_w = g.g_w; d.g_b = g.g_b; d.g_y = g.g_y;
     d.gn_gamma = g.gn_gamma; d.gn_beta = g.gn_beta; d.gn_cg = g.gn_gamma ? g.gn_cg : 0; d.gn_hw = g.gn_hw; d.gn_eps = g.gn_eps;
@@ -1986,6 +2048,31 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
             d.out_f32 || !d.gn_beta)
             return hipErrorInvalidValue;
         return launch_dt(d, dt, ((d.K >= 768 && dt != DT_F32) ? 7 : 4) * 6 + 5, s);
+    }
+    if (g.hpool) {
+        // stem conv + horizontal max-pool: tiles of 128 whole-row pixels (8-wave, 2-deep ring), N in whole 64 / 128-channel tiles
+        if ((dt != DT_BF16 && dt != DT_F16) || d.res || d.out_f32 || d.Wo < 2 || (d.Wo & (d.Wo - 1)) || d.Wo > 128 || (d.M % d.Wo) || (d.N % 64) ||
+            (d.ldy % 8) || (d.act != ACT_RELU && d.act != ACT_NONE))
+            return hipErrorInvalidValue;
+        d.hpool = 1;
+        const bool wide = d.N % 128 == 0;
+        const int BN = wide ? 128 : 64;
+        d.tilesM = (d.M + 127) / 128;
+        d.tilesN = d.N / BN;
+        d.map = 0;
+        const int grid = ((d.tilesM + 7) / 8) * 8 * d.tilesN;
+        size_t lds = 2 * (size_t)(128 + BN) * 128;
+        const size_t lds_c = (size_t)128 * (BN + 4) * 4;
+        if (lds_c > lds) lds = lds_c;
+        const void* fn;
+        if (dt == DT_BF16) fn = wide ? reinterpret_cast<const void*>(igemm_dma_kernel<bf16, 128, 128, 2, 8, 2, false, 0, true>)
+                                     : reinterpret_cast<const void*>(igemm_dma_kernel<bf16, 128, 64, 2, 8, 2, false, 0, true>);
+        else fn = wide ? reinterpret_cast<const void*>(igemm_dma_kernel<f16, 128, 128, 2, 8, 2, false, 0, true>)
+                       : reinterpret_cast<const void*>(igemm_dma_kernel<f16, 128, 64, 2, 8, 2, false, 0, true>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        void* args[] = {&d};
+        return hipLaunchKernel(fn, dim3(grid, d.groups), dim3(512), args, lds, s);
     }
     static const char* force = getenv("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
     if (force && !(narrow_stride && (atoi(force) / 6 == 0 || atoi(force) / 6 == 3))) return launch_dt(d, dt, atoi(force), s);

@@ -39,6 +39,9 @@ struct IGemm {
     // no bias): y = (conv - mean) * rstd * gamma + beta, then residual / activation as usual; 64x128 tiles are forced
     const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int gn_cg = 0, gn_hw = 0; float gn_eps = 1e-5f;
     int x_rowrun = 0;            // f32 RGB stem: weights/K laid out as KH runs of 24 floats (21 taps + 3 zero pads)
+    // horizontal half of MaxPool2d(3, 2, 1) fused into the epilogue: y is [B*Ho][Wo/2][ldy] (16-bit types, Wo a power of two <= 128, N % 64 == 0,
+    // no residual); launch_vpool3s2 finishes the pool
+    int hpool = 0;
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,
@@ -81,6 +84,8 @@ hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, 
 inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);   // -> [B][H/2+6][W/2+8]
+// vertical half of MaxPool2d(3, 2, 1): x [B][H][W][C] -> y [B][(H+1)/2][W][C] (rows 2p-1, 2p, 2p+1)
+hipError_t launch_vpool3s2(const void* x, void* y, int dt, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel
 hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s,

@@ -399,3 +399,28 @@ def test_bottleneck_tail_downsample_folded(prec, cfg):
     err1 = (o1.float() - r1k).abs().max().item() / max(r1k.abs().max().item(), 1e-6)
     assert err1 < tol, err1
     assert (o1.float() - r1).abs().max().item() / max(r1.abs().max().item(), 1e-6) < 3 * tol
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, "f32"), (2, 256, 256, 128, "f32"), (3, 32, 128, 128, "u8"), (1, 16, 8, 64, "f32")])
+def test_stem_conv_packed_pool(prec, cfg):
+    """conv1 + ReLU + MaxPool2d(3, 2, 1) with the horizontal half of the pool in the conv's epilogue: BIT-identical to the packed stem
+    followed by the stand-alone pool kernel."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cout, src = cfg
+    xf = (_rnd(B, H, W, 3) * 0.5 + 0.5) * 255
+    x = xf.to(torch.uint8).cuda() if src == "u8" else xf.cuda()
+    xcode = L.HCM_U8 if src == "u8" else L.HCM_F32
+    w = _rnd(Cout, 224, scale=0.1, seed=1).cuda().to(tdt)
+    b = _rnd(Cout, scale=0.3, seed=2).cuda()
+    scratch = torch.empty(lib.hcm_op_stem_scratch_bytes(B, H, W), device="cuda", dtype=torch.uint8)
+    full = torch.empty(B, H // 2, W // 2, Cout, device="cuda", dtype=tdt)
+    ref = torch.empty(B, H // 4, W // 4, Cout, device="cuda", dtype=tdt)
+    assert lib.hcm_op_stem_conv_packed(_p(x), xcode, _p(w), _p(b), _p(full), code, B, H, W, Cout, 1 / 255.0, L.ACT_RELU, _p(scratch), None) == 0
+    assert lib.hcm_op_maxpool3x3s2(_p(full), _p(ref), code, B, H // 2, W // 2, Cout, None) == 0
+    half = torch.empty(B, H // 2, W // 4, Cout, device="cuda", dtype=tdt)
+    y = torch.full((B, H // 4, W // 4, Cout), float("nan"), device="cuda", dtype=tdt)
+    assert lib.hcm_op_stem_conv_packed_pool(_p(x), xcode, _p(w), _p(b), _p(y), code, B, H, W, Cout, 1 / 255.0, _p(scratch), _p(half), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16))
