@@ -829,13 +829,15 @@ hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, f
     return hipGetLastError();
 }
 
-// The whole packed (bi)LSTM scan in ONE launch: a workgroup owns SB samples of one direction for all L steps, thread j owns
-// hidden unit j (blockDim.x == H).  h lives in LDS (double-buffered, broadcast reads), c in registers; W_hh is read
-// transposed ([k][4H], so the 4 gate weights of unit j for input k are coalesced across threads) from L2 every step --
-// 4*H*H*4 bytes per step and workgroup, which bounds the step at a few microseconds instead of two launches.
+// The whole packed (bi)LSTM scan in ONE launch: a workgroup owns SB samples of one direction for all L steps.  h lives in LDS
+// (double-buffered, broadcast reads), c in registers; W_hh is read from L2 every step, transposed and gate-interleaved ([k][unit][4
+// gates]: the four gate weights of (k, unit j) are one 16-byte load, coalesced across the units) -- 4*H*H*4 bytes per step and
+// workgroup.  SB is chosen small (2 for B = 64, both directions: 64 workgroups): per step a thread then does SB * 256 FMAs behind 64
+// 16-byte loads, and the step is bounded by that weight stream (1 MB from L2) instead of by 8 samples' worth of FMAs and LDS
+// broadcasts on 16 CUs (CMANet step at B = 64, L = 80: 3.15 -> 2.56 ms; the trunks alone take 2.4).
 struct LstmScanArgs {
     const float* pre[2];       // per direction: x_t W_ih^T + b_ih + b_hh for every token, [B*L][4H]
-    const float* wt[2];        // per direction: W_hh transposed, [H][4H]
+    const float* wt[2];        // per direction: W_hh as [H (k)][H (unit)][4 (gate)]
 };
 // 1024 threads = 256 hidden units x 4 quarters of the k range: each thread streams a quarter of its unit's recurrent weights
 // (64 k x 4 gates, several loads in flight) for SB samples; the four partial sums per (gate, sample, unit) meet in LDS.
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(1024) void instr_lstm_scan_kernel(LstmScanArgs a, c
     const int j = threadIdx.x & 255, kq = threadIdx.x >> 8;
     const int KQ = H / 4;
     const float* __restrict__ pre = a.pre[dir];
-    const float* __restrict__ wt = a.wt[dir] + (size_t)kq * KQ * 4 * H + j;
+    const float* __restrict__ wt = a.wt[dir] + ((size_t)kq * KQ * H + j) * 4;
     float c[SB];
 #pragma unroll
     for (int s_ = 0; s_ < SB; ++s_) c[s_] = 0.f;
@@ -867,8 +869,8 @@ __global__ __launch_bounds__(1024) void instr_lstm_scan_kernel(LstmScanArgs a, c
         const float* hc = hs + cur * SB * H + kq * KQ;
 #pragma unroll 8
         for (int k = 0; k < KQ; ++k) {
-            const float* wr = wt + (size_t)k * 4 * H;
-            const float w0 = wr[0], w1 = wr[H], w2 = wr[2 * H], w3 = wr[3 * H];
+            const float4 w4 = *reinterpret_cast<const float4*>(wt + (size_t)k * 4 * H);
+            const float w0 = w4.x, w1 = w4.y, w2 = w4.z, w3 = w4.w;
 #pragma unroll
             for (int s_ = 0; s_ < SB; ++s_) {
                 const float hk = hc[s_ * H + k];
@@ -912,18 +914,21 @@ __global__ __launch_bounds__(1024) void instr_lstm_scan_kernel(LstmScanArgs a, c
 hipError_t launch_instr_lstm_scan(const float* pre0, const float* pre1, const float* wt0, const float* wt1, const int* lengths, float* out,
                                   int B, int L, int H, int dirs, int ld_out, hipStream_t s) {
     if (H != 256) return hipErrorInvalidValue;          // 256 hidden units x 4 k-quarters = 1024 threads
-    constexpr int SB = 8;
     LstmScanArgs a;
     a.pre[0] = pre0; a.pre[1] = pre1; a.wt[0] = wt0; a.wt[1] = wt1;
+    // samples per workgroup: the fewest that keep the launch within one workgroup per CU
+    static const char* fsb = getenv("HCM_LSTM_SB");
+    int SB = 2;        // (SB = 1 measured slower at B = 64 -- 128 workgroups take the CUs from the trunks running beside the scan)
+    while (SB < 8 && ((B + SB - 1) / SB) * dirs > 128) SB *= 2;
+    if (fsb) SB = atoi(fsb);
     const size_t lds = (size_t)(2 * SB * H + 3 * 4 * SB * H) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(instr_lstm_scan_kernel<SB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    hipLaunchKernelGGL(instr_lstm_scan_kernel<SB>, dim3((B + SB - 1) / SB, dirs), dim3(1024), lds, s, a, lengths, out, B, L, H, ld_out);
-    return hipGetLastError();
+    const void* fn = SB == 2 ? reinterpret_cast<const void*>(instr_lstm_scan_kernel<2>)
+                   : SB == 4 ? reinterpret_cast<const void*>(instr_lstm_scan_kernel<4>) : SB == 8 ? reinterpret_cast<const void*>(instr_lstm_scan_kernel<8>) : nullptr;
+    if (!fn) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    void* args[] = {&a, &lengths, &out, &B, &L, &H, &ld_out};
+    return hipLaunchKernel(fn, dim3((B + SB - 1) / SB, dirs), dim3(1024), args, lds, s);
 }
 
 // CMANet._attn (models/cma.py:201-209): ONE query per sample over S positions:

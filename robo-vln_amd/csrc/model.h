@@ -123,7 +123,7 @@ struct CmaW {
     int depth_S = 0, depth_C = 0;
     float* emb = nullptr;          // word embedding table [vocab][E] f32
     LinW ih[2], hh[2];             // per direction: W_ih (bias = b_ih + b_hh) and W_hh, f32
-    float* hh_t[2] = {nullptr, nullptr};   // W_hh transposed [H][4H] for the one-launch scan
+    float* hh_t[2] = {nullptr, nullptr};   // W_hh transposed and gate-interleaved [H (k)][H (unit)][4 gates] for the one-launch scan
     int dirs = 1;
     LinW rgb_linear, depth_linear, rgb_kv, depth_kv;    // token-side projections (dt_vla weights, f32 outputs)
     LinW state_q, text_k, text_q, compress;             // f32

@@ -847,8 +847,9 @@ void prepare_cma(hcm_ctx* ctx) {
             const HostTensor& whh = T_(ctx, M, p + "weight_hh_l0" + sfx);       // (4H, H)
             const int H4 = (int)whh.shape[0], H = (int)whh.shape[1];
             std::vector<float> t((size_t)H * H4);
+            // [k][unit j][gate g]: the four gate weights of (input k, unit j) are one 16-byte load of the scan kernel
             for (int n = 0; n < H4; ++n)
-                for (int k = 0; k < H; ++k) t[(size_t)k * H4 + n] = whh.f[(size_t)n * H + k];
+                for (int k = 0; k < H; ++k) t[((size_t)k * H + (n % H)) * 4 + n / H] = whh.f[(size_t)n * H + k];
             w.hh_t[d] = up.f32(t);
         }
     }

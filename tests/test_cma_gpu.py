@@ -120,3 +120,47 @@ def test_cma_hipgraph_replay_equals_eager():
         assert torch.equal(oe, og) and torch.equal(se, sg) and torch.equal(he, hg)
         hg = hg.clone()
     assert graph.query(7) >= 3        # HCM_GRAPH_LAUNCHES: steps served by graph replay
+
+
+def test_cma_two_engines_bitwise_deterministic():
+    """Two engines built from the same state_dict, the same inputs, several calls: identical bits (guards the one-launch
+    instruction-encoder scan and the multi-stream schedule against races)."""
+    from robo_vln_amd.cma import CMAEngine
+    cfg, B, T = cases.cma_case_config("cma_128_L20")
+    sd = synth.make_cma_weights(cfg, cases.SEED)
+    e1 = CMAEngine(cfg, sd, max_batch=B, precision="bf16")
+    e2 = CMAEngine(cfg, sd, max_batch=B, precision="bf16")
+    h = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda")
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_observations(cfg, B, step=0, seed=cases.SEED).items()}
+    m = torch.from_numpy(cases.step_masks(B, 0)).cuda()
+    ref = None
+    for e in (e1, e1, e2, e1, e2):
+        out = [t.clone() for t in e.forward(obs, h, m)]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+def test_cma_batch_split_consistency():
+    """A batch of 12 environments equals its three sub-batches of 4 run separately (fp32 path): the instruction-encoder scan, which
+    owns a couple of samples per workgroup, the grouped trunk launches and the attention kernels do not mix samples."""
+    from robo_vln_amd.cma import CMAEngine
+    cfg, _, _ = cases.cma_case_config("cma_128_L20")
+    B = 12
+    sd = synth.make_cma_weights(cfg, cases.SEED)
+    eng = CMAEngine(cfg, sd, max_batch=B, precision="fp32")
+    obs_np = synth.make_cma_observations(cfg, B, step=1, seed=cases.SEED + 3)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    h = (torch.rand(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda") - 0.5) * 0.2
+    m = torch.ones(B, device="cuda")
+    full = [t.clone() for t in eng.forward(obs, h, m)]
+    for lo in range(0, B, 4):
+        sub_obs = {k: v[lo:lo + 4].contiguous() for k, v in obs.items()}
+        part = eng.forward(sub_obs, h[:, lo:lo + 4].contiguous(), m[lo:lo + 4].contiguous())
+        torch.cuda.synchronize()
+        assert (full[0][lo:lo + 4] - part[0]).abs().max().item() <= 2e-5
+        assert (full[1][lo:lo + 4] - part[1]).abs().max().item() <= 2e-5
+        assert (full[2][:, lo:lo + 4] - part[2]).abs().max().item() <= 2e-5
+    eng.close()
