@@ -93,10 +93,10 @@ def dominant_kernel_probe(batch):
         rc = lib.hcm_op_bottleneck_tail_next(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
                                              y.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, CN, st)
         assert rc == 0
-    for _ in range(20):
+    for _ in range(100):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
+    n = 100
     e0.record()
     for _ in range(n):
         run()
