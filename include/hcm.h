@@ -232,6 +232,12 @@ int hcm_op_bottleneck_tail_next(const void* x, const void* w2, const float* b2, 
 int hcm_op_bottleneck_tail_ds(const void* x, const void* w2, const float* b2, const void* w3ds, const float* b3ds, const void* xd,
                               void* y, const void* w1, const float* b1, void* o1, int dtype, int B, int H, int W, int stride,
                               void* stream);
+/* conv2d (no bias) + GroupNorm(groups) (+ residual) (+ ReLU) for LARGE maps (Ho*Wo a multiple of 64 and >= 256, 16-bit dtypes): the
+ * conv's epilogue emits the GroupNorm partial sums from its f32 tile image, one more launch normalises in place (the GN-ResNet
+ * layers at 64x64 .. 16x16; resnet_encoders.py:37-101 / habitat resnet.py GroupNorm(ngroups)). */
+int hcm_op_conv2d_gn_large(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
+                           int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
+                           int relu, void* stream);
 /* first-layer (Cin = 1 or 3) convolution gathering straight from the raw frame x (x_dtype HCM_F32 / HCM_U8 / dtype):
  * w is [Cout][Kp] with k = (kh*KW+kw)*C + ci (rowrun = 0) or k = kh*24 + kw*3 + ci (rowrun = 1, f32 RGB frames only). */
 int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W, int C,

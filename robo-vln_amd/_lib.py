@@ -67,6 +67,7 @@ EXPORTS = {
     "hcm_op_bottleneck_tail_next": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 7 + [C.c_void_p]),
     "hcm_op_bottleneck_tail_ds": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
     "hcm_op_conv2d_gn": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
+    "hcm_op_conv2d_gn_large": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_stem_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_stem_conv_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "hcm_op_stem_conv_packed_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

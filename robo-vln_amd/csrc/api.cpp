@@ -663,6 +663,30 @@ int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, 
     }
     return op_rc(launch_groupnorm(x_inplace, residual, gamma, beta, scratch, op_dt(dtype), B, HW, C, groups, eps, relu, (hipStream_t)stream));
 }
+int hcm_op_conv2d_gn_large(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* residual, void* y,
+                           int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups, float eps,
+                           int relu, void* stream) {
+    if (groups < 1 || Cout % groups) return HCM_ERR_ARG;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1, hw = Ho * Wo, dt = op_dt(dtype);
+    if (!groupnorm_apply_ok(dt, hw, Cout, groups)) return HCM_ERR_ARG;
+    static float* scratch = nullptr;
+    static size_t scratch_floats = 0;
+    const size_t need = gn_stats_floats(B, hw, groups);
+    if (need > scratch_floats) {
+        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); }
+        if (hipMalloc((void**)&scratch, need * 4) != hipSuccess) return HCM_ERR_NOMEM;
+        scratch_floats = need;
+    }
+    IGemm g;
+    g.x = x; g.w = w_ohwi; g.y = y;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.xC = Cin; g.Ho = Ho; g.Wo = Wo;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.M = B * hw; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = ACT_NONE;
+    g.cs_part = scratch; g.cs_cg = Cout / groups; g.cs_hw = hw; g.cs_G = groups;
+    int rc = op_rc(launch_igemm(g, dt, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    return op_rc(launch_groupnorm_apply(y, residual, gamma, beta, scratch, hw / 64, dt, B, hw, Cout, groups, eps, relu, (hipStream_t)stream));
+}
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     return op_rc(launch_maxpool3x3s2(x, y, op_dt(dtype), B, H, W, C, Ho, Wo, (hipStream_t)stream));

@@ -414,17 +414,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ part, int HW, int C, int G,
-                                                        int P, float eps, int relu) {
+                                                        int P, float eps, int relu, int PS) {
     constexpr int CH = Tr<T>::CH;
     __shared__ float s_scale[512], s_shift[512];
     __shared__ float s_mean[256], s_rstd[256];
     const int b = blockIdx.y, pc = blockIdx.x;
     const int tid = threadIdx.x;
     const int Cg = C / G;
+    // PS partial sums per (sample, group): P of them from gn_stats_kernel, or HW / 64 from the producing conv's epilogue
     for (int g = tid; g < G; g += 256) {
         float a = 0.f, q = 0.f;
-        for (int i = 0; i < P; ++i) {
-            const float* o = part + (((size_t)b * P + i) * G + g) * 2;
+#pragma unroll 4
+        for (int i = 0; i < PS; ++i) {
+            const float* o = part + (((size_t)b * PS + i) * G + g) * 2;
             a += o[0]; q += o[1];
         }
         const float inv_n = 1.0f / ((float)HW * (float)Cg);
@@ -475,7 +477,7 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
         (HW >= 1024 || C <= 256)) {             // 16 x 16 maps with 512 channels: the slab kernel is faster (13 vs 21 us)
         HCM_DISPATCH_T(dt, {
             hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(P, B), dim3(256), 0, s, (const T*)x, stats, HW, C, G, P);
-            hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(P, B), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, stats, HW, C, G, P, eps, relu);
+            hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(P, B), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, stats, HW, C, G, P, eps, relu, P);
         });
         return hipGetLastError();
     }
@@ -488,6 +490,22 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
     if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) return hipErrorInvalidValue;
     const int grid = B * (C / CS);
     HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, CS, eps, relu));
+    return hipGetLastError();
+}
+
+bool groupnorm_apply_ok(int dt, int HW, int C, int G) {
+    const int CH = dt_chunk(dt);
+    if (dt == DT_F32 || C % CH || C % G) return false;
+    const int P = gn_partials(HW), cprw = C / CH;
+    return P > 0 && !(cprw & (cprw - 1)) && cprw <= 128 && C <= 512 && G <= 256 && HW % P == 0 && HW % 64 == 0 && (HW >= 1024 || C <= 256) &&
+           32 % (C / G) == 0;
+}
+hipError_t launch_groupnorm_apply(void* x, const void* res, const float* gamma, const float* beta, const float* part, int PS, int dt, int B,
+                                  int HW, int C, int G, float eps, int relu, hipStream_t s) {
+    if (!groupnorm_apply_ok(dt, HW, C, G) || PS < 1) return hipErrorInvalidValue;
+    const int P = gn_partials(HW);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(P, B), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, part, HW, C, G, P, eps,
+                                          relu, PS));
     return hipGetLastError();
 }
 

@@ -67,14 +67,24 @@ struct Fwd {
         if (fuse) {
             conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg);
         } else {
+            // large maps: the statistics come out of the conv's epilogue (column sums of the f32 tile image per 64-row block and
+            // group), so GroupNorm is one launch over the map instead of two
+            static const bool no_cs = getenv("HCM_NO_GN_EPISTATS") != nullptr;
+            if (!no_cs && !w.bias && groupnorm_apply_ok(w.dt, hw, C, G) && w.Cout % cg == 0) {
+                float* stats = alloc_f(gn_stats_floats(in.B, hw, G));
+                conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo, nullptr, 0, stats, cg, hw, G);
+                if (!dry) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, 1e-5f, relu ? 1 : 0, s), "groupnorm apply");
+                return;
+            }
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
             gn(out, res, n, in.B, hw, C, G, relu);
         }
     }
     void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo,
-              const NormW* gnw = nullptr, int gn_cg = 0) {
+              const NormW* gnw = nullptr, int gn_cg = 0, float* cs_part = nullptr, int cs_cg = 0, int cs_hw = 0, int cs_G = 0) {
         if (dry) return;
         IGemm g;
+        g.cs_part = cs_part; g.cs_cg = cs_cg; g.cs_hw = cs_hw; g.cs_G = cs_G;
         if (gnw) { g.gn_gamma = gnw->gamma; g.gn_beta = gnw->beta; g.gn_cg = gn_cg; g.gn_hw = Ho * Wo; g.gn_eps = 1e-5f; }
         g.x = in.p; g.w = w.w; g.bias = w.bias; g.res = res; g.y = out;
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;

@@ -55,6 +55,9 @@ struct IGemmDev {
     // fused GroupNorm epilogue (small maps: a 64-row tile holds whole samples): y = GN(conv) * gamma + beta (+ res) (ReLU)
     const float* gn_gamma; const float* gn_beta; int gn_cg, gn_hw; float gn_eps;
     int hpool;         // horizontal half of MaxPool2d(3, 2, 1) in the epilogue (igemm_epilogue_hpool)
+    // GroupNorm statistics of the conv output from the f32 tile image: per (sample, 64-row block, group) sum / sum of squares into
+    // cs_part[((b * cs_hw / 64 + block) * cs_G + group) * 2] (the stand-alone statistics launch and its read of the map disappear)
+    float* cs_part; int cs_cg, cs_hw, cs_G;
 };
 
 template <typename T> struct Mma;
@@ -149,6 +152,62 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
             }
         }
         __syncthreads();
+    }
+    if (p.cs_part) {
+        // column sums of the image in PARTS row slices (one thread per (slice, column), fixed order), then per 64-row block and group
+        constexpr int PARTS = 64 * NW / BN, RP = BM / PARTS, PPB = 64 / RP;      // slices; rows per slice; slices per 64-row block
+        static_assert(RP >= 8 && RP <= 64 && 64 % RP == 0, "column-sum slices");
+        float* red = sc + BM * LDC + 256;
+        // The summation order is the same for every tile shape (so a sample's statistics do not depend on the batch it runs in): rows in
+        // aligned runs of 8, left to right, then a balanced binary tree over the runs of a 64-row block, then the group's columns in order.
+        static_assert(RP % 8 == 0, "column-sum slices are whole 8-row runs");
+        {
+            const int col = tid % BN, part = tid / BN;
+            float a8[RP / 8], q8[RP / 8];
+#pragma unroll
+            for (int u = 0; u < RP / 8; ++u) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = part * RP + u * 8 + rr;
+                    const float v = (m0 + r < p.M) ? sc[r * LDC + col] : 0.f;
+                    a += v; q += v * v;
+                }
+                a8[u] = a; q8[u] = q;
+            }
+#pragma unroll
+            for (int st = 1; st < RP / 8; st *= 2)
+#pragma unroll
+                for (int u = 0; u < RP / 8; u += 2 * st) { a8[u] += a8[u + st]; q8[u] += q8[u + st]; }
+            red[(part * BN + col) * 2] = a8[0]; red[(part * BN + col) * 2 + 1] = q8[0];
+        }
+        __syncthreads();
+        const int cg = p.cs_cg, ng = BN / cg;
+        if (tid < (BM / 64) * ng) {
+            const int blk = tid / ng, gl = tid - blk * ng;
+            const int col0 = gl * cg;
+            const int m = m0 + blk * 64;
+            if (n0 + col0 < p.N && m < p.M) {
+                float a = 0.f, q = 0.f;
+                for (int j = 0; j < cg; ++j) {
+                    float at[PPB], qt[PPB];
+#pragma unroll
+                    for (int pp = 0; pp < PPB; ++pp) {
+                        const float* e = red + (((blk * PPB + pp) * BN) + col0 + j) * 2;
+                        at[pp] = e[0]; qt[pp] = e[1];
+                    }
+#pragma unroll
+                    for (int st = 1; st < PPB; st *= 2)
+#pragma unroll
+                        for (int u = 0; u < PPB; u += 2 * st) { at[u] += at[u + st]; qt[u] += qt[u + st]; }
+                    a += at[0]; q += qt[0];
+                }
+                const int smp = m / p.cs_hw, pblk = (m - smp * p.cs_hw) >> 6;
+                const int grp = ((int)blockIdx.y * p.N + n0 + col0) / cg;
+                float* o = p.cs_part + (((size_t)smp * (p.cs_hw >> 6) + pblk) * p.cs_G + grp) * 2;
+                o[0] = a; o[1] = q;
+            }
+        }
     }
     constexpr int TPR = BN / 8;            // threads per tile row
     constexpr int RPP = 64 * NW / TPR;     // rows per pass
@@ -1718,7 +1777,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         else grid = 8 * d.tilesM * ((d.tilesN + 7) / 8);       // every XCD gets ceil(tilesN/8) slots per pixel tile
     }
     size_t lds = ((variant == 2 || variant == 5 || variant >= 7) ? 3 : 2) * (size_t)(BM + BN) * 128;
-    const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024;    // f32 output-tile image of the epilogue (+ fused-GroupNorm statistics)
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024 + (d.cs_part ? 64 * 8 * 2 * 4 : 0);    // f32 output-tile image of the epilogue (+ fused-GroupNorm statistics, + column-sum slices)
     if (lds_c > lds) lds = lds_c;
     static bool attr_done = false;                            // one flag per template instantiation
     if (!attr_done) {
@@ -1884,6 +1943,7 @@ static hipError_t launch_choice(const IGemmDev& d, int choice, hipStream_t s) {
     }
 }
 static hipError_t launch_dt(const IGemmDev& d, int dt, int choice, hipStream_t s) {
+    if (d.cs_part && choice >= 100) choice = 24;           // the big-tile launchers do not reserve the column-sum scratch
     if (choice >= 110) {                                // 110..115: 64 pixels x 256 channels (whole 512-byte output rows per workgroup)
         const int c2 = choice - 110;
         const int ring = 2 + (c2 & 1);
@@ -2009,6 +2069,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.x_scale = g.x_scale;
     d.rowrun = 0;
     d.hpool = 0;
+    d.cs_part = g.cs_part; d.cs_cg = g.cs_cg; d.cs_hw = g.cs_hw; d.cs_G = g.cs_G;
     d.groups = g.groups > 1 ? g.groups : 1;
     d.g_x = g.g_x; d.g_w = g.g_w; d.g_b = g.g_b; d.g_y = g.g_y;
     d.gn_gamma = g.gn_gamma; d.gn_beta = g.gn_beta; d.gn_cg = g.gn_gamma ? g.gn_cg : 0; d.gn_hw = g.gn_hw; d.gn_eps = g.gn_eps;
@@ -2042,6 +2103,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if ((g.Cin % CH) || (narrow_stride && (d.xC * (int)dt_size(dt)) % 4) || (d.K % CH) || (d.Kp % CH) || (d.N % 4) || (d.ldy % 4) || (d.ldr % 4))
         return hipErrorInvalidValue;
     if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
+    if (d.cs_part && (d.gn_cg || d.bias || g.x_src_dt >= 0 || d.cs_cg < 1 || 32 % d.cs_cg || d.N % d.cs_cg || d.cs_hw % 64 || d.M % d.cs_hw))
+        return hipErrorInvalidValue;
     if (d.gn_cg) {
         // fused GroupNorm: 64-row tiles of whole samples, 128 channels of whole groups (igemm_epilogue)
         if (g.x_src_dt >= 0 || d.gn_hw <= 0 || 64 % d.gn_hw || d.M % d.gn_hw || d.gn_cg % 8 || 128 % d.gn_cg || d.N % d.gn_cg || d.bias ||

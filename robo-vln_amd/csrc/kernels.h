@@ -42,6 +42,10 @@ struct IGemm {
     // horizontal half of MaxPool2d(3, 2, 1) fused into the epilogue: y is [B*Ho][Wo/2][ldy] (16-bit types, Wo a power of two <= 128, N % 64 == 0,
     // no residual); launch_vpool3s2 finishes the pool
     int hpool = 0;
+    // GroupNorm statistics of the (bias-free) conv output taken from the f32 tile image in the epilogue: sum / sum of squares per
+    // (sample, 64-row pixel block, group) -> cs_part[((b * cs_hw / 64 + block) * cs_G + group) * 2]; cs_hw % 64 == 0, 32 % cs_cg == 0.
+    // launch_groupnorm_apply then normalises without a statistics pass over the map.
+    float* cs_part = nullptr; int cs_cg = 0, cs_hw = 0, cs_G = 0;
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,
@@ -98,7 +102,15 @@ hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int
 // GroupNorm over NHWC x [B,HW,C] in place: x = relu?( (x-mean)*rstd*gamma+beta (+res) ); stats scratch [B*G*2] f32
 // pixel chunks per sample of the two-launch GroupNorm (0: single-launch slab kernel); `stats` must hold gn_stats_floats()
 inline int gn_partials(int HW) { return HW >= 256 ? (HW / 64 < 16 ? HW / 64 : 16) : 0; }
-inline size_t gn_stats_floats(int B, int HW, int G) { const int P = gn_partials(HW); return (size_t)B * (P > 0 ? P : 1) * G * 2; }
+inline size_t gn_stats_floats(int B, int HW, int G) {
+    const int P = gn_partials(HW), PS = HW % 64 == 0 ? HW / 64 : 0;          // two-launch chunks / 64-row blocks of the epilogue statistics
+    const int n = P > PS ? P : PS;
+    return (size_t)B * (n > 0 ? n : 1) * G * 2;
+}
+// second half of the two-launch GroupNorm alone: statistics come from `part` = PS partial sums per (sample, group) (launch_igemm's cs_part)
+hipError_t launch_groupnorm_apply(void* x, const void* res, const float* gamma, const float* beta, const float* part, int PS, int dt, int B,
+                                  int HW, int C, int G, float eps, int relu, hipStream_t s);
+bool groupnorm_apply_ok(int dt, int HW, int C, int G);
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats,
                             int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s);
 // LayerNorm rows: y = LN(x (+res)) * gamma + beta (+ post[row % post_rows][:])

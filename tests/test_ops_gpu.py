@@ -424,3 +424,41 @@ def test_stem_conv_packed_pool(prec, cfg):
     assert lib.hcm_op_stem_conv_packed_pool(_p(x), xcode, _p(w), _p(b), _p(y), code, B, H, W, Cout, 1 / 255.0, _p(scratch), _p(half), None) == 0
     torch.cuda.synchronize()
     assert torch.equal(y.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [
+    # B, H, Cin, Cout, K, stride, pad, groups, residual, relu      (output maps of 256 .. 4096 pixels)
+    (2, 64, 32, 64, 1, 1, 0, 32, False, True),
+    (3, 32, 64, 64, 3, 1, 1, 32, False, True),
+    (2, 32, 64, 256, 1, 1, 0, 32, True, True),
+    (2, 64, 64, 128, 3, 2, 1, 32, False, True),
+    (5, 16, 128, 256, 1, 1, 0, 32, True, False),
+    (1, 64, 32, 32, 3, 1, 1, 16, False, True),
+])
+def test_conv2d_groupnorm_large_map_epilogue_stats(prec, cfg):
+    """conv + GroupNorm for the large maps: statistics from the conv's f32 tile image (column sums per 64-pixel block and group in the
+    epilogue), one normalising launch -- against torch's conv2d + group_norm."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, Cin, Cout, K, stride, pad, G, use_res, relu = cfg
+    x = _rnd(B, H, H, Cin, seed=1).to(tdt)
+    w = (_rnd(Cout, K, K, Cin, seed=2) * (2.0 / (Cin * K * K)) ** 0.5).to(tdt)
+    gamma, beta = _rnd(Cout, seed=3) * 0.5 + 1.0, _rnd(Cout, seed=4) * 0.1
+    conv = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride=stride, padding=pad)
+    Ho = conv.shape[2]
+    res = _rnd(B, Ho, Ho, Cout, seed=5).to(tdt) if use_res else None
+    ref = F.group_norm(conv, G, gamma, beta, 1e-5)
+    if use_res:
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    if relu:
+        ref = F.relu(ref)
+    xd, wd, gd, bd = x.cuda(), w.cuda(), gamma.cuda(), beta.cuda()
+    rd = res.cuda() if use_res else None
+    y = torch.full((B, Ho, Ho, Cout), float("nan"), device="cuda", dtype=tdt)
+    rc = lib.hcm_op_conv2d_gn_large(_p(xd), _p(wd), _p(gd), _p(bd), _p(rd) if use_res else None, _p(y), code, B, H, H, Cin, Cout, K, K, stride,
+                                    pad, G, 1e-5, int(relu), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 2 * tol * max(1.0, ref.abs().max().item()), err
