@@ -187,6 +187,11 @@ struct Fwd {
         // half width), a vertical-only pool follows; exact.  Not while taps are captured: `_conv1` is the full-width map.
         static const bool no_hpool = getenv("HCM_NO_STEM_HPOOL") != nullptr;
         const bool hpool = packed && !no_hpool && !ctx->taps_on && Wo >= 2 && Wo <= 128 && !(Wo & (Wo - 1)) && (c1 % 64) == 0;
+        // GroupNorm statistics of the packed depth stem from its conv's epilogue (see conv_gn)
+        static const bool no_cs_stem = getenv("HCM_NO_GN_EPISTATS") != nullptr;
+        float* stem_stats = nullptr;
+        if (t.gn && st.x_dt == -2 && !no_cs_stem && groupnorm_apply_ok(t.conv1_packed.dt, Ho * Wo, c1, G) && c1 % (c1 / G) == 0)
+            stem_stats = alloc_f(gn_stats_floats(B, Ho * Wo, G));
         if (t.gn && st.x_dt == -2) {
             // depth stem on the packed 1-channel frame: kernel row = 8 contiguous elements (7 taps + a zero-weight slot), the GEMM's
             // "virtual pixel" = the stride of 2 elements
@@ -197,12 +202,16 @@ struct Fwd {
                 g.B = B; g.H = st.H + 6; g.W = (st.W + 8) / 2; g.Cin = 8; g.xC = 2;
                 g.Ho = Ho; g.Wo = Wo; g.KH = 7; g.KW = 1; g.stride = 2; g.stride_w = 1; g.pad = 0;
                 g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = ACT_NONE;
+                if (stem_stats) { g.cs_part = stem_stats; g.cs_cg = c1 / G; g.cs_hw = Ho * Wo; g.cs_G = G; }
                 ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
             }
         } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
-        if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
+        if (t.gn && stem_stats) {
+            if (!dry) ck(launch_groupnorm_apply(slot[0], nullptr, t.n_conv1.gamma, t.n_conv1.beta, stem_stats, Ho * Wo / 64, t.conv1_packed.dt, B, Ho * Wo, c1, G,
+                                                1e-5f, 1, s), "groupnorm apply (stem)");
+        } else if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
         if (!hpool) tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
         if (hpool) {
