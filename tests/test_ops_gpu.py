@@ -437,6 +437,7 @@ def test_stem_conv_packed_pool(prec, cfg):
     (1, 64, 32, 32, 3, 1, 1, 16, False, True),
     (3, 24, 64, 64, 3, 1, 1, 32, True, True),        # 576 pixels per sample: 128-row tiles straddle two samples
     (7, 16, 64, 128, 1, 1, 0, 32, False, True),      # M = 1792: the last tile is half empty
+    (3, 16, 128, 512, 1, 1, 0, 64, True, True),      # 16 x 16 x 512: the GN-ResNet pair's layer3 expansion
 ])
 def test_conv2d_groupnorm_large_map_epilogue_stats(prec, cfg):
     """conv + GroupNorm for the large maps: statistics from the conv's f32 tile image (column sums per 64-pixel block and group in the
