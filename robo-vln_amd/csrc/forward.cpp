@@ -244,7 +244,8 @@ struct Fwd {
                 static const bool no_next = getenv("HCM_NO_BNECK_NEXT") != nullptr;
                 static const bool no_dsfold = getenv("HCM_NO_BNECK_DSFOLD") != nullptr;
                 const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
-                const bool next = nb && !no_next && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
+                static const int next_only = getenv("HCM_BNECK_NEXT_ONLY") ? atoi(getenv("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
+                const bool next = nb && !no_next && (!next_only || next_only == b.c2.Cout) && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
                                   nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
                                   ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
                 // layer1's first block: its 1x1 down-sample conv (64 -> 256, same stride) rides in the expansion GEMM as 64 more K columns
