@@ -701,6 +701,8 @@ hipError_t launch_rnn_prep(const float* h_in, const float* mask, float* xh, int 
 __device__ __forceinline__ void heads_eval(const float* hs, int Hd, const Heads& hd, int b) {
     // hs: new hidden state of sample b in LDS; one wave per output row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __shared__ float lg[64];
+    __shared__ int best_s;
     for (int r = wave; r < hd.r0 + hd.r1; r += nw) {
         const bool first = r < hd.r0;
         const int rr = first ? r : r - hd.r0;
@@ -709,9 +711,23 @@ __device__ __forceinline__ void heads_eval(const float* hs, int Hd, const Heads&
         for (int j = lane; j < Hd; j += 64) acc += w[j] * hs[j];
         acc = wave_sum(acc);
         if (lane == 0) {
-            if (first) hd.out0[(size_t)b * hd.ld0 + rr] = acc + hd.b0[rr];
+            if (first) { const float v = acc + hd.b0[rr]; hd.out0[(size_t)b * hd.ld0 + rr] = v; if (rr < 64) lg[rr] = v; }
             else hd.out1[(size_t)b * hd.ld1 + rr] = acc + hd.b1[rr];
         }
+    }
+    if (hd.pred) {                        // (kernel-uniform) argmax of the first head + embedding row of the winner
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int best = 0;
+            float bv = lg[0];
+            for (int j = 1; j < hd.r0; ++j)
+                if (lg[j] > bv) { bv = lg[j]; best = j; }
+            hd.pred[b] = best;
+            best_s = best < hd.emb_rows ? best : hd.emb_rows - 1;
+        }
+        __syncthreads();
+        const float* e = hd.emb + (size_t)best_s * hd.emb_dim;
+        for (int j = threadIdx.x; j < hd.emb_dim; j += blockDim.x) hd.emb_out[(size_t)b * hd.emb_ld + j] = e[j];
     }
 }
 

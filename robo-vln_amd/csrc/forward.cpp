@@ -486,6 +486,7 @@ struct Fwd {
     LoBufs* lo_early = nullptr;
     const float* lo_h_in_early = nullptr;
     float* lo_pre = nullptr;
+    bool pred_fused = false;          // argmax + sub-task embedding done by the high-level cell kernel (hi_tail)
 
 
     HiBufs hi_alloc(int B) {
@@ -744,6 +745,15 @@ struct Fwd {
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
+        static const bool no_pred_fuse = getenv("HCM_NO_PRED_FUSE") != nullptr;
+        pred_fused = false;
+        if (split && lo_early && !no_pred_fuse && c.num_actions <= 64) {
+            // fused act(): argmax + the low-level model's sub-task embedding lookup ride in the high-level cell kernel
+            const LowW& lw = ctx->lo;
+            hd.pred = ctx->pred_buf; hd.emb = lw.subtask_emb; hd.emb_dim = 32; hd.emb_ld = lo_early->ldx; hd.emb_rows = c.num_sub_tasks + 1;
+            hd.emb_out = lo_early->xh + lw.rnn.xcol(c.depth_out + c.rgb_out);
+            pred_fused = true;
+        }
         if (split) rnn_finish(w.rnn, xh, ldx, B, hi_pre, h_in, mask, h_out, hd);
         else rnn_scan(w.rnn, xh, ldx, T, B / T, h_in, mask, h_out, hd);
         tap_rnn_in("hi.rnn_in", w.rnn, xh, ldx, B);
@@ -778,7 +788,8 @@ struct Fwd {
         const hcm_config& c = ctx->cfg;
         const LowW& w = ctx->lo;
         use(ctx->dt_vla);
-        if (!dry) ck(launch_embed_rows(w.subtask_emb, subtask, lb.xh, B, 32, lb.ldx, w.rnn.xcol(c.depth_out + c.rgb_out), c.num_sub_tasks + 1, s), "subtask emb");
+        if (!dry && !(pred_fused && subtask == ctx->pred_buf))
+            ck(launch_embed_rows(w.subtask_emb, subtask, lb.xh, B, 32, lb.ldx, w.rnn.xcol(c.depth_out + c.rgb_out), c.num_sub_tasks + 1, s), "subtask emb");
         Heads hd;
         hd.w0 = w.lin_w; hd.b0 = w.lin_b; hd.out0 = vel; hd.r0 = c.lo_actions; hd.ld0 = ld_vel;
         hd.w1 = w.stop_w; hd.b1 = w.stop_b; hd.out1 = stop; hd.r1 = 1; hd.ld1 = ld_stop;
@@ -1005,7 +1016,7 @@ struct Fwd {
         const int64_t* st_ids = subtask;
         if (do_hi && do_lo) {
             // pred = argmax(output, dim=1)  (hierarchical_trainer.py:1098)
-            if (!dry) ck(launch_argmax(logits, ctx->pred_buf, B, ctx->cfg.num_actions, ld_logits, s), "argmax");
+            if (!dry && !pred_fused) ck(launch_argmax(logits, ctx->pred_buf, B, ctx->cfg.num_actions, ld_logits, s), "argmax");
             st_ids = ctx->pred_buf;
         }
         if (do_lo) lo_tail(B, lb, lo_h_in, mask, st_ids, vel, ld_vel, stop, ld_stop, lo_h_out);
