@@ -5,6 +5,7 @@ tuple-in / tuple-out `forward(batch)` contract and properties, all arithmetic in
     output, stop_out, rnn_hidden_states = net((observations, rnn_hidden_states, prev_actions, masks))    # robo_vln_trainer.py:1096
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -132,13 +133,19 @@ class CMAEngine:
             self._static = st
         cur, gs = torch.cuda.current_stream(), self._gstream
         gs.wait_stream(cur)
+        # observation buffers whose addresses repeat from the previous call are read in place (see HCMEngine._act_graph)
+        ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr())
+        direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
+        st["last_ptrs"] = ptrs
+        st["hold"] = (rgb, depth, ids)
+        g_rgb, g_depth, g_ids = (rgb, depth, ids) if direct else (st["rgb"], st["depth"], st["ids"])
         with torch.cuda.stream(gs):
             i = st["tick"] & 1
-            for dst, src in ((st["rgb"], rgb), (st["depth"], depth), (st["ids"], ids), (st["mask"], m), (st["h"][1 - i], h_in)):
+            for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (st["mask"], m), (st["h"][1 - i], h_in)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
-            _lib.check(self._lib.hcm_cma_forward(self._h, st["rgb"].data_ptr(), _TORCH_DT[rgb.dtype], st["depth"].data_ptr(),
-                                                 st["ids"].data_ptr(), _TORCH_DT[ids.dtype], B, st["h"][1 - i].data_ptr(),
+            _lib.check(self._lib.hcm_cma_forward(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
+                                                 g_ids.data_ptr(), _TORCH_DT[ids.dtype], B, st["h"][1 - i].data_ptr(),
                                                  st["mask"].data_ptr(), st["out"][i].data_ptr(), st["stop"][i].data_ptr(),
                                                  st["h"][i].data_ptr(), C.c_void_p(gs.cuda_stream)), self._h)
             st["tick"] += 1
