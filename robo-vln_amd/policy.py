@@ -208,20 +208,20 @@ class HCMEngine:
             # output buffers) are read in place: the captured graph is keyed by their addresses like by any other argument.
             # Tensors seen for the first time go through the engine's static copies, so that fresh allocations every step
             # do not force a new capture every step.
-            ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr())
+            ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), m.data_ptr())
             direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
             st["last_ptrs"] = ptrs
-            st["hold"] = (rgb, depth, ids)                 # keep the caller's tensors alive while the graph may read them
-            g_rgb, g_depth, g_ids = (rgb, depth, ids) if direct else (st["rgb"], st["depth"], st["ids"])
+            st["hold"] = (rgb, depth, ids, m)              # keep the caller's tensors alive while the graph may read them
+            g_rgb, g_depth, g_ids, g_m = (rgb, depth, ids, m) if direct else (st["rgb"], st["depth"], st["ids"], st["mask"])
             with torch.cuda.stream(gs):
                 i = st["tick"] & 1
-                for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (st["mask"], m),
+                for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (g_m, m),
                                  (st["hh"][1 - i], hh), (st["lh"][1 - i], lh)):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src, non_blocking=True)
                 _lib.check(self._lib.hcm_act_ex(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
                                                 g_ids.data_ptr(), _TORCH_DT[ids.dtype], B, st["hh"][1 - i].data_ptr(),
-                                                st["lh"][1 - i].data_ptr(), st["mask"].data_ptr(), st["rec"][i].data_ptr(),
+                                                st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
                                                 st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
                 st["tick"] += 1
             cur.wait_stream(gs)
