@@ -245,11 +245,11 @@ def main():
                          "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
                          # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
                          # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
-                         "traffic": 15.2 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
+                         "traffic": 15.07 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
                          "traffic_source": "profiles/r1_pmc_traffic_bench.md",
                          "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s",
                          # the same step seen from the memory side: measured HBM bytes per step / step time vs the 8 TB/s peak
-                         "hbm_view": ({"achieved_TBps": round(15.2 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(15.2 / ms / 8.0, 4)}
+                         "hbm_view": ({"achieved_TBps": round(15.07 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(15.07 / ms / 8.0, 4)}
                                       if B == 64 else None)},
         }
         if args.reuse_instruction:
