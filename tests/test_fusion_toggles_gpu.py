@@ -1,5 +1,5 @@
 """Integration check of the fused launches of the RGB trunk (bottleneck tail, next block's reduction, horizontal half of the stem
-max-pool): they are bit-identical rewrites, so a whole act() step with them must equal the step with every one of them switched off
+max-pool) and of the serial tail (argmax + sub-task embedding inside the high-level cell kernel): they are bit-identical rewrites, so a whole act() step with them must equal the step with every one of them switched off
 (HCM_NO_* knobs; read once per process, hence sub-processes).  The down-sample fold changes one rounding and is compared to
 tolerance.  Covers the slot / pointer plumbing in forward.cpp that the operator-level tests cannot see."""
 import os
@@ -46,7 +46,7 @@ def test_fused_rgb_trunk_launches_equal_the_separate_ones():
     with tempfile.TemporaryDirectory() as d:
         # the down-sample fold off in both runs: everything else must then agree to the bit
         fused = _run({"HCM_NO_BNECK_DSFOLD": "1"}, os.path.join(d, "a.npz"))
-        plain = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_BNECK_FUSE": "1", "HCM_NO_STEM_HPOOL": "1"}, os.path.join(d, "b.npz"))
+        plain = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_BNECK_FUSE": "1", "HCM_NO_STEM_HPOOL": "1", "HCM_NO_PRED_FUSE": "1"}, os.path.join(d, "b.npz"))
         nonext = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_BNECK_NEXT": "1"}, os.path.join(d, "c.npz"))
         default = _run({}, os.path.join(d, "e.npz"))
     for k in ("rec", "hh", "lh"):
