@@ -61,7 +61,9 @@ typedef struct hcm_config {
     int32_t max_batch;        /* workspace is sized for this many environments per call */
     int32_t rgb_h, rgb_w;     /* frames are NHWC */
     int32_t depth_h, depth_w;
-    int32_t instr_len;        /* L */
+    int32_t instr_len;        /* MAXIMUM instruction length: sizes the workspace (and the positional tables); every forward call
+                                 passes its own L <= instr_len (the reference model accepts any (B or 1, L) per call and its
+                                 eval loop feeds unpadded ids, common/utils.py:18-20); <= bert_max_pos (512) */
     int32_t rgb_encoder;      /* hcm_encoder; SIMPLECNN is valid for the low-level model only */
     int32_t depth_encoder;
     int32_t rgb_out, depth_out, depth_baseplanes;
@@ -72,6 +74,8 @@ typedef struct hcm_config {
     int32_t use_prev_action;            /* must be 0: broken branch in the reference (seq2seq_highlevel_cma.py:203-207) */
     int32_t ablate_instruction;         /* must be 0: broken branch (:183-184) */
     int32_t progress_monitor;           /* must be 0 in forward (:221-225 references an undefined name) */
+    int32_t ablate_depth;               /* working flags of both models: the encoder output is multiplied by 0 */
+    int32_t ablate_rgb;                 /* (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135, config/default.py:92-93) */
     int32_t reserved[8];                /* [0..3]: storage-type override (hcm_dtype + 1, 0 = default) for the depth trunk /
                                            BERT / cross-modal block / RGB trunk; see DESIGN.md section 5 */
 } hcm_config;
@@ -98,13 +102,21 @@ int hcm_finalize(hcm_handle h);
  * (hierarchical_trainer.py:1096-1097 -> models/seq2seq_highlevel_cma.py:170-233).
  *   rgb    (B,H,W,3)  rgb_dtype HCM_F32 (values 0..255, the batch_obs contract common/utils.py:78-83) or HCM_U8
  *   depth  (B,H,W,1)  f32
- *   ids    (B,L)      ids_dtype HCM_I32 / HCM_I64 / HCM_F32 (the reference carries ids as f32 and casts .long())
+ *   ids    (B,L)      ids_dtype HCM_I32 / HCM_I64 / HCM_F32 (the reference carries ids as f32 and casts .long());
+ *                     L is per call, 1 <= L <= cfg.instr_len: BERT runs without an attention mask and the poolers average over
+ *                     all L positions (:209-210), so a padded instruction gives a different result than the unpadded one --
+ *                     pass the ids exactly as the reference caller does
+ *   lengths (B,) int32 device pointer or NULL.  NULL = the reference call: every row has L tokens.  The reference evaluates ONE
+ *                     environment per call with its unpadded instruction; a batched rollout whose environments carry
+ *                     instructions of different lengths pads the rows to a common L and passes each row's token count here:
+ *                     environment b then attends over / pools over its first lengths[b] positions only and gets, bit for bit,
+ *                     the result of its own unpadded (1, lengths[b]) call.  Values are clamped to [1, L].
  *   h_in   (R,B,hidden) f32, R = hcm_query(HCM_NUM_RECURRENT_LAYERS)
  *   mask   (B,) f32   -- column 0 of the reference's masks (masks[:,0], :208); 0 at episode start
  *   logits (B,num_actions) f32 out;  h_out (R,B,hidden) f32 out (may alias h_in)
  * prev_actions is ignored on the working path of the reference and is not part of this ABI. */
 int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
-                     const void* ids, int ids_dtype, int B,
+                     const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
                      const float* h_in, const float* mask,
                      float* logits, float* h_out, void* stream);
 
@@ -121,7 +133,7 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
  *   rgb/depth/ids/subtask: T*N rows, time-major (row t*N + n);  masks (T*N,) f32;  h_in/h_out (R,N,hidden);
  *   logits (T*N,num_actions) / vel (T*N,2) / stop (T*N,1).  T*N must not exceed max_batch.  Inference only (no autograd). */
 int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
-                         int T, int N, const float* h_in, const float* masks, float* logits, float* h_out, void* stream);
+                         const int32_t* lengths /* (T*N,) or NULL */, int T, int N, int L, const float* h_in, const float* masks, float* logits, float* h_out, void* stream);
 int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, int T, int N,
                         const float* h_in, const float* masks, const int64_t* subtask,
                         float* vel, float* stop, float* h_out, void* stream);
@@ -131,25 +143,28 @@ int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const floa
  * When called repeatedly with the same pointers on a non-default stream, the step (all forked encoder streams
  * included) is captured into a hipGraph on the second call and replayed afterwards (HCM_GRAPH=0 disables). */
 int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
-            const void* ids, int ids_dtype, int B,
+            const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
             const float* hi_h_in, const float* lo_h_in, const float* mask,
             float* record, float* hi_h_out, float* lo_h_out, void* stream);
 
 /* hcm_act with flags.  HCM_ACT_REUSE_INSTRUCTION: the instruction ids of every environment are the same as in the previous
- * hcm_act / hcm_act_ex call on this handle (same B): BERT and the instruction stream of Visual_Ling_Attn are not recomputed,
+ * hcm_act / hcm_act_ex call on this handle (same B and L): BERT and the instruction stream of Visual_Ling_Attn are not recomputed,
  * the tensors of the previous step are reused (the reference recomputes them every step although an instruction is fixed
  * for an episode, seq2seq_highlevel_cma.py:189-195).  NOT the measured configuration: bench.py and the parity tests run with
  * flags = 0; with the flag the step executes 13.8 GFLOP per environment less.  Returns HCM_ERR_STATE if there is no
- * previous step with this batch size. */
+ * previous hcm_act / hcm_act_ex step with this batch size and L, or if any other forward entry point ran on the handle in between
+ * (they re-use the workspace region that holds the cached tensors). */
 enum hcm_act_flags { HCM_ACT_REUSE_INSTRUCTION = 1 };
-int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
+               const int32_t* lengths, int B, int L,
                const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                int flags, void* stream);
 
 /* Companion of HCM_ACT_REUSE_INSTRUCTION for batched rollouts in which a few environments start a new episode: recomputes
  * the cached instruction stream of the n listed environments (HOST array of indices into the batch) from ids (B,L) (device),
  * leaving the other environments' cached tensors untouched.  Needs a previous hcm_act / hcm_act_ex step at this batch size. */
-int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, int B, const int32_t* env_indices, int n, void* stream);
+int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
+                            const int32_t* env_indices, int n, void* stream);
 
 int hcm_query(hcm_handle h, int what, int64_t* out);
 
@@ -167,7 +182,7 @@ typedef struct hcm_cma_config {
     int32_t precision;            /* HCM_BF16 (16-bit trunks, fp32 text / recurrent / attention side) or HCM_F32 */
     int32_t max_batch;
     int32_t rgb_h, rgb_w, depth_h, depth_w;
-    int32_t instr_len;            /* padded token count per instruction handed to forward (<= 256) */
+    int32_t instr_len;            /* MAXIMUM padded token count per instruction (<= 256); every forward passes its own L <= instr_len */
     int32_t vocab_size, embedding_size, instr_hidden, bidirectional;   /* MODEL.INSTRUCTION_ENCODER.* (default.py:97-115) */
     int32_t rgb_out, depth_out, depth_baseplanes;
     int32_t hidden, rnn_type;     /* MODEL.STATE_ENCODER.* for both state encoders */
@@ -187,7 +202,7 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out);
  *   mask (B,) f32 (column 0 of the reference's masks, cma.py:219)
  *   out (B,num_actions), stop (B,1), h_out (R,B,hidden): f32 outputs.  The reference writes the new hidden state into
  *   the tensor it was given and returns it; here h_out may alias h_in to get the same effect. */
-int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L,
                     const float* h_in, const float* mask, float* out, float* stop, float* h_out, void* stream);
 
 /* ---- test / profiling hooks (not part of the drop-in surface) ---- */
@@ -204,7 +219,7 @@ int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t c
 int hcm_debug_igemm_prof(uint64_t* out8, int reset);
 
 /* Stand-alone operator entry points used by the kernel-level parity tests (device pointers, f32 or bf16
- * per `dtype`; layouts NHWC / row-major).  See robo-vln_amd/csrc/ops_api.cpp. */
+ * per `dtype`; layouts NHWC / row-major); implemented at the end of robo-vln_amd/csrc/api.cpp. */
 int hcm_op_conv2d(const void* x, const void* w_ohwi, const float* bias, const void* residual, void* y,
                   int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                   int act, void* stream);

@@ -23,7 +23,31 @@ CASES = {
     "cfg4_L160_N6": (dict(rgb_hw=128, depth_hw=128, instr_len=160, vla_layers=6), 1, 1, "hi"),
     # reference-native frame sizes (robo_vln_task.yaml:10-17): RGB 224 (7x7 -> overlapping adaptive pool), depth 256
     "native_224_256": (dict(rgb_hw=224, depth_hw=256, instr_len=40, bert_layers=2), 1, 1, "both"),
+    # working ablation flags of both models (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135)
+    "ablate_depth_128": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2, ablate_depth=True), 2, 2, "both"),
+    "ablate_rgb_128": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2, ablate_rgb=True), 2, 2, "both"),
 }
+
+# The reference's eval loop feeds the model the UNPADDED token ids of the episode's instruction as a (1, L) tensor
+# (common/utils.py:18-20 returns `output.ids`; hierarchical_trainer.py:1193-1196), L differing from episode to episode.
+# name -> (config kwargs, batch, [L of step 0, L of step 1, ...]): one engine / one reference model stepped through all lengths
+# with the recurrent state carried; the instruction is (1, L), row-expanded to the batch by the model (:189-190).
+VARLEN_CASES = {
+    "varlen_128": (dict(rgb_hw=128, depth_hw=128, bert_layers=2, vla_layers=2), 2, [7, 37, 80, 123, 200, 320]),
+}
+
+
+def varlen_case_config(name):
+    kw, batch, lens = VARLEN_CASES[name]
+    return HCMConfig(**kw).validate(), batch, list(lens)
+
+
+def varlen_ids(cfg, L, step):
+    """(1, L) unpadded instruction: [CLS]=101, L-2 word pieces, [SEP]=102 -- the shape of `tokenizer.encode(text).ids`."""
+    ids = synth.randint(f"obs/varlen/{step}", L, 1000, cfg.bert_vocab, SEED).reshape(1, L)
+    ids[0, 0] = 101
+    ids[0, L - 1] = 102
+    return ids
 
 SEED = 0
 TAP_MAX = 16384

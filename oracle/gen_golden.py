@@ -80,7 +80,11 @@ def run_case(name):
             records.append(torch.cat(rec, dim=1))
     dt = time.time() - t0
     out = {"records": torch.stack(records).numpy(), "hi_hidden": hi_h.numpy(), "lo_hidden": lo_h.numpy()}
+    # the hooks sit on the encoder modules, i.e. BEFORE the `* 0` of an ablated encoder: those tensors reach no output, drop them
+    dropped = (("hi.depth_spatial", "lo.depth_flat") if cfg.ablate_depth else ()) + (("hi.rgb_spatial", "lo.rgb_flat") if cfg.ablate_rgb else ())
     for k, v in taps.items():
+        if k in dropped:
+            continue
         if k == "hi.vla":
             out["tap.hi.vla_rgb"] = cases.subsample(v[0].numpy())
             out["tap.hi.vla_depth"] = cases.subsample(v[1].numpy())
@@ -135,6 +139,40 @@ def compare_oracle(name, gold, hi_sd, lo_sd):
                         print(f"    {pre + k:24s} max-abs {dd:.3e}  (|gold| max {np.abs(g).max():.3f} std {g.std():.3f})")
                         worst = max(worst, dd)
         print(f"    step {t} record max-abs {d:.3e}   record={np.array2string(rec[0], precision=4)}")
+    return worst
+
+
+def run_varlen_case(name):
+    """One reference model pair stepped through instructions of different, unpadded lengths ((1, L) ids), state carried."""
+    cfg, B, lens = cases.varlen_case_config(name)
+    hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
+    hi, lo = ref_shims.build_models(cfg, hi_sd, lo_sd)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    R = cfg.num_recurrent_layers
+    hi_h = torch.zeros(R, B, cfg.hidden); lo_h = torch.zeros(R, B, cfg.hidden)
+    o_hh = torch.zeros(R, B, cfg.hidden); o_lh = torch.zeros(R, B, cfg.hidden)
+    prev = torch.zeros(B, 2, dtype=torch.long)
+    records, worst = [], 0.0
+    with torch.no_grad():
+        for t, L in enumerate(lens):
+            obs_np = synth.make_observations(cfg, B, step=t, seed=cases.SEED)
+            obs_np["instruction"] = cases.varlen_ids(cfg, L, t)
+            obs = {k: torch.from_numpy(v.astype(np.float32)) for k, v in obs_np.items()}
+            m = cases.step_masks(B, t)
+            masks = ref_shims.ref_masks(m)
+            logits, hi_h = hi((dict(obs), hi_h, prev, masks))
+            vel, stop, lo_h = lo((dict(obs), lo_h, prev, masks, torch.argmax(logits, dim=1)))
+            records.append(torch.cat([logits, vel, stop], dim=1))
+            rec_o, o_hh, o_lh = ora.act(obs_np, o_hh, o_lh, m)
+            worst = max(worst, (rec_o - records[-1]).abs().max().item())
+    out = {"records": torch.stack(records).numpy(), "hi_hidden": hi_h.numpy(), "lo_hidden": lo_h.numpy(),
+           "meta": np.array(repr(dict(case=name, config=repr(cfg.to_dict()), batch=B, lengths=lens, seed=cases.SEED, torch=torch.__version__,
+                                      note="reference hi/lo models stepped with UNPADDED (1, L) instructions of these lengths, one step each")))}
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    worst = max(worst, (o_hh - hi_h).abs().max().item(), (o_lh - lo_h).abs().max().item())
+    print(f"[{name}] unpadded lengths {lens} B={B}: oracle-vs-reference worst max-abs {worst:.3e}")
     return worst
 
 
@@ -209,9 +247,10 @@ def run_cma_case(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(cases.CASES) + list(cases.SEQ_CASES) + list(cases.CMA_CASES))
+    names = sys.argv[1:] or (list(cases.CASES) + list(cases.VARLEN_CASES) + list(cases.SEQ_CASES) + list(cases.CMA_CASES))
     bad = 0
     for n in names:
-        w = run_cma_case(n) if n in cases.CMA_CASES else run_seq_case(n) if n in cases.SEQ_CASES else run_case(n)
+        w = (run_cma_case(n) if n in cases.CMA_CASES else run_seq_case(n) if n in cases.SEQ_CASES
+             else run_varlen_case(n) if n in cases.VARLEN_CASES else run_case(n))
         bad |= (w > 1e-4)
     sys.exit(1 if bad else 0)

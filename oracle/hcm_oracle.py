@@ -317,6 +317,10 @@ class HighLevelOracle:
         mask = torch.as_tensor(mask).float().reshape(B, -1)[:, 0]   # masks[:,0] (:208)
         dep = depth_resnet_spatial(depth, w.sub("depth_encoder."), cfg.depth_baseplanes // 2).flatten(2)  # :178-179
         rg = rgb_resnet_spatial(rgb, w.sub("rgb_encoder.")).flatten(2)                                     # :180-181
+        if cfg.ablate_depth:
+            dep = dep * 0                                                                                  # :185-186
+        if cfg.ablate_rgb:
+            rg = rg * 0                                                                                    # :187-188
         ids = ids.expand(B, ids.shape[1])                                                                  # :189-190
         emb = bert_encoder(ids, w.sub("embedding_layer."), cfg.bert_layers, cfg.bert_heads)                # :192-195
         rgb_sp = F.conv1d(rg, w("rgb_kv.weight"), w("rgb_kv.bias"))                                        # :198
@@ -360,6 +364,10 @@ class LowLevelOracle:
             r = rgb_resnet_flat(rgb, w.sub("rgb_encoder."))                                                # :129
         else:
             r = simple_rgb_cnn(rgb, w.sub("rgb_encoder."))
+        if cfg.ablate_depth:
+            d = d * 0                                                                                      # :132-133
+        if cfg.ablate_rgb:
+            r = r * 0                                                                                      # :134-135
         st = w("sub_task_embedding.weight")[subtask]                                                       # :141
         x = torch.cat([d, r, st], dim=1)                                                                   # :143
         h, hid = rnn_forward(x, hidden, mask, w.sub("state_encoder."), cfg.rnn_type)                       # :147
@@ -378,8 +386,25 @@ class PolicyOracle:
         self.hi = HighLevelOracle(cfg, hi_sd)
         self.lo = LowLevelOracle(cfg, lo_sd)
 
-    def act(self, obs, hi_h, lo_h, mask):
-        logits, hi_h2 = self.hi.forward(obs, hi_h, mask)
+    def hi_forward_ragged(self, obs, hi_h, mask, lengths):
+        """A padded batch whose environment b owns the first lengths[b] tokens of its row == the reference called once per
+        environment with that environment's unpadded (1, lengths[b]) instruction (its eval loop runs one environment,
+        hierarchical_trainer.py:1088-1197)."""
+        B = len(lengths)
+        mask = torch.as_tensor(mask).float().reshape(B, -1)[:, 0]
+        outs, hs = [], []
+        for b in range(B):
+            ob = {"rgb": obs["rgb"][b:b + 1], "depth": obs["depth"][b:b + 1], "instruction": obs["instruction"][b:b + 1, :int(lengths[b])]}
+            lg, hb = self.hi.forward(ob, torch.as_tensor(hi_h)[:, b:b + 1], mask[b:b + 1])
+            outs.append(lg)
+            hs.append(hb)
+        return torch.cat(outs, 0), torch.cat(hs, 1)
+
+    def act(self, obs, hi_h, lo_h, mask, lengths=None):
+        if lengths is not None:
+            logits, hi_h2 = self.hi_forward_ragged(obs, hi_h, mask, lengths)
+        else:
+            logits, hi_h2 = self.hi.forward(obs, hi_h, mask)
         pred = torch.argmax(logits, dim=1)                                                                 # :1098
         vel, stop, lo_h2 = self.lo.forward(obs, lo_h, mask, pred)
         return torch.cat([logits, vel, stop], dim=1), hi_h2, lo_h2

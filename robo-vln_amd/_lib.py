@@ -26,7 +26,7 @@ class HcmConfigStruct(C.Structure):
         "vla_layers", "d_model", "vla_heads", "d_ff", "vis_in", "ins_in",
         "hidden", "rnn_type", "num_actions", "num_sub_tasks", "lo_actions",
         "bert_layers", "bert_hidden", "bert_heads", "bert_inter", "bert_vocab", "bert_max_pos",
-        "build_high", "build_low", "use_prev_action", "ablate_instruction", "progress_monitor")] + [("reserved", C.c_int32 * 8)]
+        "build_high", "build_low", "use_prev_action", "ablate_instruction", "progress_monitor", "ablate_depth", "ablate_rgb")] + [("reserved", C.c_int32 * 8)]
 
 
 class HcmCmaConfigStruct(C.Structure):
@@ -38,24 +38,24 @@ class HcmCmaConfigStruct(C.Structure):
 
 EXPORTS = {
     "hcm_cma_create": (C.c_int, [C.POINTER(HcmCmaConfigStruct), C.POINTER(C.c_void_p)]),
-    "hcm_cma_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "hcm_cma_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_create": (C.c_int, [C.POINTER(HcmConfigStruct), C.POINTER(C.c_void_p)]),
     "hcm_load_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "hcm_finalize": (C.c_int, [C.c_void_p]),
-    "hcm_high_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "hcm_high_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_low_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "hcm_high_forward_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+    "hcm_high_forward_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_low_forward_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "hcm_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "hcm_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "hcm_last_error": (C.c_char_p, [C.c_void_p]),
     "hcm_destroy": (None, [C.c_void_p]),

@@ -101,8 +101,9 @@ class CMAEngine:
             if tuple(depth.shape) != (B, c.depth_hw, c.depth_hw, 1):
                 raise ValueError(f"depth must be (B,{c.depth_hw},{c.depth_hw},1), got {tuple(depth.shape)}")
             ids = self._dev(observations["instruction"], (torch.int64, torch.int32, torch.float32))
-            if ids.dim() != 2 or ids.shape[1] != c.instr_len:
-                raise ValueError(f"instruction must be (B or 1, {c.instr_len}), got {tuple(ids.shape)}")
+            # cfg.instr_len is the longest padded instruction the workspace is sized for; every call brings its own L
+            if ids.dim() != 2 or ids.shape[0] not in (1, B) or not 1 <= ids.shape[1] <= c.instr_len:
+                raise ValueError(f"instruction must be (B or 1, L <= {c.instr_len}), got {tuple(ids.shape)}")
             ids = ids.expand(B, ids.shape[1]).contiguous()                       # cma.py:226
             h_in = self._dev(hidden, (torch.float32,))
             R = self.num_recurrent_layers
@@ -116,7 +117,7 @@ class CMAEngine:
             h_out = torch.empty_like(h_in)
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self._lib.hcm_cma_forward(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
-                                                 _TORCH_DT[ids.dtype], B, h_in.data_ptr(), m.data_ptr(), out.data_ptr(),
+                                                 _TORCH_DT[ids.dtype], B, ids.shape[1], h_in.data_ptr(), m.data_ptr(), out.data_ptr(),
                                                  stop.data_ptr(), h_out.data_ptr(), st), self._h)
         return out, stop, h_out
 
@@ -126,7 +127,8 @@ class CMAEngine:
             self._gstream = torch.cuda.Stream(device=self.device)
         st = self._static
         if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype:
-            st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth), "ids": torch.empty_like(ids),
+            st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth),
+                  "ids": torch.empty(B * c.instr_len, device=self.device, dtype=ids.dtype),
                   "mask": torch.empty_like(m), "h": [torch.zeros_like(h_in) for _ in range(2)],
                   "out": [torch.empty(B, c.num_actions, device=self.device) for _ in range(2)],
                   "stop": [torch.empty(B, 1, device=self.device) for _ in range(2)]}
@@ -138,14 +140,15 @@ class CMAEngine:
         direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
         st["last_ptrs"] = ptrs
         st["hold"] = (rgb, depth, ids)
-        g_rgb, g_depth, g_ids = (rgb, depth, ids) if direct else (st["rgb"], st["depth"], st["ids"])
+        L = ids.shape[1]
+        g_rgb, g_depth, g_ids = (rgb, depth, ids) if direct else (st["rgb"], st["depth"], st["ids"][:B * L].view(B, L))
         with torch.cuda.stream(gs):
             i = st["tick"] & 1
             for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (st["mask"], m), (st["h"][1 - i], h_in)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
             _lib.check(self._lib.hcm_cma_forward(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
-                                                 g_ids.data_ptr(), _TORCH_DT[ids.dtype], B, st["h"][1 - i].data_ptr(),
+                                                 g_ids.data_ptr(), _TORCH_DT[ids.dtype], B, L, st["h"][1 - i].data_ptr(),
                                                  st["mask"].data_ptr(), st["out"][i].data_ptr(), st["stop"][i].data_ptr(),
                                                  st["h"][i].data_ptr(), C.c_void_p(gs.cuda_stream)), self._h)
             st["tick"] += 1

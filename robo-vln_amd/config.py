@@ -12,7 +12,7 @@ class HCMConfig:
     # observation sizes (frames are NHWC)
     rgb_hw: int = 256
     depth_hw: int = 256
-    instr_len: int = 80            # L: tokens per instruction
+    instr_len: int = 80            # L: tokens per instruction of the synthetic workloads; an engine accepts any L <= its max_instr_len per call
     # encoders: cnn_type strings are the reference's
     rgb_encoder: str = "TorchVisionResNet50"      # or "SimpleRGBCNN" (low-level only)
     depth_encoder: str = "VlnResnetDepthEncoder"  # or "SimpleDepthCNN" (low-level only)
@@ -40,11 +40,12 @@ class HCMConfig:
     bert_inter: int = 3072
     bert_vocab: int = 30522
     bert_max_pos: int = 512
+    # working ablation flags of both models: encoder output * 0 (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135)
+    ablate_depth: bool = False
+    ablate_rgb: bool = False
     # flags the reference has but whose branches are broken
     use_prev_action: bool = False
     ablate_instruction: bool = False
-    ablate_depth: bool = False
-    ablate_rgb: bool = False
     progress_monitor: bool = False
 
     def validate(self):

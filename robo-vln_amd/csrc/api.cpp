@@ -13,7 +13,7 @@ void prepare_high(hcm_ctx* ctx);
 void prepare_low(hcm_ctx* ctx);
 void build_spec_cma(hcm_ctx* ctx);
 void prepare_cma(hcm_ctx* ctx);
-void run_refresh_instruction(hcm_ctx* ctx, const void* ids, int ids_dt, int B, const int32_t* idx, int n);
+void run_refresh_instruction(hcm_ctx* ctx, const void* ids, int ids_dt, int B, const int32_t* idx, int n);   // L = ctx->cur_L
 void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
              const float* mask, float* out, float* stop, float* h_out);
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
@@ -107,8 +107,8 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
                 "VISUAL_LING_ATTN: d_model must be 256 and ins_in_features must equal the BERT width");
         REQUIRE(cfg->d_model / cfg->vla_heads == 64 && cfg->bert_hidden / cfg->bert_heads == 64, HCM_ERR_UNSUPPORTED,
                 "attention head dim must be 64");
-        REQUIRE(cfg->bert_hidden == 768 && cfg->instr_len >= 1 && cfg->instr_len <= 160 && cfg->instr_len <= cfg->bert_max_pos,
-                HCM_ERR_UNSUPPORTED, "BERT width must be 768 and 1 <= instr_len <= 160");
+        REQUIRE(cfg->bert_hidden == 768 && cfg->instr_len >= 1 && cfg->instr_len <= 512 && cfg->instr_len <= cfg->bert_max_pos,
+                HCM_ERR_UNSUPPORTED, "BERT width must be 768 and 1 <= instr_len (the maximum L of a call) <= min(512, bert_max_pos)");
         REQUIRE(cfg->vla_layers >= 1 && cfg->bert_layers >= 1, HCM_ERR_ARG, "layer counts must be >= 1");
     }
     REQUIRE(cfg->hidden == 512 || cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
@@ -226,15 +226,30 @@ int hcm_load_tensor(hcm_handle h, int model, const char* key, const void* data, 
     return HCM_OK;
 }
 
+// Workspace sizing: the forward code is run in "dry" mode (allocations only) for every entry shape and the arena gets the largest
+// peak: the single step at max_batch, the sequence path at T = 2 and 3 (its scan keeps ping-pong state buffers on top of the
+// per-step scratch; larger T only shrink N = max_batch / T), each model alone (hcm_high_forward / hcm_low_forward take un-paired
+// trunk paths), all at the maximum instruction length (every allocation is monotone in L).
 static void dry_run(hcm_ctx* h, int B) {
     h->arena.dry = true;
     h->arena.peak = 0;
+    h->cur_L = h->cfg.instr_len;
+    h->cur_lens = nullptr;
     if (h->kind == 1) {
         run_cma(h, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr, nullptr, nullptr);
         return;
     }
-    run_step(h, h->cfg.build_high != 0, h->cfg.build_low != 0, nullptr, DT_F32, nullptr, nullptr, DT_I64, B, nullptr, nullptr, nullptr,
-             nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr);
+    const bool hi = h->cfg.build_high != 0, lo = h->cfg.build_low != 0;
+    for (int T = 1; T <= 3 && T <= B; ++T) {
+        const int rows = B / T * T;
+        for (int which = 0; which < 3; ++which) {          // both (the fused step) / high alone / low alone
+            const bool dh = hi && which != 2, dl = lo && which != 1;
+            if ((which == 0 && !(hi && lo)) || (which == 1 && !hi) || (which == 2 && !lo)) continue;
+            if (which == 0 && T > 1) continue;             // the fused step has no sequence form
+            run_step(h, dh, dl, nullptr, DT_F32, nullptr, nullptr, DT_I64, rows, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                     nullptr, 0, nullptr, nullptr, T);
+        }
+    }
 }
 
 int hcm_finalize(hcm_handle h) {
@@ -324,14 +339,25 @@ static int check_fwd(hcm_ctx* h, int B) {
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, HCM_ERR_ARG, "batch must be in [1, max_batch]");
     return HCM_OK;
 }
+static int check_len(hcm_ctx* h, int L) {
+    REQUIRE(L >= 1 && L <= h->cfg.instr_len, HCM_ERR_ARG,
+            "instruction length " + std::to_string(L) + " outside [1, " + std::to_string(h->cfg.instr_len) + "] (hcm_config.instr_len is the maximum L)");
+    h->cur_L = L;
+    return HCM_OK;
+}
+// every entry point other than hcm_act_ex re-uses the workspace region that holds the cached instruction stream
+static void drop_instruction_cache(hcm_ctx* h) { h->last_hi_batch = -1; h->last_hi_L = -1; }
 
 static bool rgb_dt_ok(int d) { return d == HCM_F32 || d == HCM_U8; }
 static bool ids_dt_ok(int d) { return d == HCM_F32 || d == HCM_I32 || d == HCM_I64; }
 
-int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
-                     const float* h_in, const float* mask, float* logits, float* h_out, void* stream) {
+int hcm_high_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
+                     const int32_t* lengths, int B, int L, const float* h_in, const float* mask, float* logits, float* h_out, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
+    if ((rc = check_len(h, L))) return rc;
+    h->cur_lens = lengths;
+    drop_instruction_cache(h);
     REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
     REQUIRE(rgb && depth && ids && h_in && mask && logits && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
@@ -349,6 +375,7 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
                     const float* mask, const int64_t* subtask, float* vel, float* stop, float* h_out, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
+    drop_instruction_cache(h);
     REQUIRE(h->cfg.build_low, HCM_ERR_STATE, "handle holds no low-level model");
     REQUIRE(rgb && depth && h_in && mask && subtask && vel && stop && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype), HCM_ERR_ARG, "unsupported rgb dtype");
@@ -362,25 +389,29 @@ int hcm_low_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* d
     return HCM_OK;
 }
 
-int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
+int hcm_cma_forward(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L,
                     const float* h_in, const float* mask, float* out, float* stop, float* h_out, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
+    if ((rc = check_len(h, L))) return rc;
     REQUIRE(h->kind == 1, HCM_ERR_STATE, "not a CMANet handle (hcm_cma_create)");
     REQUIRE(rgb && depth && ids && h_in && mask && out && stop && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     h->stream = (hipStream_t)stream;
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
                                        (uint64_t)h_in, (uint64_t)mask, (uint64_t)out, (uint64_t)stop, (uint64_t)h_out, (uint64_t)stream};
     return run_graphed(h, key, stream, [&]() { run_cma(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h_in, mask, out, stop, h_out); });
 }
 
-int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int T, int N,
-                         const float* h_in, const float* masks, float* logits, float* h_out, void* stream) {
+int hcm_high_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
+                         const int32_t* lengths, int T, int N, int L, const float* h_in, const float* masks, float* logits, float* h_out, void* stream) {
     REQUIRE(h, HCM_ERR_ARG, "null handle");
     REQUIRE(T >= 1 && N >= 1, HCM_ERR_ARG, "T and N must be >= 1");
     int rc = check_fwd(h, T * N);
     if (rc) return rc;
+    if ((rc = check_len(h, L))) return rc;
+    h->cur_lens = lengths;
+    drop_instruction_cache(h);
     REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
     REQUIRE(rgb && depth && ids && h_in && masks && logits && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
@@ -400,6 +431,7 @@ int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const floa
     REQUIRE(T >= 1 && N >= 1, HCM_ERR_ARG, "T and N must be >= 1");
     int rc = check_fwd(h, T * N);
     if (rc) return rc;
+    drop_instruction_cache(h);
     REQUIRE(h->cfg.build_low, HCM_ERR_STATE, "handle holds no low-level model");
     REQUIRE(rgb && depth && h_in && masks && subtask && vel && stop && h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype), HCM_ERR_ARG, "unsupported rgb dtype");
@@ -413,41 +445,48 @@ int hcm_low_forward_seq(hcm_handle h, const void* rgb, int rgb_dtype, const floa
     return HCM_OK;
 }
 
-int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
-               const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
+               const int32_t* lengths, int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                int flags, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
+    if ((rc = check_len(h, L))) return rc;
+    h->cur_lens = lengths;
     REQUIRE(h->cfg.build_high && h->cfg.build_low, HCM_ERR_STATE, "hcm_act needs both models in the handle");
     REQUIRE(rgb && depth && ids && hi_h_in && lo_h_in && mask && record && hi_h_out && lo_h_out, HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     REQUIRE(h->cfg.num_actions + h->cfg.lo_actions + 1 == 7, HCM_ERR_UNSUPPORTED, "record layout assumes 4 + 2 + 1 outputs");
     const bool reuse = (flags & HCM_ACT_REUSE_INSTRUCTION) != 0;
-    REQUIRE(!reuse || h->last_hi_batch == B, HCM_ERR_STATE, "HCM_ACT_REUSE_INSTRUCTION: no previous step with this batch size");
+    REQUIRE(!reuse || (h->last_hi_batch == B && h->last_hi_L == L), HCM_ERR_STATE,
+            "HCM_ACT_REUSE_INSTRUCTION: the previous call on this handle was not an hcm_act step with this batch size and instruction length");
     h->stream = (hipStream_t)stream;
     h->reuse_instruction = reuse;
     const int ld = 7;
-    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
+    const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
                                        (uint64_t)hi_h_in, (uint64_t)lo_h_in, (uint64_t)mask, (uint64_t)record, (uint64_t)hi_h_out,
-                                       (uint64_t)lo_h_out, (uint64_t)stream, (uint64_t)flags};
+                                       (uint64_t)lo_h_out, (uint64_t)stream, (uint64_t)flags, (uint64_t)lengths};
     rc = run_graphed(h, key, stream, [&]() {
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
     });
     h->reuse_instruction = false;
-    if (rc == HCM_OK) h->last_hi_batch = B;
+    if (rc == HCM_OK) { h->last_hi_batch = B; h->last_hi_L = L; } else drop_instruction_cache(h);
     return rc;
 }
 
-int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, int B, const int32_t* env_indices, int n, void* stream) {
+int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L, const int32_t* env_indices,
+                            int n, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
+    if ((rc = check_len(h, L))) return rc;
     REQUIRE(h->cfg.build_high, HCM_ERR_STATE, "handle holds no high-level model");
     REQUIRE(ids && (env_indices || n == 0) && n >= 0 && n <= B, HCM_ERR_ARG, "bad argument");
     REQUIRE(ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported ids dtype");
-    REQUIRE(h->last_hi_batch == B, HCM_ERR_STATE, "hcm_refresh_instruction: no previous step with this batch size");
+    REQUIRE(h->last_hi_batch == B && h->last_hi_L == L, HCM_ERR_STATE,
+            "hcm_refresh_instruction: the previous call on this handle was not an hcm_act step with this batch size and instruction length");
     for (int i = 0; i < n; ++i) REQUIRE(env_indices[i] >= 0 && env_indices[i] < B, HCM_ERR_ARG, "environment index out of range");
     if (n == 0) return HCM_OK;
+    h->cur_lens = lengths;
     h->stream = (hipStream_t)stream;
     try {
         run_refresh_instruction(h, ids, ids_dtype, B, env_indices, n);
@@ -457,10 +496,10 @@ int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, int B,
     return HCM_OK;
 }
 
-int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B,
-            const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
+            int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
             void* stream) {
-    return hcm_act_ex(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, record, hi_h_out, lo_h_out, 0, stream);
+    return hcm_act_ex(h, rgb, rgb_dtype, depth, ids, ids_dtype, lengths, B, L, hi_h_in, lo_h_in, mask, record, hi_h_out, lo_h_out, 0, stream);
 }
 
 int hcm_query(hcm_handle h, int what, int64_t* out) {

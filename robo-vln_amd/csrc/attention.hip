@@ -2,9 +2,9 @@
 // passes no attention_mask, seq2seq_highlevel_cma.py:194) and ScaledDotProductAttention of the cross-modal block
 // (4 heads, L x 16 or L x L; models/transformer/transformer.py:81-109, masks None).
 //
-// v1: one workgroup per (batch, head); K and V staged once in LDS as f32; four lanes share a query row (16 of the
-// 64 dims each), online softmax in registers.  Scores are tiny here (<= 160 x 160 per head, 1.7 % of BERT's
-// FLOPs) so this kernel is LDS-bandwidth bound, not MFMA bound.
+// v1 (fp32 path): one workgroup per (batch, head, block of 64 queries); K and V staged in LDS as f32 in chunks of up to
+// KC_MAX keys (any Lk: the online softmax state carries across chunks, keys are visited in order whatever the chunking);
+// four lanes share a query row (16 of the 64 dims each), online softmax in registers.  LDS-bandwidth bound, not MFMA bound.
 #include <cstdlib>
 #include "kernels.h"
 #include "dev.h"
@@ -13,34 +13,24 @@ namespace hcm {
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                        T* __restrict__ out, int heads, int Lq, int Lk, int ldq, int ldk,
-                                                        int ldv, int ldo, int q_batch_mod) {
+                                                        T* __restrict__ out, int heads, int Lq, int Lk0, int ldq, int ldk,
+                                                        int ldv, int ldo, int q_batch_mod, int KC, const int* __restrict__ klens) {
     constexpr int CH = Tr<T>::CH;
     constexpr int D = 64;
     extern __shared__ __attribute__((aligned(16))) char smem_att[];
     float* Ks = reinterpret_cast<float*>(smem_att);
-    float* Vs = Ks + (size_t)Lk * D;
+    float* Vs = Ks + (size_t)KC * D;
 
     const int b = blockIdx.x / heads;
     const int h = blockIdx.x % heads;
     const int bq = b % q_batch_mod;
     const int tid = threadIdx.x;
-
-    // stage K, V (f32) -- chunks of CH elements
-    const int chunks = Lk * (D / CH);
-    for (int e = tid; e < chunks; e += 256) {
-        const int row = e / (D / CH);
-        const int c = (e % (D / CH)) * CH;
-        float kv[CH], vv[CH];
-        ld_chunk(k + ((size_t)b * Lk + row) * ldk + h * D + c, kv);
-        ld_chunk(v + ((size_t)b * Lk + row) * ldv + h * D + c, vv);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { Ks[row * D + c + j] = kv[j]; Vs[row * D + c + j] = vv[j]; }
-    }
-    __syncthreads();
+    int Lk = Lk0;                           // keys this sample attends over (uniform per workgroup); rows keep the stride Lk0
+    if (klens) { Lk = klens[b]; Lk = Lk < 1 ? 1 : Lk > Lk0 ? Lk0 : Lk; }
 
     const int part = tid & 3;               // which 16-dim slice of the head
-    for (int q0 = 0; q0 < Lq; q0 += 64) {
+    {
+        const int q0 = blockIdx.y * 64;
         const int qi = q0 + (tid >> 2);
         const bool active = qi < Lq;
         float qr[16], o[16];
@@ -57,7 +47,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
             }
         }
         float m = -3.0e38f, l = 0.f;
-        for (int key = 0; key < Lk; ++key) {
+        for (int k0 = 0; k0 < Lk; k0 += KC) {
+        const int kn = Lk - k0 < KC ? Lk - k0 : KC;
+        if (k0) __syncthreads();
+        // stage this chunk of K, V (f32) -- pieces of CH elements
+        for (int e = tid; e < kn * (D / CH); e += 256) {
+            const int row = e / (D / CH);
+            const int c = (e % (D / CH)) * CH;
+            float kv[CH], vv[CH];
+            ld_chunk(k + ((size_t)b * Lk0 + k0 + row) * ldk + h * D + c, kv);
+            ld_chunk(v + ((size_t)b * Lk0 + k0 + row) * ldv + h * D + c, vv);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { Ks[row * D + c + j] = kv[j]; Vs[row * D + c + j] = vv[j]; }
+        }
+        __syncthreads();
+        for (int key = 0; key < kn; ++key) {
             const float4* kp = reinterpret_cast<const float4*>(Ks + key * D + part * 16);
             float s = 0.f;
 #pragma unroll
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
             }
             m = mn;
         }
+        }
         if (active) {
             const float inv = 1.0f / l;
             T* op = out + ((size_t)b * Lq + qi) * ldo + h * D + part * 16;
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// MFMA variant for the 16-bit storage types (Lk <= 160).  One workgroup per (batch, head), 4 waves, each wave owns
+// MFMA variant for the 16-bit storage types (Lk <= 512; the score registers of a query tile are sized by the MAXKT template
+// parameter, so short instructions keep the 160-key build's occupancy).  One workgroup per (batch, head), 4 waves, each wave owns
 // 16-query tiles.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand = K rows from LDS, B operand = Q rows
 // straight from global), so that in the accumulator layout a lane holds 4 keys of ONE query per key tile: the
 // softmax row reduction is in-register plus two cross-lane steps (xor 16, 32), and the exponentiated scores are
@@ -125,12 +131,13 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
     return (uint32_t)t[0].v | ((uint32_t)t[1].v << 16);
 }
 
-template <typename T>
+template <typename T, int MAXKT>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                             T* __restrict__ out, int heads, int Lq, int Lk, int ldq, int ldk,
-                                                             int ldv, int ldo, int q_batch_mod) {
-    constexpr int D = 64;
-    constexpr int MAXKT = 10;                 // Lk <= 160
+                                                             T* __restrict__ out, int heads, int Lq, int Lk0, int ldq, int ldk,
+                                                             int ldv, int ldo, int q_batch_mod, const int* __restrict__ klens) {
+    int Lk = Lk0;                             // keys this sample attends over (uniform per workgroup); rows keep the stride Lk0
+    if (klens) { Lk = klens[blockIdx.x / heads]; Lk = Lk < 1 ? 1 : Lk > Lk0 ? Lk0 : Lk; }
+    constexpr int D = 64;                     // MAXKT 16-key tiles: Lk <= 16 * MAXKT (10 -> 160, 16 -> 256, 32 -> 512)
     extern __shared__ __attribute__((aligned(16))) char smem_att[];
     const int KT2 = (Lk + 31) / 32;           // 32-key MFMA steps
     const int Lkp = KT2 * 32;
@@ -150,8 +157,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
         const int row = e >> 3, c = e & 7;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (row < Lk) {
-            kv = *reinterpret_cast<const uint4*>(k + ((size_t)b * Lk + row) * ldk + h * D + c * 8);
-            vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Lk + row) * ldv + h * D + c * 8);
+            kv = *reinterpret_cast<const uint4*>(k + ((size_t)b * Lk0 + row) * ldk + h * D + c * 8);
+            vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Lk0 + row) * ldv + h * D + c * 8);
         }
         *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
         const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -246,9 +253,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
 }
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads, int Lq,
-                            int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s) {
-    const size_t lds = (size_t)Lk * 64 * sizeof(float) * 2;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+                            int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s, const int* klens) {
+    constexpr int KC_MAX = 256;                                   // keys per LDS chunk of the VALU kernel (128 KB of f32 K + V)
+    const int KC = Lk < KC_MAX ? Lk : KC_MAX;
+    const size_t lds = (size_t)KC * 64 * sizeof(float) * 2;
+    if (Lk < 1 || Lq < 1) return hipErrorInvalidValue;
     const int CH = dt_chunk(dt);
     if ((ldq % CH) || (ldk % CH) || (ldv % CH) || (ldo % CH)) return hipErrorInvalidValue;
     if (q_batch_mod <= 0) q_batch_mod = B;
@@ -257,18 +266,24 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<bf16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<f16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<bf16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<f16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     static const char* valu = getenv("HCM_ATT_VALU");
-    if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 160 && !(valu && atoi(valu))) {
+    if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 512 && !(valu && atoi(valu))) {
         const int Lkp = (Lk + 31) / 32 * 32;
-        const size_t lds2 = (size_t)Lkp * 128 + (size_t)64 * (Lkp + 4) * 2;
-#define LM(T) hipLaunchKernelGGL(attention_mfma_kernel<T>, dim3(B * heads), dim3(256), lds2, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod)
-        if (dt == DT_BF16) LM(bf16); else LM(f16);
+        const size_t lds2 = (size_t)Lkp * 128 + (size_t)64 * (Lkp + 4) * 2;          // 131.6 KB at Lk = 512
+#define LM(T, KT) hipLaunchKernelGGL((attention_mfma_kernel<T, KT>), dim3(B * heads), dim3(256), lds2, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod, klens)
+        if (Lk <= 160) { if (dt == DT_BF16) LM(bf16, 10); else LM(f16, 10); }
+        else if (Lk <= 256) { if (dt == DT_BF16) LM(bf16, 16); else LM(f16, 16); }
+        else { if (dt == DT_BF16) LM(bf16, 32); else LM(f16, 32); }
 #undef LM
         return hipGetLastError();
     }
-#define LA(T) hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads), dim3(256), lds, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod)
+#define LA(T) hipLaunchKernelGGL(attention_kernel<T>, dim3(B * heads, (Lq + 63) / 64), dim3(256), lds, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod, KC, klens)
     if (dt == DT_BF16) LA(bf16); else if (dt == DT_F16) LA(f16); else if (dt == DT_F32) LA(float); else return hipErrorInvalidValue;
 #undef LA
     return hipGetLastError();

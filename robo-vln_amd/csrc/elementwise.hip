@@ -229,12 +229,15 @@ hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H,
 // ------------------------------------------------------------------------------------------ mean over rows
 // AdaptiveAvgPool1d(1) over tokens: rgb_linear.0 (seq2seq_highlevel_cma.py:83-85), cross_pooler (:114-115,:209-210).
 template <typename T>
-__global__ void mean_rows_kernel(const T* __restrict__ x, void* __restrict__ y, int B, int S, int C, int ldx, int ldy, int out_f32) {
+__global__ void mean_rows_kernel(const T* __restrict__ x, void* __restrict__ y, int B, int S0, int C, int ldx, int ldy, int out_f32,
+                                 const int* __restrict__ lens) {
     const size_t total = (size_t)B * C;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         const int b = (int)(e / C);
-        const T* p = x + (size_t)b * S * ldx + c;
+        const T* p = x + (size_t)b * S0 * ldx + c;
+        int S = S0;
+        if (lens) { S = lens[b]; S = S < 1 ? 1 : S > S0 ? S0 : S; }
         // four independent partial sums and an unrolled body keep several loads in flight (a single dependent chain
         // of S strided 2-byte loads costs S x L2 latency: 24 us for the 80-token cross_pooler)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -252,9 +255,9 @@ __global__ void mean_rows_kernel(const T* __restrict__ x, void* __restrict__ y, 
         else Tr<T>::st(reinterpret_cast<T*>(y) + (size_t)b * ldy + c, acc);
     }
 }
-hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s) {
+hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s, const int* lens) {
     const size_t total = (size_t)B * C;
-    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(mean_rows_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, y, B, S, C, ldx, ldy, out_f32));
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(mean_rows_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, y, B, S, C, ldx, ldy, out_f32, lens));
     return hipGetLastError();
 }
 

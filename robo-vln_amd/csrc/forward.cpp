@@ -370,20 +370,23 @@ struct Fwd {
     }
 
     // ---------------------------------------------------------------- BERT encoder
-    void bert(const BertW& w, const void* ids, int ids_dt, int B, void* x) {
+    void bert(const BertW& w, const void* ids, int ids_dt, int B, void* x, const int* lens) {
         const hcm_config& c = ctx->cfg;
-        const int L = c.instr_len, D = c.bert_hidden, rows = B * L;
-        void* qkv = alloc_t((size_t)rows * 3 * D);
-        void* ctxb = alloc_t((size_t)rows * D);
-        void* tmp = alloc_t((size_t)rows * D);
-        void* hbuf = alloc_t((size_t)rows * c.bert_inter);
+        // L is per call (ctx->cur_L <= cfg.instr_len); buffers are carved at the maximum length so that the workspace layout -- and with
+        // it the cached instruction stream of HCM_ACT_REUSE_INSTRUCTION -- does not move when L changes
+        const int L = ctx->cur_L, D = c.bert_hidden, rows = B * L;
+        const size_t rmax = (size_t)B * c.instr_len;
+        void* qkv = alloc_t(rmax * 3 * D);
+        void* ctxb = alloc_t(rmax * D);
+        void* tmp = alloc_t(rmax * D);
+        void* hbuf = alloc_t(rmax * c.bert_inter);
         if (!dry) ck(launch_bert_embed(ids, ids_dt, w.word, w.pos, w.type0, w.ln.gamma, w.ln.beta, x, dt, B, L, D, c.bert_vocab, 1e-12f, s), "bert_embed");
         tap("hi.bert_emb", x, true, {B, L, D});
         int li = 0;
         for (const BertLayerW& l : w.layers) {
             linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
             if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
-                                          L, L, 3 * D, 3 * D, 3 * D, D, B, s), "bert attention");
+                                          L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
             linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
             ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
             linear(l.ff1, x, rows, D, hbuf, c.bert_inter, ACT_GELU, false);
@@ -447,7 +450,11 @@ struct Fwd {
             Heads hd = heads;
             if (hd.out0) hd.out0 += (size_t)t * N * hd.ld0;
             if (hd.out1) hd.out1 += (size_t)t * N * hd.ld1;
+            // the steps run in order on one stream: every step re-uses the same gate / split-K scratch (bounded by the dry runs at
+            // T = 1..3 of hcm_finalize instead of growing with T)
+            const size_t m = ar.mark();
             rnn_step(w, xh + (size_t)t * N * ld, ld, N, cur, mask + (size_t)t * N, dst, hd);
+            ar.release(m);
             cur = dst;
         }
     }
@@ -550,15 +557,16 @@ struct Fwd {
     void hi_ins_pre(int B, HiBufs& hb) {
         const hcm_config& c = ctx->cfg;
         const VlaW& v = ctx->hi.vla;
-        const int L = c.instr_len, d = c.d_model, rows = B * L;
+        const int L = ctx->cur_L, d = c.d_model, rows = B * L;
+        const size_t rmax = (size_t)B * c.instr_len;
         use(ctx->dt_vla);
         void* emb = hb.emb;
         if (ctx->dt_bert != ctx->dt_vla) {
-            void* e2 = alloc_t((size_t)rows * c.bert_hidden);
+            void* e2 = alloc_t(rmax * c.bert_hidden);
             if (!dry) ck(launch_convert(emb, ctx->dt_bert, e2, ctx->dt_vla, (size_t)rows * c.bert_hidden, s), "bert out convert");
             emb = e2;
         }
-        void* tmp = alloc_t((size_t)rows * d);
+        void* tmp = alloc_t(rmax * d);
         linear(v.ins_fc, emb, rows, c.bert_hidden, tmp, d, ACT_RELU, false);
         ln(tmp, nullptr, v.ln, v.pe, L, hb.I, rows, d, 1e-5f);     // LN then + PE; identical for both calls -> computed once
         for (size_t l = 0; l < v.layers.size(); ++l) linear(v.layers[l].q, hb.I, rows, d, hb.Q[l], d, ACT_NONE, false);
@@ -680,18 +688,40 @@ struct Fwd {
         tap("hi.rgb_spatial", hb.rgb_tok, true, {B, 16, rC});
         hi_vis_pre(0, B, hb);
     }
+    // ablate_depth / ablate_rgb (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135): `embedding * 0` right after the
+    // encoder -- for the high-level model the whole (B, C+64, S) token tensor including its positional-embedding channels, for the
+    // low-level model the encoder's feature vector.  The encoder's value cannot reach any output (finite x * 0 = 0), so the trunk is
+    // not run; everything downstream (rgb_kv / depth_kv, Visual_Ling_Attn, the projections) runs on the zeros as in the reference.
+    void ablated_encoder(int stream, int B, HiBufs* hb, LoBufs* lb) {
+        const hcm_config& c = ctx->cfg;
+        const HighW& w = ctx->hi;
+        use(ctx->dt_vla);
+        if (hb) {
+            void* tok = stream == 0 ? hb->rgb_tok : hb->dep_tok;
+            const size_t n = stream == 0 ? (size_t)B * 16 * (2048 + 64) : (size_t)B * w.depth_S * w.depth_C;
+            if (!dry) ck(hipMemsetAsync(tok, 0, n * esz, s), "ablate: zero tokens");
+            tap(stream == 0 ? "hi.rgb_spatial" : "hi.depth_spatial", tok, true,
+                stream == 0 ? Shape{B, 16, 2048 + 64} : Shape{B, w.depth_S, w.depth_C});
+            hi_vis_pre(stream, B, *hb);
+        }
+        if (lb && !dry) {
+            float* col = lb->xh + (stream == 0 ? c.depth_out : 0);
+            const int ncol = stream == 0 ? c.rgb_out : c.depth_out;
+            ck(hipMemset2DAsync(col, (size_t)lb->ldx * 4, 0, (size_t)ncol * 4, B, s), "ablate: zero features");
+        }
+    }
     // BERT (:189-195) -> emb
     void hi_bert(const void* ids, int ids_dt, int B, HiBufs& hb) {
         use(ctx->dt_bert);
-        bert(ctx->hi.bert, ids, ids_dt, B, hb.emb);
-        tap("hi.bert", hb.emb, true, {B, ctx->cfg.instr_len, ctx->cfg.bert_hidden});
+        bert(ctx->hi.bert, ids, ids_dt, B, hb.emb, ctx->cur_lens);
+        tap("hi.bert", hb.emb, true, {B, ctx->cur_L, ctx->cfg.bert_hidden});
         hi_ins_pre(B, hb);
     }
     // Visual_Ling_Attn x2 (the cross-modal part), poolers, state encoder, head (:200-232)
     void hi_tail(int B, HiBufs& hb, const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
         const hcm_config& c = ctx->cfg;
         const HighW& w = ctx->hi;
-        const int L = c.instr_len, d = c.d_model;
+        const int L = ctx->cur_L, Lm = c.instr_len, d = c.d_model;
         const int dS = w.depth_S;
         const int ldx = hb.ldx;
         float* xh = hb.xh;
@@ -707,17 +737,20 @@ struct Fwd {
             if (fork) on(stream == 0 ? main_s : ctx->aux[0]);
             const int S = stream == 0 ? 16 : dS;
             int Lk = S;
-            void* kv = alloc_t((size_t)B * (S > L ? S : L) * 2 * d);
-            void* att = alloc_t((size_t)rows * d);
-            void* t2 = alloc_t((size_t)rows * d);
-            void* ffh = alloc_t((size_t)rows * c.d_ff);
-            void* out = alloc_t((size_t)rows * d);
+            void* kv = alloc_t((size_t)B * (S > Lm ? S : Lm) * 2 * d);
+            void* att = alloc_t((size_t)B * Lm * d);
+            void* t2 = alloc_t((size_t)B * Lm * d);
+            void* ffh = alloc_t((size_t)B * Lm * c.d_ff);
+            void* out = alloc_t((size_t)B * Lm * d);
             void* kvin = hb.kvin[stream];
             for (size_t l = 0; l < v.layers.size(); ++l) {
                 const VlaLayerW& ly = v.layers[l];
                 const void* kvl = hb.kv0[stream];                                          // layer 0: projected in the encoder chain
                 if (l > 0) { linear(ly.kv, kvin, B * Lk, d, kv, 2 * d, ACT_NONE, false); kvl = kv; }
-                if (!dry) ck(launch_attention(hb.Q[l], kvl, (const char*)kvl + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s), "vla attention");
+                // layer 0 attends over the visual tokens; deeper layers over the previous layer's (B, L, d) output, of which a ragged
+                // batch's sample owns the first lengths[b] rows only
+                if (!dry) ck(launch_attention(hb.Q[l], kvl, (const char*)kvl + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s,
+                                              l > 0 ? ctx->cur_lens : nullptr), "vla attention");
                 linear(ly.o, att, rows, d, t2, d, ACT_NONE, false, I, d);                 // queries + att
                 ln(t2, nullptr, ly.ln_att, nullptr, 0, att, rows, d, 1e-5f);             // MultiHeadAttention.layer_norm
                 linear(ly.ff1, att, rows, d, ffh, c.d_ff, ACT_RELU, false);
@@ -731,7 +764,7 @@ struct Fwd {
             }
             tap(stream == 0 ? "hi.vla_rgb" : "hi.vla_depth", out, true, {B, L, d});
             // cross_pooler: mean over all L tokens (:209-210) -> xh columns
-            if (!dry) ck(launch_mean_rows(out, xh + w.rnn.xcol(c.rgb_out + c.depth_out + stream * d), dt, B, L, d, d, ldx, 1, s), "cross_pooler");
+            if (!dry) ck(launch_mean_rows(out, xh + w.rnn.xcol(c.rgb_out + c.depth_out + stream * d), dt, B, L, d, d, ldx, 1, s, ctx->cur_lens), "cross_pooler");
         }
         // meanwhile (third stream): the early halves of both recurrent steps
         float* hi_pre = nullptr;
@@ -804,20 +837,24 @@ struct Fwd {
         const hcm_config& c = ctx->cfg;
         ar.reset();
         HiBufs hb = hi_alloc(B);                                  // same offsets as in step(): the persistent tensors
-        const int L = c.instr_len, d = c.d_model;
+        const int L = ctx->cur_L, d = c.d_model;
         const size_t idsz = ids_dt == DT_I64 ? 8 : 4;
         char* sub_ids = (char*)ar.alloc((size_t)n * L * idsz);
+        int* sub_lens = ctx->cur_lens ? (int*)ar.alloc((size_t)n * sizeof(int)) : nullptr;
         HiBufs hn;
         use(ctx->dt_bert);
-        hn.emb = alloc_t((size_t)n * L * c.bert_hidden);
+        hn.emb = alloc_t((size_t)n * c.instr_len * c.bert_hidden);
         use(ctx->dt_vla);
-        hn.I = alloc_t((size_t)n * L * d);
+        hn.I = alloc_t((size_t)n * c.instr_len * d);
         hn.Q.resize(hb.Q.size());
-        for (auto& q : hn.Q) q = alloc_t((size_t)n * L * d);
+        for (auto& q : hn.Q) q = alloc_t((size_t)n * c.instr_len * d);
         for (int i = 0; i < n; ++i)
             ck(hipMemcpyAsync(sub_ids + (size_t)i * L * idsz, (const char*)ids + (size_t)idx[i] * L * idsz, (size_t)L * idsz, hipMemcpyDeviceToDevice, s), "ids gather");
+        if (sub_lens)
+            for (int i = 0; i < n; ++i)
+                ck(hipMemcpyAsync(sub_lens + i, ctx->cur_lens + idx[i], sizeof(int), hipMemcpyDeviceToDevice, s), "lengths gather");
         use(ctx->dt_bert);
-        bert(ctx->hi.bert, sub_ids, ids_dt, n, hn.emb);
+        bert(ctx->hi.bert, sub_ids, ids_dt, n, hn.emb, sub_lens);
         hi_ins_pre(n, hn);
         use(ctx->dt_vla);
         const size_t row = (size_t)L * d * esz;
@@ -835,7 +872,7 @@ struct Fwd {
         const hcm_config& c = ctx->cfg;
         const hcm_cma_config& m = ctx->cma_cfg;
         const CmaW& w = ctx->cma;
-        const int L = c.instr_len, Hi = m.instr_hidden, C = Hi * w.dirs, E = m.embedding_size;
+        const int L = ctx->cur_L, Lm = c.instr_len, Hi = m.instr_hidden, C = Hi * w.dirs, E = m.embedding_size;
         const int H = c.hidden, hh = H / 2, rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
         const int R = c.rnn_type == HCM_LSTM ? 2 : 1;
         const bool multi = ctx->concurrent && !ctx->taps_on;
@@ -845,7 +882,7 @@ struct Fwd {
         use(ctx->dt_vla);
         void* rgb_tok = alloc_t((size_t)B * 16 * rC);
         void* dep_tok = alloc_t((size_t)B * dS * dC);
-        float* ins = alloc_f((size_t)B * L * C);                 // (B, C, L) of the reference, token-major [B][L][C]
+        float* ins = alloc_f((size_t)B * Lm * C);                 // (B, C, L) of the reference, token-major [B][L][C]
         if (multi) fork_join_begin(2);
 
         // chain A (aux 0): instruction encoder (instruction_encoder.py:70-92) -- embedding, input projection of every token
@@ -854,9 +891,9 @@ struct Fwd {
         on(a0);
         {
             const int ldx = w.ih[0].Kp;
-            float* x = alloc_f((size_t)B * L * ldx);
+            float* x = alloc_f((size_t)B * Lm * ldx);
             if (!dry) ck(launch_instr_embed(ids, ids_dt, w.emb, x, ctx->len_buf, B, L, E, ldx, m.vocab_size, s), "instr embed");
-            float* pre[2] = {alloc_f((size_t)B * L * 4 * Hi), w.dirs > 1 ? alloc_f((size_t)B * L * 4 * Hi) : nullptr};
+            float* pre[2] = {alloc_f((size_t)B * Lm * 4 * Hi), w.dirs > 1 ? alloc_f((size_t)B * Lm * 4 * Hi) : nullptr};
             float* gh = alloc_f((size_t)B * 4 * Hi);
             float* hc = alloc_f((size_t)2 * B * Hi);
             for (int d = 0; d < w.dirs; ++d) linear(w.ih[d], x, B * L, ldx, pre[d], 4 * Hi, ACT_NONE, true);
@@ -923,7 +960,7 @@ struct Fwd {
         // text attention (:272-277): the query is the state, keys text_k(instruction), values the instruction itself
         float* q1 = alloc_f((size_t)B * hh);
         linear(w.state_q, state, B, H, q1, hh, ACT_NONE, true);
-        float* kt = alloc_f((size_t)B * L * hh);
+        float* kt = alloc_f((size_t)B * Lm * hh);
         linear(w.text_k, ins, B * L, C, kt, hh, ACT_NONE, true);
         if (!dry) ck(launch_attn1q(q1, hh, kt, hh, ins, C, ctx->len_buf, xc + H, ldc, B, L, hh, C, w.scale, s), "text attention");
         // visual attention (:281-290): query text_q(text); keys | values are the two halves of rgb_kv / depth_kv
@@ -978,7 +1015,11 @@ struct Fwd {
         const bool multi = ctx->concurrent && !ctx->taps_on;    // taps allocate/synchronise: keep them single-stream
         hipStream_t main_s = ctx->stream;
         hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s, a2 = multi ? ctx->aux[2] : main_s;
-        static const int skip = getenv("HCM_SKIP") ? atoi(getenv("HCM_SKIP")) : 0;   // profiling aid: drop chains (bitmask)
+#ifdef HCM_DEV_KNOBS
+        static const int skip = getenv("HCM_SKIP") ? atoi(getenv("HCM_SKIP")) : 0;   // profiling aid (make DEV=1 builds only): drop chains (bitmask)
+#else
+        constexpr int skip = 0;
+#endif
         if (multi) fork_join_begin(4);
         // Host enqueue order = start order on the GPU: the chains made of many small dependent launches go first (BERT,
         // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
@@ -991,24 +1032,27 @@ struct Fwd {
         on(a1);
         const bool dshare = do_hi && do_lo && ctx->hi.depth_shared && !ctx->lo.depth_simple;
         const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;
-        if (dshare) {
+        if (ctx->cfg.ablate_depth) {
+            if (!(skip & 4)) ablated_encoder(1, B, do_hi ? &hb : nullptr, do_lo ? &lb : nullptr);
+        } else if (dshare) {
             if (!(skip & 4)) depth_shared(depth, B, hb, lb);
         } else if (pair) {
             if (!(skip & 4)) depth_pair(depth, B, hb, lb);
         } else if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
         on(a1);
-        if (do_lo && !pair && !dshare && !(skip & 4)) lo_depth(depth, B, lb);
+        if (do_lo && !pair && !dshare && !ctx->cfg.ablate_depth && !(skip & 4)) lo_depth(depth, B, lb);
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
         const bool rshare = do_hi && do_lo && ctx->hi.rgb_shared && !ctx->lo.rgb_simple;
         const bool rpair = do_hi && do_lo && ctx->hi.has_rgb_pair && !ctx->lo.rgb_simple;
-        if (rshare) { if (!(skip & 1)) rgb_shared(rgb, rgb_dt, B, hb, lb); }
+        if (ctx->cfg.ablate_rgb) { if (!(skip & 1)) ablated_encoder(0, B, do_hi ? &hb : nullptr, do_lo ? &lb : nullptr); }
+        else if (rshare) { if (!(skip & 1)) rgb_shared(rgb, rgb_dt, B, hb, lb); }
         else if (rpair) { if (!(skip & 1)) rgb_pair(rgb, rgb_dt, B, hb, lb); }
         else if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
         static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
         on(rgb_serial ? main_s : a0);
-        if (do_hi && do_lo && !rpair && !rshare && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
+        if (do_hi && do_lo && !rpair && !rshare && !ctx->cfg.ablate_rgb && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);
         if (do_hi && do_lo && T == 1) { lo_early = &lb; lo_h_in_early = lo_h_in; }

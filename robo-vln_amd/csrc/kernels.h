@@ -95,7 +95,9 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int
 hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s,
                                    int ldx = 0 /* input pixel stride in elements, 0 = C */);
 // mean over S rows: x [B,S,ldx(>=C)] (T) -> y [B, ldy] (T or f32 when out_f32) columns [0,C)
-hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s);
+// lens (optional, device, [B]): sample b averages its first clamp(lens[b], 1, S) rows only (ragged instruction batches)
+hipError_t launch_mean_rows(const void* x, void* y, int dt, int B, int S, int C, int ldx, int ldy, int out_f32, hipStream_t s,
+                            const int* lens = nullptr);
 // write a constant f32 table tab[S][C] into columns of y [B,S,ldy] (T)
 hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int C, int ldy, hipStream_t s);
 
@@ -121,8 +123,10 @@ hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, con
                              const float* gamma, const float* beta, void* y, int dt, int B, int L, int D, int vocab,
                              float eps, hipStream_t s);
 // softmax(Q K^T / sqrt(64)) V, head dim 64.  q batch index = b % q_batch_mod (shared queries)
+// klens (optional, device, [B]): sample b attends over its first clamp(klens[b], 1, Lk) keys only; rows keep the stride Lk.  The result
+// for those queries equals a launch with Lk = klens[b] on the unpadded tensors bit for bit.
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads,
-                            int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s);
+                            int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s, const int* klens = nullptr);
 
 // RNN input assembly: xh[b][x_cols + j] = h_in[0][b][j] * mask[b]   (f32)
 hipError_t launch_rnn_prep(const float* h_in, const float* mask, float* xh, int B, int Hd, int ld, int col0, hipStream_t s);

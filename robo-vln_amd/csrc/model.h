@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include <stdint.h>
@@ -141,6 +142,9 @@ struct Arena {
         char* p = (dry ? (char*)0x1000 : base) + off;
         off += bytes;
         if (off > peak) peak = off;
+        // the capacity is the maximum over the dry runs of every entry shape (api.cpp: hcm_finalize); a request beyond it is a bug in
+        // that sizing -- fail the call instead of writing past the allocation
+        if (!dry && off > cap) throw std::runtime_error("workspace arena overflow (" + std::to_string(off) + " > " + std::to_string(cap) + " bytes)");
         return p;
     }
     size_t mark() const { return off; }
@@ -188,5 +192,7 @@ struct hcm_ctx {
     // hcm_act_ex(HCM_ACT_REUSE_INSTRUCTION): skip BERT + the instruction stream of Visual_Ling_Attn and reuse the tensors the
     // previous step left in the workspace (same batch size required); set per call
     bool reuse_instruction = false;
-    int last_hi_batch = 0;
+    int last_hi_batch = -1, last_hi_L = -1;   // shape of the cached instruction stream; -1 = none (invalidated by every other entry point)
+    int cur_L = 0;                  // instruction length of the current call (<= cfg.instr_len)
+    const int* cur_lens = nullptr;  // optional per-environment instruction lengths of the current call (device, [B]); null = all L
 };

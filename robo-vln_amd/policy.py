@@ -22,7 +22,12 @@ _SUB_SLOTS = {"depth": 0, "bert": 1, "vla": 2, "rgb": 3}
 _SUB_DT = {"fp32": _lib.HCM_F32, "bf16": _lib.HCM_BF16, "fp16": _lib.HCM_F16}
 
 
-def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None):
+def _ptr(t):
+    """device pointer of an optional tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None, max_instr_len=None):
     s = _lib.HcmConfigStruct()
     for name, p in (sub_precision or {}).items():
         s.reserved[_SUB_SLOTS[name]] = _SUB_DT[p] + 1
@@ -31,7 +36,7 @@ def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_
     s.max_batch = max_batch
     s.rgb_h = s.rgb_w = cfg.rgb_hw
     s.depth_h = s.depth_w = cfg.depth_hw
-    s.instr_len = cfg.instr_len
+    s.instr_len = max_instr_len or cfg.instr_len           # the library's instr_len is the MAXIMUM L of a call
     s.rgb_encoder = _lib.HCM_ENC_RESNET if cfg.rgb_encoder == "TorchVisionResNet50" else _lib.HCM_ENC_SIMPLECNN
     s.depth_encoder = _lib.HCM_ENC_RESNET if cfg.depth_encoder == "VlnResnetDepthEncoder" else _lib.HCM_ENC_SIMPLECNN
     s.rgb_out, s.depth_out, s.depth_baseplanes = cfg.rgb_out, cfg.depth_out, cfg.depth_baseplanes
@@ -45,6 +50,7 @@ def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_
     s.build_high, s.build_low = int(build_high), int(build_low)
     s.use_prev_action, s.ablate_instruction = int(cfg.use_prev_action), int(cfg.ablate_instruction)
     s.progress_monitor = int(cfg.progress_monitor)
+    s.ablate_depth, s.ablate_rgb = int(cfg.ablate_depth), int(cfg.ablate_rgb)
     return s
 
 
@@ -61,13 +67,17 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="bf16", device=None, sub_precision=None, graph=False):
+                 precision="bf16", device=None, sub_precision=None, graph=False, max_instr_len=None):
         """precision: "bf16" (16-bit storage + MFMA with fp32 accumulate; by default the GroupNorm depth trunk uses
         fp16 tiles and everything else bf16, recurrent cells/heads fp32) or "fp32".  `sub_precision` overrides the
         storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
         graph=True: act() runs on an engine-owned stream with engine-owned static I/O buffers, so that libhcm replays
         one captured hipGraph per step; the returned record / hidden tensors then alias those buffers and stay valid
-        until the second-next act() call (ping-pong), which is what a rollout loop that rebinds them every step needs."""
+        until the second-next act() call (ping-pong), which is what a rollout loop that rebinds them every step needs.
+        max_instr_len: the longest instruction (tokens) a call may carry; sizes the workspace.  Every call takes its own
+        (B or 1, L <= max_instr_len) ids, as the reference model does (its eval loop feeds the unpadded tokens of the episode's
+        instruction, common/utils.py:18-20).  Default: cfg.instr_len.  BERT's position table allows up to 512."""
+        self.max_instr_len = int(max_instr_len or cfg.instr_len)
         self._graph = bool(graph)
         self._gstream = None
         self._static = None
@@ -81,7 +91,7 @@ class HCMEngine:
         self.has_high = high_level_state_dict is not None
         self.has_low = low_level_state_dict is not None
         with torch.cuda.device(self.device):
-            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision)
+            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision, self.max_instr_len)
             _lib.check(self._lib.hcm_create(C.byref(st), C.byref(self._h)))
             try:
                 # load_state_dict(strict=True) semantics (hierarchical_trainer.py:343-345)
@@ -138,14 +148,19 @@ class HCMEngine:
             raise ValueError(f"rgb must be (B,{c.rgb_hw},{c.rgb_hw},3), got {tuple(rgb.shape)}")
         if tuple(depth.shape) != (B, c.depth_hw, c.depth_hw, 1):
             raise ValueError(f"depth must be (B,{c.depth_hw},{c.depth_hw},1), got {tuple(depth.shape)}")
-        ids = None
+        ids = lens = None
         if need_ids:
             ids = self._dev(observations["instruction"], (torch.int64, torch.int32, torch.float32))
-            if ids.dim() != 2 or ids.shape[1] != c.instr_len:
-                raise ValueError(f"instruction must be (B or 1, {c.instr_len}), got {tuple(ids.shape)}")
+            if ids.dim() != 2 or ids.shape[0] not in (1, B) or not 1 <= ids.shape[1] <= self.max_instr_len:
+                raise ValueError(f"instruction must be (B or 1, L) with 1 <= L <= {self.max_instr_len} (max_instr_len), got {tuple(ids.shape)}")
             # instruction.expand(B, L) (seq2seq_highlevel_cma.py:189-190)
             ids = ids.expand(B, ids.shape[1]).contiguous()
-        return rgb, depth, ids, B
+            # extension for batched rollouts (not a reference key): per-environment token counts of a padded ragged batch
+            if observations.get("instruction_lengths") is not None:
+                lens = self._dev(observations["instruction_lengths"], (torch.int32,)).reshape(-1)
+                if lens.numel() != B:
+                    raise ValueError(f"instruction_lengths must hold {B} entries, got {lens.numel()}")
+        return rgb, depth, ids, lens, B
 
     def _mask(self, masks, B):
         m = self._dev(masks, (torch.float32,))
@@ -167,18 +182,18 @@ class HCMEngine:
     # ---- the three calls
     def high_forward(self, observations, hidden, masks):
         with torch.cuda.device(self.device):
-            rgb, depth, ids, B = self._obs(observations, True)
+            rgb, depth, ids, lens, B = self._obs(observations, True)
             h_in, m = self._hidden(hidden, B), self._mask(masks, B)
             logits = torch.empty(B, self.cfg.num_actions, device=self.device, dtype=torch.float32)
             h_out = torch.empty_like(h_in)
             _lib.check(self._lib.hcm_high_forward(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(),
-                                                  ids.data_ptr(), _TORCH_DT[ids.dtype], B, h_in.data_ptr(), m.data_ptr(),
+                                                  ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], h_in.data_ptr(), m.data_ptr(),
                                                   logits.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
         return logits, h_out
 
     def low_forward(self, observations, hidden, masks, subtask):
         with torch.cuda.device(self.device):
-            rgb, depth, _, B = self._obs(observations, False)
+            rgb, depth, _, _, B = self._obs(observations, False)
             h_in, m = self._hidden(hidden, B), self._mask(masks, B)
             st = self._dev(subtask, (torch.int64,)).reshape(B)
             vel = torch.empty(B, self.cfg.lo_actions, device=self.device, dtype=torch.float32)
@@ -191,13 +206,18 @@ class HCMEngine:
 
     def _act_graph(self, observations, hi_hidden, lo_hidden, masks, flags=0):
         with torch.cuda.device(self.device):
-            rgb, depth, ids, B = self._obs(observations, True)
+            rgb, depth, ids, lens, B = self._obs(observations, True)
+            L = ids.shape[1]
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             if self._gstream is None:
                 self._gstream = torch.cuda.Stream(device=self.device)
             st = self._static
             if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype:
-                st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth), "ids": torch.empty_like(ids),
+                # the static ids buffer holds the longest instruction; a call uses its first B*L elements, so the graph of a new L
+                # differs by its key only, not by the buffer address
+                st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth),
+                      "ids": torch.empty(B * self.max_instr_len, device=self.device, dtype=ids.dtype),
+                      "lens": torch.empty(B, device=self.device, dtype=torch.int32),
                       "mask": torch.empty_like(m), "rec": [torch.empty(B, 7, device=self.device) for _ in range(2)],
                       "hh": [torch.zeros_like(hh) for _ in range(2)], "lh": [torch.zeros_like(lh) for _ in range(2)]}
                 self._static = st
@@ -208,19 +228,21 @@ class HCMEngine:
             # output buffers) are read in place: the captured graph is keyed by their addresses like by any other argument.
             # Tensors seen for the first time go through the engine's static copies, so that fresh allocations every step
             # do not force a new capture every step.
-            ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), m.data_ptr())
+            ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), m.data_ptr(), L, lens.data_ptr() if lens is not None else 0)
             direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
             st["last_ptrs"] = ptrs
-            st["hold"] = (rgb, depth, ids, m)              # keep the caller's tensors alive while the graph may read them
-            g_rgb, g_depth, g_ids, g_m = (rgb, depth, ids, m) if direct else (st["rgb"], st["depth"], st["ids"], st["mask"])
+            st["hold"] = (rgb, depth, ids, m, lens)        # keep the caller's tensors alive while the graph may read them
+            s_ids = st["ids"][:B * L].view(B, L)
+            g_rgb, g_depth, g_ids, g_m = (rgb, depth, ids, m) if direct else (st["rgb"], st["depth"], s_ids, st["mask"])
+            g_lens = None if lens is None else lens if direct else st["lens"]
             with torch.cuda.stream(gs):
                 i = st["tick"] & 1
-                for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (g_m, m),
+                for dst, src in ((g_rgb, rgb), (g_depth, depth), (g_ids, ids), (g_m, m), (g_lens, lens),
                                  (st["hh"][1 - i], hh), (st["lh"][1 - i], lh)):
-                    if dst.data_ptr() != src.data_ptr():
+                    if dst is not None and dst.data_ptr() != src.data_ptr():
                         dst.copy_(src, non_blocking=True)
                 _lib.check(self._lib.hcm_act_ex(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
-                                                g_ids.data_ptr(), _TORCH_DT[ids.dtype], B, st["hh"][1 - i].data_ptr(),
+                                                g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
                                                 st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
                                                 st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
                 st["tick"] += 1
@@ -230,7 +252,7 @@ class HCMEngine:
     # ---- training / validation path: T*N frames per call, RNNStateEncoder.seq_forward (state_encoder.py:83-133)
     def high_forward_seq(self, observations, hidden, masks):
         with torch.cuda.device(self.device):
-            rgb, depth, ids, TN = self._obs(observations, True)
+            rgb, depth, ids, lens, TN = self._obs(observations, True)
             h_in = self._hidden(hidden)
             N = h_in.shape[1]
             if TN % N:
@@ -239,13 +261,13 @@ class HCMEngine:
             logits = torch.empty(TN, self.cfg.num_actions, device=self.device, dtype=torch.float32)
             h_out = torch.empty_like(h_in)
             _lib.check(self._lib.hcm_high_forward_seq(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
-                                                      _TORCH_DT[ids.dtype], TN // N, N, h_in.data_ptr(), m.data_ptr(), logits.data_ptr(),
+                                                      _TORCH_DT[ids.dtype], _ptr(lens), TN // N, N, ids.shape[1], h_in.data_ptr(), m.data_ptr(), logits.data_ptr(),
                                                       h_out.data_ptr(), self._stream()), self._h)
         return logits, h_out
 
     def low_forward_seq(self, observations, hidden, masks, subtask):
         with torch.cuda.device(self.device):
-            rgb, depth, _, TN = self._obs(observations, False)
+            rgb, depth, _, _, TN = self._obs(observations, False)
             h_in = self._hidden(hidden)
             N = h_in.shape[1]
             if TN % N:
@@ -272,32 +294,38 @@ class HCMEngine:
                 rec = out
             return rec, hh2, lh2
         with torch.cuda.device(self.device):
-            rgb, depth, ids, B = self._obs(observations, True)
+            rgb, depth, ids, lens, B = self._obs(observations, True)
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
             hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)
             _lib.check(self._lib.hcm_act_ex(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
-                                            _TORCH_DT[ids.dtype], B, hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
+                                            _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
                                             rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
         return rec, hh2, lh2
 
-    def refresh_instruction(self, instruction, env_indices):
+    def refresh_instruction(self, instruction, env_indices, instruction_lengths=None):
         """Recompute the cached instruction stream of the listed environments (those that started a new episode) from
-        `instruction` (B, L); afterwards act(..., reuse_instruction=True) is valid again (hcm_refresh_instruction)."""
+        `instruction` (B, L) -- same L as the cached step; afterwards act(..., reuse_instruction=True) is valid again
+        (hcm_refresh_instruction)."""
         idx = np.ascontiguousarray(np.asarray(env_indices, dtype=np.int32).reshape(-1))
         with torch.cuda.device(self.device):
             ids = self._dev(instruction, (torch.int64, torch.int32, torch.float32))
-            B = ids.shape[0]
+            B, L = ids.shape
+            lens = None if instruction_lengths is None else self._dev(instruction_lengths, (torch.int32,)).reshape(-1)
             if self._graph and self._static is not None and self._static["B"] == B and self._static["ids"].dtype == ids.dtype:
                 gs = self._gstream
                 gs.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(gs):
-                    self._static["ids"].copy_(ids, non_blocking=True)
-                    _lib.check(self._lib.hcm_refresh_instruction(self._h, self._static["ids"].data_ptr(), _TORCH_DT[ids.dtype], B,
+                    s_ids = self._static["ids"][:B * L].view(B, L)
+                    s_ids.copy_(ids, non_blocking=True)
+                    if lens is not None:
+                        self._static["lens"].copy_(lens, non_blocking=True)
+                        lens = self._static["lens"]
+                    _lib.check(self._lib.hcm_refresh_instruction(self._h, s_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(lens), B, L,
                                                                  idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, C.c_void_p(gs.cuda_stream)), self._h)
                 torch.cuda.current_stream().wait_stream(gs)
             else:
-                _lib.check(self._lib.hcm_refresh_instruction(self._h, ids.data_ptr(), _TORCH_DT[ids.dtype], B,
+                _lib.check(self._lib.hcm_refresh_instruction(self._h, ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(lens), B, L,
                                                              idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, self._stream()), self._h)
 
     # ---- debug taps

@@ -3,7 +3,8 @@
 `vocab_files/bert-base-uncased-vocab.txt` and encodes the instruction text on EVERY environment step
 (hierarchical_trainer.py:1193-1196).  Here: a self-contained BERT tokenizer (basic tokenisation + greedy longest-match
 WordPiece, same defaults: lowercase, accents stripped, CJK characters isolated, [UNK] for words over 100 characters), built once,
-and an episode cache so that an instruction is tokenised once per episode, zero-padded to the engine's fixed `instr_len`.
+and an episode cache so that an instruction is tokenised once per episode: unpadded by default (what the reference feeds the
+model), or padded to a common length together with per-environment token counts for batched rollouts (`pad_batch`).
 """
 import unicodedata
 from typing import Dict, Iterable, List, Optional, Union
@@ -121,9 +122,15 @@ class WordPieceTokenizer:
 
 
 class InstructionCache:
-    """Tokenise an episode's instruction once (the reference re-tokenises every step)."""
+    """Tokenise an episode's instruction once (the reference re-tokenises every step).
 
-    def __init__(self, tokenizer: WordPieceTokenizer, instr_len: int, capacity: int = 4096):
+    instr_len=None (default): `get` returns the UNPADDED ids `tokenizer.encode(text).ids`, exactly what the reference's eval loop
+    hands to the model (common/utils.py:18-20; `max_seq_length` is accepted and ignored there).  BERT runs without an attention
+    mask and the cross-modal poolers average over all positions, so padding changes the model's output: pass these ids as a
+    (1, L) instruction.  instr_len=N: zero-padded / truncated to N, for batched rollouts that need one common L -- hand the
+    engine `instruction_lengths` (see `pad_batch`) so that every environment still gets its unpadded result."""
+
+    def __init__(self, tokenizer: WordPieceTokenizer, instr_len: Optional[int] = None, capacity: int = 4096):
         self.tok, self.L, self.cap = tokenizer, instr_len, capacity
         self._d: Dict[object, np.ndarray] = {}
         self.hits = self.misses = 0
@@ -133,7 +140,8 @@ class InstructionCache:
         if ids is None:
             if text is None:
                 raise KeyError(episode_id)
-            ids = self.tok.encode_padded(text, self.L)
+            ids = (np.asarray(self.tok.encode(text), dtype=np.int32) if self.L is None
+                   else self.tok.encode_padded(text, self.L))
             if len(self._d) >= self.cap:
                 self._d.pop(next(iter(self._d)))
             self._d[episode_id] = ids
@@ -141,3 +149,13 @@ class InstructionCache:
         else:
             self.hits += 1
         return ids
+
+
+def pad_batch(id_lists, pad_id: int = 0):
+    """Ragged token-id lists of B environments -> (ids (B, Lmax) int32 zero-padded, lengths (B,) int32) for
+    observations["instruction"] / observations["instruction_lengths"] of a batched engine call."""
+    lens = np.asarray([len(x) for x in id_lists], dtype=np.int32)
+    out = np.full((len(id_lists), int(lens.max())), pad_id, dtype=np.int32)
+    for i, x in enumerate(id_lists):
+        out[i, :len(x)] = np.asarray(x, dtype=np.int32)
+    return out, lens

@@ -73,7 +73,7 @@ def test_strict_state_dict_keys_and_shapes():
         assert l.hcm_query(h, _lib.HCM_NUM_RECURRENT_LAYERS, C.byref(out)) == 0 and out.value == 2
         assert l.hcm_query(h, _lib.HCM_RECORD_WIDTH, C.byref(out)) == 0 and out.value == 7
         # forward before finalize
-        assert l.hcm_act(h, *([None] * 1), 0, None, None, 0, 1, None, None, None, None, None, None, None) == -2
+        assert l.hcm_act(h, None, 0, None, None, 0, None, 1, 20, None, None, None, None, None, None, None) == -2
     finally:
         l.hcm_destroy(h)
 

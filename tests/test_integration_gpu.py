@@ -71,7 +71,7 @@ def test_c_abi_error_codes():
     d = torch.zeros(64, device="cuda")
     p = C.c_void_p(d.data_ptr())
     # forward before finalize -> HCM_ERR_STATE (-2)
-    assert lib.hcm_act(h, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -2
+    assert lib.hcm_act(h, p, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 1, 20, p, p, p, p, p, p, None) == -2
     assert b"finalize" in lib.hcm_last_error(h)
     # finalize with missing tensors -> HCM_ERR_KEY (-3), message names a key
     assert lib.hcm_finalize(h) == -3 and b"Missing key" in lib.hcm_last_error(h)
@@ -81,10 +81,13 @@ def test_c_abi_error_codes():
     from robo_vln_amd.policy import HCMEngine
     eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=2, precision="bf16")
     hh = eng._h
-    assert lib.hcm_act(hh, None, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -1          # null rgb
-    assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 3, p, p, p, p, p, p, None) == -1             # B > max_batch
-    assert lib.hcm_act(hh, p, _lib.HCM_BF16, p, p, _lib.HCM_I64, 1, p, p, p, p, p, p, None) == -1            # bad rgb dtype
-    assert lib.hcm_cma_forward(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, p, p, p, p, p, None) == -2        # not a CMANet handle
+    assert lib.hcm_act(hh, None, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 1, 20, p, p, p, p, p, p, None) == -1          # null rgb
+    assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 3, 20, p, p, p, p, p, p, None) == -1             # B > max_batch
+    assert lib.hcm_act(hh, p, _lib.HCM_BF16, p, p, _lib.HCM_I64, None, 1, 20, p, p, p, p, p, p, None) == -1            # bad rgb dtype
+    assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 1, 21, p, p, p, p, p, p, None) == -1             # L > max L of the engine
+    assert b"instruction length 21" in lib.hcm_last_error(hh)
+    assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 1, 0, p, p, p, p, p, p, None) == -1              # L < 1
+    assert lib.hcm_cma_forward(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, 1, 20, p, p, p, p, p, None) == -2        # not a CMANet handle
     out = C.c_int64()
     assert lib.hcm_query(hh, 99, C.byref(out)) == -1
     assert lib.hcm_query(hh, _lib.HCM_RECORD_WIDTH, C.byref(out)) == 0 and out.value == 7

@@ -50,6 +50,49 @@ def test_oracle_matches_reference_golden(name):
     np.testing.assert_allclose(lo_h.numpy(), gold["lo_hidden"], atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("name", list(cases.VARLEN_CASES))
+def test_oracle_matches_reference_unpadded_variable_length(name):
+    """The reference eval loop's operating point: unpadded (1, L) instructions whose length changes from step to step."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, B, lens = cases.varlen_case_config(name)
+    hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    R = cfg.num_recurrent_layers
+    hh, lh = torch.zeros(R, B, cfg.hidden), torch.zeros(R, B, cfg.hidden)
+    for t, L in enumerate(lens):
+        obs = synth.make_observations(cfg, B, step=t, seed=cases.SEED)
+        obs["instruction"] = cases.varlen_ids(cfg, L, t)
+        rec, hh, lh = ora.act(obs, hh, lh, cases.step_masks(B, t))
+        np.testing.assert_allclose(rec.numpy(), gold["records"][t], atol=TOL, rtol=0)
+    np.testing.assert_allclose(hh.numpy(), gold["hi_hidden"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(lh.numpy(), gold["lo_hidden"], atol=TOL, rtol=0)
+
+
+def test_padding_changes_the_reference_result_and_ragged_oracle_undoes_it():
+    """Why L is a per-call argument: BERT has no attention mask and the poolers average over all L positions, so a zero-padded
+    instruction gives a different record than the unpadded one; the ragged form (lengths) is per-environment unpadded."""
+    cfg = cases.HCMConfig(rgb_hw=64, depth_hw=64, bert_layers=1, instr_len=12).validate()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=1)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    B, R = 2, cfg.num_recurrent_layers
+    obs = synth.make_observations(cfg, B, step=0, seed=1)
+    lens = np.array([7, 12], np.int32)
+    ids = obs["instruction"].copy()
+    ids[0, lens[0]:] = 0
+    obs["instruction"] = ids
+    z = torch.zeros(R, B, cfg.hidden)
+    m = np.zeros(B, np.float32)
+    padded, _, _ = ora.act(obs, z, z, m)
+    ragged, _, _ = ora.act(obs, z, z, m, lengths=lens)
+    one = {k: v[:1] for k, v in obs.items()}
+    one["instruction"] = ids[:1, :7]
+    single, _, _ = ora.act(one, z[:, :1], z[:, :1], m[:1])
+    assert (padded[0, :4] - single[0, :4]).abs().max().item() > 1e-4          # padding is visible in the high-level logits
+    assert (ragged[0, :4] - single[0, :4]).abs().max().item() < 1e-5
+    assert (ragged[1] - padded[1]).abs().max().item() < 1e-5                  # the full-length row is unaffected
+
+
 @pytest.mark.parametrize("name", list(cases.CMA_CASES))
 def test_cma_oracle_matches_reference_golden(name):
     """CMANet flat baseline (models/cma.py:211-333): outputs, final hidden state and step-0 intermediates."""
