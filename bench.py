@@ -1,14 +1,19 @@
 """bench.py -- policy env-steps/sec of the batched HCM act() on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {0,1,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]/[2]): per GPU 64 environments, 256x256 RGB-D frames, 80-token
-instruction, full HCM model (2x ResNet-50 RGB, 2x GN-ResNet-50 depth, BERT-base, cross-modal block,
-2x LSTM + heads), bf16 storage / fp32 accumulate, random-init weights, synthetic inputs resident in HBM.
-One step = one fused act() (hi -> argmax -> lo) over the rank's 64 environments, followed (N>1) by ONE
-RCCL all-gather of the (64,7) action records.  Weak scaling: global batch = 64 * N.
-Prints ONE JSON line on rank 0.
+Default workload (BASELINE.json configs[1]/[2], the configuration the metric is quoted on): per GPU 64 environments, 256x256
+RGB-D frames, 80-token instruction, full HCM model (2x ResNet-50 RGB, 2x GN-ResNet-50 depth, BERT-base, cross-modal block,
+2x LSTM + heads), 16-bit storage / fp32 accumulate, random-init weights, synthetic inputs resident in HBM (two observation sets
+used alternately).  One step = one fused act() (hi -> argmax -> lo) over the rank's 64 environments, followed (N>1) by ONE RCCL
+all-gather of the (64,7) action records ON THE CRITICAL PATH: a rollout cannot produce the next observation before it
+has the record.  Weak scaling: global batch = 64 * N.  Prints ONE JSON line on rank 0.
+
+The other BASELINE configs are parity-test shapes; `--config` times them for their per-config roofline:
+  0  B=4, 128x128, L=20, N=2 (the reference's CPU-runnable plumbing case)            act()
+  3  SimpleDepthCNN + 1-layer Visual_Ling_Attn, B=256 (memory-bound path)             robo-vln_amd/probe.py, HBM roofline
+  4  high-level model, ResNet-50 RGB + N=6 decoder, L=160, B=128 (MFMA-bound path)    hcm_high_forward, MFMA roofline
 """
 import argparse
 import json
@@ -19,9 +24,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_STEP = 36.9          # SURVEY.md 8a / BASELINE.md section 2: config 2/3, 2xMAC conv+matmul+attention+RNN
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PER_GPU_BATCH = 64
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense 16-bit MFMA peak (MI355X_MICROARCH.md); bf16 and fp16 have the same rate
+PEAK_HBM_TBPS = 8.0
+# algorithmic work per env-step, SURVEY.md 8a table (2 x MAC of conv + matmul + attention + RNN gates)
+GFLOP = {0: 9.34, 1: 36.9, 4: 42.9}
+BATCH = {0: 4, 1: 64, 3: 256, 4: 128}
+WORKLOAD = {
+    0: "BASELINE.json configs[0]: full HCM act(), 128x128 RGB-D, L=20, VLA N=2, LSTM-512",
+    1: "BASELINE.json configs[1]: full HCM act() (hi->argmax->lo), 256x256 RGB-D, L=80, VLA N=1, LSTM-512",
+    3: "BASELINE.json configs[3]: SimpleDepthCNN(256x256 depth) -> one visual token -> Visual_Ling_Attn(N=1) over a pre-computed (B,80,768) instruction tensor",
+    4: "BASELINE.json configs[4]: high-level model alone, ResNet-50 RGB + GN-ResNet-50 depth + BERT + 6-layer cross-modal decoder, 256x256, L=160",
+}
 
 
 def host_cores():
@@ -37,8 +50,8 @@ def host_cores():
 
 
 def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
-    """The CPU oracle (kind 'port': torch-CPU fp32 restatement validated against the imported reference)
-    timed on this host's cores on a bounded sample of the same workload."""
+    """The CPU oracle (kind 'port': torch-CPU fp32 restatement validated against the imported reference) timed on this
+    host's cores on a bounded sample of the same workload (batch 16 instead of 64: about 10-20 s of CPU work)."""
     import numpy as np
     import torch
     from oracle import hcm_oracle
@@ -58,18 +71,60 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
         _, hh, lh = ora.act(obs, hh, lh, mask)
     dt = time.time() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "env-steps/s", "cores": ncores, "kind": "port",
-            "sample": f"{steps} act() steps at batch {batch}, 256x256 RGB-D, L=80, fp32, torch {torch.__version__} "
+            "sample": f"{steps} act() steps at batch {batch} (the GPU line runs batch 64), 256x256 RGB-D, L=80, fp32, torch {torch.__version__} "
                       f"with {torch.get_num_threads()} threads"}
 
 
-def dominant_kernel_probe(batch):
-    """The launch type with the largest share of the step is the fused bottleneck kernel of the RGB ResNet-50 pair, `bneck231_kernel`
-    (3x3 conv 64->64 + ReLU, 1x1 expansion 64->256 + identity + ReLU, and the next block's 1x1 reduction 256->64 + ReLU in one
-    launch; six launches per step in four shapes).  Time its layer1 middle-block shape live with HIP events (torch events on the
-    launch stream).  In the step that layer is ONE launch over the hi|lo pair (2 groups x B images); the probe runs the same amount
-    of work as a single group over 2*B images (same tile count, same per-tile work), so its duration is comparable with the
-    bneck231_kernel<bf16,128,64,64,0> row of profiles/r1_kernel_trace_bench.md.  The launch is HBM-bound: algorithmic bytes =
-    2 B/elem * M * (64 in + 256 identity + 256 out + 64 next-reduction out); algorithmic FLOPs = 2 * M * (576*64 + 64*256 + 256*64)."""
+def _time_op(run, n=60, warm=30):
+    """HIP events on torch's current stream, which is the stream the operator entry points are handed."""
+    import torch
+    for _ in range(warm):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n          # ms
+
+
+def dominant_kernel_probe(batch, L=80):
+    """The kernel with the largest share of a step's kernel time is the implicit-GEMM kernel `igemm_dma_kernel` on the fp16 BERT
+    shapes (profiles/r2_kernel_trace_bench.md): 12 launches each of QKV (768 -> 2304), attention-output (768 -> 768), FFN1
+    (768 -> 3072, GELU) and FFN2 (3072 -> 768) over M = batch * L token rows.  Each is timed live here through the library's operator
+    entry point (same kernel, same tile choice as inside the step) and priced against the dense 16-bit MFMA peak: algorithmic FLOPs
+    per launch = 2*M*N*K.  The FFN1 launch is the single most expensive one and is the `roofline` of the JSON line."""
+    import ctypes as C
+    import torch
+    from robo_vln_amd import _lib
+    lib = _lib.lib()
+    M = batch * L
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for name, N, K, act, res in (("ffn1", 3072, 768, _lib.ACT_GELU, False), ("qkv", 2304, 768, 0, False),
+                                 ("ffn2", 768, 3072, 0, True), ("attn_out", 768, 768, 0, True)):
+        x = (torch.randn(M, K, device="cuda") * 0.5).half()
+        w = (torch.randn(N, K, device="cuda") * 0.03).half()
+        b = torch.randn(N, device="cuda") * 0.1
+        r = (torch.randn(M, N, device="cuda") * 0.5).half() if res else None
+        y = torch.empty(M, N, device="cuda", dtype=torch.float16)
+
+        def run():
+            rc = lib.hcm_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(),
+                                   _lib.HCM_F16, M, N, K, act, 0, st)
+            assert rc == 0
+        ms = _time_op(run)
+        fl = 2.0 * M * N * K
+        out[name] = {"shape": f"M={M} N={N} K={K}", "us_per_launch": round(ms * 1e3, 2), "gflop_per_launch": round(fl / 1e9, 2),
+                     "tflops": round(fl / ms / 1e9, 1), "frac_of_peak": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "launches_per_step": 12}
+    return out
+
+
+def hbm_kernel_probe(batch):
+    """Second, HBM-bound probe: the fused bottleneck kernel of the RGB ResNet-50 pair, `bneck231_kernel` (3x3 conv 64->64 + ReLU, 1x1
+    expansion 64->256 + identity + ReLU and the next block's 1x1 reduction in one launch), at its layer1 middle-block shape on the
+    hi|lo pair workload (M = 2*B*4096 pixels).  Algorithmic bytes = 2 B/elem * M * (64 in + 256 identity + 256 out + 64 next)."""
     import ctypes as C
     import torch
     from robo_vln_amd import _lib
@@ -93,22 +148,97 @@ def dominant_kernel_probe(batch):
         rc = lib.hcm_op_bottleneck_tail_next(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
                                              y.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, CN, st)
         assert rc == 0
-    for _ in range(100):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 100
-    e0.record()
-    for _ in range(n):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    ms = _time_op(run, 100, 100)
     M = B * H * W
-    flops = 2.0 * M * (9 * C1 * C1 + C1 * C3 + C3 * CN)
     gbytes = 2.0 * M * (C1 + 2 * C3 + CN) / 1e9
-    return {"kernel": "bneck231_kernel<bf16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair workload (M=2*B*4096)",
-            "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": 8.0,
-            "frac": round(gbytes / ms / 8.0, 4), "tflops": round(flops / ms / 1e9, 1)}
+    return {"kernel": "bneck231_kernel<bf16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair (M=2*B*4096)",
+            "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": PEAK_HBM_TBPS,
+            "frac": round(gbytes / ms / PEAK_HBM_TBPS, 4)}
+
+
+def pmc_traffic():
+    """HBM bytes from the PMC counters: written by tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+    passes of this same command (x2 gfx950 correction on FETCH_SIZE, MI355X_MICROARCH.md); never a literal in this file."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------ workloads
+def build_act_workload(args, cfg_idx, rank, world, local_rank):
+    import torch
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import baseline_config
+    from robo_vln_amd.policy import HCMEngine
+    cfg = baseline_config(cfg_idx)
+    B = args.batch or BATCH[cfg_idx]
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank (SURVEY 8e)
+    hi_only = cfg_idx == 4
+    eng = HCMEngine(cfg, hi_sd, None if hi_only else lo_sd, max_batch=B, precision=args.precision, graph=not args.no_graph and not hi_only)
+    # two observation sets resident in HBM, used alternately (distinct frames per rank, same shapes)
+    sets = []
+    for k in range(2):
+        o = synth.make_observations(cfg, B, step=2 * rank + k, seed=0, rgb_uint8=True)
+        sets.append({"rgb": torch.from_numpy(o["rgb"]).cuda(), "depth": torch.from_numpy(o["depth"]).cuda(),
+                     "instruction": torch.from_numpy(o["instruction"]).cuda()})
+    R = cfg.num_recurrent_layers
+    state = {"hh": torch.zeros(R, B, cfg.hidden, device="cuda"), "lh": torch.zeros(R, B, cfg.hidden, device="cuda"), "tick": 0}
+    mask1 = torch.ones(B, device="cuda")
+    stager = None
+    if args.h2d:
+        from robo_vln_amd.obs import ObsStager
+        stager = ObsStager(B, cfg.rgb_hw, cfg.depth_hw, cfg.instr_len, device=torch.device("cuda", local_rank))
+        stager.host["rgb"].copy_(sets[0]["rgb"].cpu())
+        stager.host["depth"].copy_(sets[0]["depth"].cpu())
+        stager.host["instruction"].copy_(sets[0]["instruction"].cpu().int())
+
+    def step(mask=None):
+        obs = sets[state["tick"] & 1]
+        state["tick"] += 1
+        if stager is not None:
+            for k in ("rgb", "depth"):
+                stager.dev[k].copy_(stager.host[k], non_blocking=True)
+            obs = stager.dev
+        m = mask1 if mask is None else mask
+        if hi_only:
+            logits, state["hh"] = eng.high_forward(obs, state["hh"], m)
+            return logits
+        r, state["hh"], state["lh"] = eng.act(obs, state["hh"], state["lh"], m,
+                                              reuse_instruction=args.reuse_instruction and mask is None and state["tick"] > 3)
+        return r
+    return cfg, B, eng, step, (hi_sd, lo_sd)
+
+
+def build_probe_workload(args):
+    """configs[3]: the depth-only SimpleCNN -> one token -> 1-layer cross-modal block composition (robo-vln_amd/probe.py)."""
+    import torch
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import HCMConfig
+    from robo_vln_amd.probe import DepthCnnVlaProbe
+    cfg = HCMConfig(vla_layers=1).validate()
+    B, L = args.batch or BATCH[3], cfg.instr_len
+    cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, cfg.depth_hw, 128), "probe_cnn", 0)
+    vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
+    prec = "fp16" if args.precision == "bf16" else "fp32"
+    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec)
+    tdt = torch.float16 if prec == "fp16" else torch.float32
+    sets = []
+    for k in range(2):
+        depth = synth.uniform01(f"probe/depth{k}", B * 256 * 256, 0).reshape(B, 256, 256, 1)
+        ins = synth.uniform01(f"probe/ins{k}", B * L * 768, 0).reshape(B, L, 768) * 2 - 1
+        sets.append((torch.from_numpy(depth).cuda(), torch.from_numpy(ins).to(tdt).cuda()))
+    state = {"tick": 0}
+
+    def step(mask=None):
+        d, i = sets[state["tick"] & 1]
+        state["tick"] += 1
+        return probe.forward(d, i)
+    esz = 2 if prec == "fp16" else 4
+    # SURVEY 8d: depth f32 in + instruction tensor in + (B,L,256) out, weights once per batch
+    alg_bytes = B * (256 * 256 * 4 + L * 768 * esz + L * 256 * esz) + (3.26e6 + 1.02e6) * esz
+    return cfg, B, probe, step, alg_bytes, prec
 
 
 def main():
@@ -116,25 +246,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 3, 4], help="BASELINE.json configs index (1 = the headline workload)")
     ap.add_argument("--no-kernel-probe", action="store_true", help="skip the dominant-kernel timing (profiler runs: keeps the trace to the step's own launches)")
     ap.add_argument("--prewarm", type=int, default=40, help="untimed clock-ramp steps before the W warm-up steps (0 for profiler runs)")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="environments per GPU")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the additional sustained measurement reported as `sustained` (0 = skip)")
+    ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the BASELINE size of the config)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--reuse-instruction", action="store_true",
                     help="NOT the headline configuration: steps after the first skip BERT (instructions unchanged; hcm_act_ex flag)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="include the per-step host->device staging of uint8 RGB + f32 depth "
                     "(pinned buffers) in the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue the ~700 kernels of a step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
+
+    if os.environ.get("HCM_SKIP"):
+        # a development build of the library (make DEV=1) drops whole encoder chains under this variable: whatever it measures is
+        # not the workload, so no result line is printed
+        print("bench.py: HCM_SKIP is set -- a work-dropping profiling knob; refusing to produce a benchmark line", file=sys.stderr)
+        raise SystemExit(3)
 
     import torch
     import torch.distributed as dist
     import hcm_pkg
     hcm_pkg.load()
-    from robo_vln_amd import synth
-    from robo_vln_amd.config import baseline_config
-    from robo_vln_amd.policy import HCMEngine
     from robo_vln_amd.rollout import shard_range, gather_records
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +278,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world > 1 and args.config != 1:
+        raise SystemExit("--config 0/3/4 are single-GPU roofline lines; the multi-GPU workload is configs[1]/[2]")
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run (any N)
     if use_dist:
@@ -151,122 +288,175 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    cfg = baseline_config(1)
-    B = args.batch
+    alg_bytes = None
+    if args.config == 3:
+        cfg, B, eng, raw_step, alg_bytes, prec3 = build_probe_workload(args)
+        weights = None
+    else:
+        cfg, B, eng, raw_step, weights = build_act_workload(args, args.config, rank, world, local_rank)
     global_B = B * world
-    hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank
-    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=args.precision, graph=not args.no_graph)
-    # this rank's contiguous block of environments e -> rank e // B
-    lo_e, hi_e = shard_range(global_B, world, rank)
-    obs_np = synth.make_observations(cfg, B, step=rank, seed=0)    # distinct frames per rank, same shapes
-    obs = {"rgb": torch.from_numpy(obs_np["rgb"]).cuda(), "depth": torch.from_numpy(obs_np["depth"]).cuda(),
-           "instruction": torch.from_numpy(obs_np["instruction"]).cuda()}
-    R = cfg.num_recurrent_layers
-    hh = torch.zeros(R, B, cfg.hidden, device="cuda")
-    lh = torch.zeros(R, B, cfg.hidden, device="cuda")
-    mask0 = torch.zeros(B, device="cuda")
-    mask1 = torch.ones(B, device="cuda")
+    lo_e, hi_e = shard_range(global_B, world, rank)     # this rank's contiguous block of environments e -> rank e // B
     rec = torch.empty(B, 7, device="cuda")
     all_rec = torch.empty(global_B, 7, device="cuda") if use_dist else rec
+    last = {}
 
-    stager = None
-    if args.h2d:
-        from robo_vln_amd.obs import ObsStager
-        stager = ObsStager(B, cfg.rgb_hw, cfg.depth_hw, cfg.instr_len, device=torch.device("cuda", local_rank))
-        stager.host["rgb"].copy_(torch.from_numpy(obs_np["rgb"].astype("uint8")))
-        stager.host["depth"].copy_(torch.from_numpy(obs_np["depth"]))
-        stager.host["instruction"].copy_(torch.from_numpy(obs_np["instruction"].astype("int32")))
-
-    # The all-gather of step i is enqueued on a communication stream and overlaps the compute of step i+1 (the gathered
-    # records are the step's OUTPUT towards the environments; nothing in the next policy step reads them).  The engine's
-    # record buffers ping-pong, so step i+2 waits for gather i before overwriting its source.
+    # N>1: the all-gather of step i can either sit on the critical path (what a rollout needs: the environments cannot produce
+    # observation i+1 before they have record i) or be overlapped with the compute of step i+1 on a communication stream (an upper
+    # bound that only a pipelined simulator could use).  `value` is the former; the latter is reported as an extra key.
     comm = torch.cuda.Stream() if use_dist else None
     pending = []
 
-    def step(mask):
-        nonlocal hh, lh, obs
-        if use_dist and len(pending) >= 2:
+    def step(mask=None, overlap=False):
+        if use_dist and overlap and len(pending) >= 2:
             torch.cuda.current_stream().wait_event(pending.pop(0))
-        if stager is not None:
-            for k in ("rgb", "depth"):
-                stager.dev[k].copy_(stager.host[k], non_blocking=True)
-            obs = stager.dev
-        r, hh, lh = eng.act(obs, hh, lh, mask, reuse_instruction=args.reuse_instruction and mask is mask1)
+        r = raw_step(mask)
+        last["r"] = r
+        if not use_dist:
+            return
+        if not overlap:
+            gather_records(r, all_rec)                  # ONE RCCL all-gather of the (B,7) records per step, in stream order
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            gather_records(r, all_rec)
+            done = torch.cuda.Event()
+            done.record(comm)
+        pending.append(done)
+
+    def timed(n, overlap=False):
         if use_dist:
-            ready = torch.cuda.Event()
-            ready.record()
-            comm.wait_event(ready)
-            with torch.cuda.stream(comm):
-                gather_records(r, all_rec)              # ONE RCCL all-gather of the (B,7) records per step
-                done = torch.cuda.Event()
-                done.record(comm)
-            pending.append(done)
-        else:
-            rec.copy_(r)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(overlap=overlap)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    if use_dist:
+        # prove that the collective moves every rank's rows to every rank: rank-tagged records, checked on all ranks
+        tag = (torch.arange(B * 7, device="cuda", dtype=torch.float32).reshape(B, 7) + 1000.0 * rank)
+        gather_records(tag, all_rec)
+        torch.cuda.synchronize()
+        want = torch.cat([torch.arange(B * 7, dtype=torch.float32).reshape(B, 7) + 1000.0 * r for r in range(world)]).cuda()
+        assert torch.equal(all_rec, want), f"rank {rank}: all-gather did not deliver every rank's rows in rank order"
 
     # two untimed steps before the W warm-up steps: the library runs a new (batch, pointer set) eagerly once and captures its
-    # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is
-    step(mask0)
-    step(mask1)
-    for _ in range(args.prewarm):                      # ... and ~0.25 s of untimed steps so that the clocks have ramped (a fixed
-        step(mask1)                                    # count: every rank must issue the same number of all-gathers)
+    # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is (x2: two observation sets)
+    zero = torch.zeros(B, device="cuda")
+    step(zero)
+    for _ in range(5):
+        step()
+    for _ in range(args.prewarm):                      # ~0.25 s of untimed steps so that the clocks have ramped (a fixed
+        step()                                         # count: every rank must issue the same number of all-gathers)
     for _ in range(args.warmup):
-        step(mask1)
+        step()
+    dt = timed(args.steps)
+    # what the step returned is checked, not only timed: finite, and (N>1) this rank's rows of the gathered records are its own
+    r = last["r"]
+    assert torch.isfinite(r.float()).all(), "non-finite outputs"
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(mask1)
-    torch.cuda.synchronize()
+        assert torch.equal(all_rec[lo_e:hi_e], r), "gathered records do not contain this rank's rows"
+        chk = all_rec.double().sum().reshape(1)
+        lo_c, hi_c = chk.clone(), chk.clone()
+        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+        assert float(lo_c) == float(hi_c), "ranks disagree on the gathered records"
+
+    sustained = None
+    if args.sustain > 0:
+        n_s = max(args.steps, int(args.sustain / (dt / args.steps)) + 1)
+        if use_dist:
+            t = torch.tensor([n_s], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_s = int(t.item())
+        dts = timed(n_s)
+        sustained = {"seconds": round(dts, 3), "steps": n_s, "value": round(global_B * n_s / dts, 2), "ms_per_step": round(dts / n_s * 1e3, 3)}
+    overlapped = None
     if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert os.environ.get("HCM_SKIP") or torch.isfinite(all_rec).all()
+        for _ in range(4):
+            step(overlap=True)
+        dto = timed(args.steps, overlap=True)
+        torch.cuda.current_stream().wait_stream(comm)
+        overlapped = {"value": round(global_B * args.steps / dto, 2), "ms_per_step": round(dto / args.steps * 1e3, 3),
+                      "note": "all-gather of step i on a communication stream, overlapping the compute of step i+1 (needs a pipelined simulator)"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = global_B * args.steps / dt
-        achieved = value * GFLOP_PER_STEP / 1e3               # TFLOP/s, algorithmic
+        tr = pmc_traffic() if args.config == 1 and B == 64 else None
         out = {
-            "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr",
+            "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr" if args.config == 1 else
+                      f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
             "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16+fp16 (16-bit MFMA, fp32 accumulate; DESIGN.md section 5)" if args.precision == "bf16" else "fp32", "data": "synthetic (random-init weights, random RGB-D frames and token ids, resident in HBM)",
+            "dtype": ("bf16+fp16 (16-bit MFMA, fp32 accumulate; DESIGN.md section 5)" if args.precision == "bf16" else "fp32") if args.config != 3
+                     else (prec3 + " storage / MFMA, fp32 accumulate"),
+            "data": "synthetic (random-init weights, random RGB-D frames and token ids, two observation sets resident in HBM used alternately)",
             "h2d_in_timed_region": bool(args.h2d),
-            "config": {"workload": "BASELINE.json configs[1]: full HCM act() (hi->argmax->lo), 256x256 RGB-D, L=80, VLA N=1, LSTM-512",
-                       "per_gpu_batch": B, "global_batch": global_B,
-                       "parallelism": f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
-                         # HBM-side bytes per act() step at B=64 from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) +
-                         # WRITE_SIZE, separate passes of this same command: profiles/r1_pmc_traffic_bench.md
-                         "traffic": 15.07 if B == 64 else None, "traffic_unit": "GB per act() step at B=64 (whole step, like achieved)",
-                         "traffic_source": "profiles/r1_pmc_traffic_bench.md",
-                         "basis": f"{GFLOP_PER_STEP} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s",
-                         # the same step seen from the memory side: measured HBM bytes per step / step time vs the 8 TB/s peak
-                         "hbm_view": ({"achieved_TBps": round(15.07 / ms, 3), "peak_TBps": 8.0 * world, "frac": round(15.07 / ms / 8.0, 4)}
-                                      if B == 64 else None)},
+            "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": global_B,
+                       "parallelism": (f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step on the critical path"
+                                       if world > 1 else "single GPU")},
         }
-        if args.reuse_instruction:
-            out["metric"] += " [instruction stream cached: BERT skipped, 23.1 instead of 36.9 GFLOP per env-step executed]"
-            out["roofline"]["achieved"] = round(value * (GFLOP_PER_STEP - 13.83) / 1e3, 2)
-            out["roofline"]["frac"] = round(out["roofline"]["achieved"] / (PEAK_BF16_TFLOPS * world), 4)
-            out["roofline"]["basis"] = "cached-instruction variant: 36.9 - 13.83 (BERT) GFLOP per env-step x env-steps/s"
-        out["config"]["hipgraph"] = {"enabled": not args.no_graph, "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
-        if args.precision == "bf16" and not args.no_kernel_probe:
-            try:
-                out["roofline"]["dominant_kernel"] = dominant_kernel_probe(B)
-            except Exception as e:       # never lose the headline number to the probe
-                out["roofline"]["dominant_kernel"] = {"error": str(e)}
-        if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(cfg, hi_sd, lo_sd)
+        if sustained:
+            out["sustained"] = sustained
+        if overlapped:
+            out["overlapped_all_gather"] = overlapped
+        if args.config == 3:
+            gb = alg_bytes / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(gb / ms, 4), "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": round(gb / ms / PEAK_HBM_TBPS, 4),
+                               "traffic": None, "basis": f"{gb * 1e3:.1f} MB algorithmic bytes per step (depth f32 in + (B,80,768) instruction tensor in + (B,80,256) out + "
+                               "weights once, SURVEY 8d) / step time; the step is the whole probe (all its launches)"}
+        else:
+            gf = GFLOP[args.config]
+            achieved = value * gf / 1e3                           # TFLOP/s, algorithmic
+            whole = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                     "frac": round(achieved / (PEAK_BF16_TFLOPS * world), 4),
+                     "basis": f"{gf} algorithmic GFLOP per env-step (SURVEY 8a) x env-steps/s"}
+            if tr:
+                whole["traffic_GB_per_step"] = tr.get("step_GB")
+                whole["hbm_view"] = {"achieved_TBps": round(tr["step_GB"] / ms, 3), "peak_TBps": PEAK_HBM_TBPS * world,
+                                     "frac": round(tr["step_GB"] / ms / PEAK_HBM_TBPS, 4)}
+            if args.reuse_instruction:
+                out["metric"] += " [instruction stream cached: BERT skipped, 23.1 instead of 36.9 GFLOP per env-step executed]"
+                whole["achieved"] = round(value * (gf - 13.83) / 1e3, 2)
+                whole["frac"] = round(whole["achieved"] / (PEAK_BF16_TFLOPS * world), 4)
+                whole["basis"] = "cached-instruction variant: 36.9 - 13.83 (BERT) GFLOP per env-step x env-steps/s"
+            roof = dict(whole)
+            roof["scope"] = "whole step"
+            if args.precision == "bf16" and not args.no_kernel_probe and args.config in (1, 4):
+                try:
+                    L = cfg.instr_len
+                    dk = dominant_kernel_probe(B, L)
+                    top = dk["ffn1"]
+                    k_tr = (tr or {}).get("dominant_kernel_GB_per_launch")
+                    # the JSON line's `roofline` is the DOMINANT KERNEL (igemm_dma_kernel on the BERT FFN1 shape), live HIP-event timing;
+                    # the whole-step view and the HBM-bound probe ride along as labelled sub-objects
+                    roof = {"bound": "mfma", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_peak"],
+                            "traffic": k_tr, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)" if k_tr else None,
+                            "scope": "dominant kernel: igemm_dma_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
+                                     f"{top['gflop_per_launch']} algorithmic GFLOP per launch, 12 launches per step",
+                            "bert_gemms": dk, "whole_step": whole}
+                    roof["hbm_probe"] = hbm_kernel_probe(B)
+                except Exception as e:       # never lose the headline number to the probe
+                    roof["dominant_kernel_error"] = str(e)
+            out["roofline"] = roof
+        if hasattr(eng, "query"):
+            out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
+        if not args.no_cpu_baseline and world == 1 and args.config == 1:          # reported on rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(cfg, *weights)
         print(json.dumps(out), flush=True)
-    eng.close()
+    if hasattr(eng, "close"):
+        eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

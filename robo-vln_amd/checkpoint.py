@@ -2,8 +2,9 @@
 
 `RoboDaggerTrainer.save_checkpoint` writes `torch.save({"high_level_state_dict", "low_level_state_dict", "config"})`
 (robo_vln_baselines/hierarchical_trainer.py:349-363); `_setup_actor_critic_agent` loads the two state_dicts with
-`load_state_dict` (:343-345).  The pickled `config` is a yacs `CfgNode`; yacs is not needed here: unknown classes
-un-pickle as plain dict/object stand-ins.
+`load_state_dict` (:343-345).  The pickled `config` is a yacs `CfgNode`; yacs is not needed here: every class outside a
+small allow-list (tensor rebuild helpers, OrderedDict, builtin containers) un-pickles as an inert dict stand-in, so a
+checkpoint cannot execute code through the un-pickler.
 """
 import pickle
 
@@ -15,7 +16,11 @@ IGNORED_SUFFIXES = ("embeddings.position_ids", "embeddings.token_type_ids")
 
 
 class _Stub(dict):
-    """Stand-in for classes whose module is not installed (e.g. yacs.config.CfgNode)."""
+    """Inert stand-in for every class a checkpoint's pickle names outside the allow-list below (e.g. yacs.config.CfgNode,
+    habitat's Config): constructed without running any code of the named class, keeps whatever state the pickle sets."""
+
+    def __init__(self, *a, **k):
+        dict.__init__(self)
 
     def __setstate__(self, state):
         if isinstance(state, dict):
@@ -25,12 +30,34 @@ class _Stub(dict):
         return (dict, (dict(self),))
 
 
+# What a `torch.save`d state_dict needs and nothing else.  Un-pickling resolves ONLY these globals; any other (module, name) --
+# importable or not -- becomes an inert _Stub subclass, so loading a checkpoint from an untrusted source cannot run code through
+# `find_class` (the hole of a plain pickle / weights_only=False load).
+_ALLOWED = {
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.serialization", "_get_layout"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "bytes"), ("builtins", "complex"),
+}
+
+
+def _allowed(module, name):
+    if (module, name) in _ALLOWED:
+        return True
+    # legacy typed storage classes (torch.FloatStorage, ...) and dtype singletons (torch.float32, ...)
+    if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+        return True
+    return False
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
+        if _allowed(module, name):
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return type(name, (_Stub,), {"__module__": module})
+        return type(name, (_Stub,), {"__module__": module})
 
 
 class _TolerantPickle:

@@ -137,8 +137,12 @@ class CMAEngine:
         gs.wait_stream(cur)
         # observation buffers whose addresses repeat from the previous call are read in place (see HCMEngine._act_graph)
         ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr())
-        direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
-        st["last_ptrs"] = ptrs
+        seen = st.setdefault("seen_ptrs", [])
+        direct = ptrs in seen and not os.environ.get("HCM_NO_DIRECT_OBS")
+        if ptrs in seen:
+            seen.remove(ptrs)
+        seen.append(ptrs)
+        del seen[:-4]
         st["hold"] = (rgb, depth, ids)
         L = ids.shape[1]
         g_rgb, g_depth, g_ids = (rgb, depth, ids) if direct else (st["rgb"], st["depth"], st["ids"][:B * L].view(B, L))

@@ -229,8 +229,13 @@ class HCMEngine:
             # Tensors seen for the first time go through the engine's static copies, so that fresh allocations every step
             # do not force a new capture every step.
             ptrs = (rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), m.data_ptr(), L, lens.data_ptr() if lens is not None else 0)
-            direct = st.get("last_ptrs") == ptrs and not os.environ.get("HCM_NO_DIRECT_OBS")
-            st["last_ptrs"] = ptrs
+            # (a caller that rotates a few buffer sets -- double-buffered staging -- is recognised as well: the last four sets)
+            seen = st.setdefault("seen_ptrs", [])
+            direct = ptrs in seen and not os.environ.get("HCM_NO_DIRECT_OBS")
+            if ptrs in seen:
+                seen.remove(ptrs)
+            seen.append(ptrs)
+            del seen[:-4]
             st["hold"] = (rgb, depth, ids, m, lens)        # keep the caller's tensors alive while the graph may read them
             s_ids = st["ids"][:B * L].view(B, L)
             g_rgb, g_depth, g_ids, g_m = (rgb, depth, ids, m) if direct else (st["rgb"], st["depth"], s_ids, st["mask"])

@@ -6,6 +6,7 @@ import sys
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from robo_vln_amd import _lib, checkpoint, synth
@@ -60,3 +61,79 @@ def test_missing_state_dict_key_is_reported():
         assert "low_level_state_dict" in str(e)
     else:
         raise AssertionError("expected KeyError")
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+def _strict_load(cfg, hi_sd, lo_sd):
+    l = _lib.lib()
+    st = _to_struct(cfg, 2, "bf16", True, True)
+    h = C.c_void_p()
+    assert l.hcm_create(C.byref(st), C.byref(h)) == 0
+    try:
+        for model, sd in ((_lib.HCM_HIGH, hi_sd), (_lib.HCM_LOW, lo_sd)):
+            for k, v in sd.items():
+                a, dt = _np32(v)
+                shp = (C.c_int64 * max(1, a.ndim))(*a.shape)
+                assert l.hcm_load_tensor(h, model, k.encode(), a.ctypes.data_as(C.c_void_p), dt, shp, a.ndim) == 0, (k, l.hcm_last_error(h))
+        # nothing is missing either: the only failure finalize can still report without a GPU is a HIP one
+        rc = l.hcm_finalize(h)
+        assert rc != -3, l.hcm_last_error(h)
+    finally:
+        l.hcm_destroy(h)
+
+
+def test_reference_written_checkpoint_structure():
+    """A checkpoint dict written by the REAL reference modules' state_dict() (oracle/gen_checkpoint_fixture.py; values hollowed
+    out, structure intact: 721 + 497 keys in the reference's order, BertEmbeddings buffers, num_batches_tracked scalars, OrderedDict
+    metadata, a config object of a class that cannot be imported here) goes through load_checkpoint and libhcm's strict loader
+    at the default full-size configuration."""
+    import os
+    hi, lo, conf = checkpoint.load_checkpoint(os.path.join(GOLD, "ref_checkpoint_structure.pth"))
+    cfg = HCMConfig().validate()
+    assert len(lo) == 497 and set(lo) == {k for k, *_ in synth.low_level_spec(cfg)}
+    assert set(hi) == {k for k, *_ in synth.high_level_spec(cfg)}
+    assert hi["embedding_layer.embeddings.word_embeddings.weight"].shape == (30522, 768)
+    assert hi["rgb_encoder.cnn.bn1.num_batches_tracked"].dim() == 0
+    # the config came back as an inert stand-in that still carries the reference's fields
+    assert type(conf).__module__ != "builtins" and conf["STATE_ENCODER"]["rnn_type"] == "LSTM" and conf["VISUAL_LING_ATTN"]["N"] == 1
+    _strict_load(cfg, hi, lo)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/robo_vln_baselines"), reason="needs the reference checkout (build container only)")
+def test_checkpoint_saved_from_reference_modules_roundtrips_exactly():
+    """Container-only: the imported reference models (synthetic weights loaded with strict=True) are saved exactly as
+    RoboDaggerTrainer.save_checkpoint does (hierarchical_trainer.py:349-363) and read back: every value identical, strict load ok."""
+    from oracle import ref_shims
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=2)
+    hi, lo = ref_shims.build_models(cfg, hi_sd, lo_sd)
+    buf = io.BytesIO()
+    torch.save({"high_level_state_dict": hi.state_dict(), "low_level_state_dict": lo.state_dict(), "config": ref_shims.model_config(cfg)}, buf)
+    buf.seek(0)
+    hi2, lo2, conf = checkpoint.load_checkpoint(buf)
+    for got, ref in ((hi2, hi.state_dict()), (lo2, lo.state_dict())):
+        keys = [k for k in ref if not k.endswith(checkpoint.IGNORED_SUFFIXES)]
+        assert list(got) == keys
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), k
+    assert torch.equal(hi2["linear.weight"], torch.from_numpy(hi_sd["linear.weight"]))
+    _strict_load(cfg, hi2, lo2)
+
+
+def test_untrusted_pickle_cannot_run_code():
+    """find_class resolves only the allow-listed tensor / container globals: a __reduce__ payload naming any other callable is
+    turned into an inert stand-in instead of being called."""
+    import os
+    marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hcm_pwned_{os.getpid()}")
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    buf = io.BytesIO()
+    torch.save({"high_level_state_dict": {}, "low_level_state_dict": {}, "config": Evil()}, buf)
+    buf.seek(0)
+    hi, lo, conf = checkpoint.load_checkpoint(buf)
+    assert not os.path.exists(marker)
+    assert isinstance(conf, dict) and type(conf).__name__ == "system"

@@ -243,3 +243,69 @@ def test_partial_instruction_refresh(full):
     rec, h2, l2 = eng.act(dict(new), a0[1], a0[2], m, reuse_instruction=True)
     torch.cuda.synchronize()
     assert torch.equal(rec, ref[0]) and torch.equal(h2, ref[1]) and torch.equal(l2, ref[2])
+
+
+def test_instruction_cache_is_dropped_by_other_entry_points():
+    """The cached instruction stream lives in the per-step workspace, which hcm_high_forward / hcm_low_forward (and their sequence
+    forms) re-use: after any of them, act(reuse_instruction=True) must fail with HCM_ERR_STATE instead of reading clobbered memory;
+    likewise after an act() with a different instruction length."""
+    from robo_vln_amd.policy import HCMEngine, Policy
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    n = 3
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=3)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision="bf16", max_instr_len=32)
+    pol = Policy(eng)
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, n, seed=3).items()}
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, n, cfg.hidden, device="cuda"); lh = torch.zeros(R, n, cfg.hidden, device="cuda")
+    m = torch.ones(n, device="cuda")
+    ref = [t.clone() for t in eng.act(dict(obs), hh, lh, m)]
+    ok = eng.act(dict(obs), hh, lh, m, reuse_instruction=True)
+    assert torch.equal(ok[0], ref[0])
+    for clobber in ("low", "high", "len"):
+        eng.act(dict(obs), hh, lh, m)                                   # valid cache again
+        if clobber == "low":
+            pol.low_level((dict(obs), lh, None, m, torch.zeros(n, dtype=torch.int64, device="cuda")))
+        elif clobber == "high":
+            pol.high_level((dict(obs), hh, None, m))
+        else:
+            eng.act(dict(obs, instruction=obs["instruction"][:, :11].contiguous()), hh, lh, m)
+        with pytest.raises(RuntimeError):
+            eng.act(dict(obs), hh, lh, m, reuse_instruction=True)
+        with pytest.raises(RuntimeError):
+            eng.refresh_instruction(obs["instruction"], [0])
+    # and the engine still computes the right thing afterwards
+    again = eng.act(dict(obs), hh, lh, m)
+    assert torch.equal(again[0], ref[0])
+    eng.close()
+
+
+@pytest.mark.parametrize("which", ["hi", "lo"])
+@pytest.mark.parametrize("rnn", ["LSTM", "GRU"])
+def test_sequence_path_on_a_single_model_engine_at_full_workspace(which, rnn):
+    """T*N == max_batch on an engine that holds ONE model: the scan's state and gate buffers must be inside the workspace the
+    dry runs of hcm_finalize sized (an overrun now fails the call; before, it wrote past the allocation) and the result must match
+    the oracle."""
+    from oracle import cases, hcm_oracle
+    from robo_vln_amd.policy import HCMEngine, Seq2Seq_HighLevel_CMA, Seq2Seq_LowLevel
+    T, N = 4, 2
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1, rnn_type=rnn).validate()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=cases.SEED)
+    eng = HCMEngine(cfg, hi_sd if which == "hi" else None, lo_sd if which == "lo" else None, max_batch=T * N, precision="fp32")
+    obs_np = cases.seq_observations(cfg, T, N)
+    m = cases.seq_masks(T, N)
+    R = cfg.num_recurrent_layers
+    h0 = torch.rand(R, N, cfg.hidden, generator=torch.Generator().manual_seed(3)) - 0.5
+    obs = {k: torch.from_numpy(v).cuda() for k, v in obs_np.items()}
+    masks = torch.from_numpy(m).cuda()
+    if which == "hi":
+        got, h = Seq2Seq_HighLevel_CMA(eng)((dict(obs), h0.cuda(), None, masks))
+        ref, rh = hcm_oracle.HighLevelOracle(cfg, hi_sd).forward(obs_np, h0.clone(), m)
+    else:
+        st = torch.from_numpy(cases.fixed_subtask(T * N, 1))
+        got, stop, h = Seq2Seq_LowLevel(eng)((dict(obs), h0.cuda(), None, masks, st.cuda()))
+        ref, rstop, rh = hcm_oracle.LowLevelOracle(cfg, lo_sd).forward(obs_np, h0.clone(), m, st)
+        assert (stop.cpu() - rstop).abs().max().item() <= 1e-3
+    assert (got.cpu() - ref).abs().max().item() <= 1e-3
+    assert (h.cpu() - rh).abs().max().item() <= 1e-3
+    eng.close()

@@ -18,27 +18,36 @@ class _OraclePolicy:
         from oracle import hcm_oracle
         self.o = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
 
-    def act(self, obs, hh, lh, prev, masks):
+        self.engine = self          # rollout(cache_instruction=True) talks to policy.engine
+        self.refreshed = []
+
+    def act(self, obs, hh, lh, prev, masks, reuse_instruction=False):
+        # the oracle recomputes the instruction stream every step, which is what the cached path must be equal to
         return self.o.act(obs, hh, lh, masks.numpy())
 
+    def refresh_instruction(self, instruction, env_indices):
+        self.refreshed.append(list(map(int, env_indices)))
 
-def _setup():
+
+def _setup(G=4, vocab=30522):
     import hcm_pkg
     hcm_pkg.load()
     from robo_vln_amd import synth
     from robo_vln_amd.config import HCMConfig
-    cfg = HCMConfig(rgb_hw=64, depth_hw=64, instr_len=8, bert_layers=1)
+    cfg = HCMConfig(rgb_hw=64, depth_hw=64, instr_len=8, bert_layers=1, bert_vocab=vocab)
     hi_sd, lo_sd = synth.make_weights(cfg, seed=1)
-    G = 4
     allobs = [synth.make_observations(cfg, G, step=t, seed=1) for t in range(3)]
 
     def obs_fn(t, lo, hi):
         return {k: v[lo:hi] for k, v in allobs[t].items()}
 
     def done_fn(t, lo, hi):
+        # uneven pattern: env 2 ends after step 0; with 16 envs also envs 5, 6 (one rank loses both its envs) and 15 after step 1
         d = torch.zeros(G, dtype=torch.bool)
         if t == 0:
             d[2] = True
+        if t == 1 and G >= 16:
+            d[5] = d[6] = d[15] = True
         return d[lo:hi]
     return cfg, hi_sd, lo_sd, obs_fn, done_fn, G
 
@@ -59,11 +68,20 @@ def _worker_body(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from robo_vln_amd.rollout import rollout
-    cfg, hi_sd, lo_sd, obs_fn, done_fn, G = _setup()
-    rec = rollout(_OraclePolicy(cfg, hi_sd, lo_sd), obs_fn, done_fn, G // world, 3, cfg.num_recurrent_layers, cfg.hidden,
-                  "cpu", world, rank)
+    big = world > 2
+    cfg, hi_sd, lo_sd, obs_fn, done_fn, G = _setup(16, 2048) if big else _setup()
+    pol = _OraclePolicy(cfg, hi_sd, lo_sd)
+    rec = rollout(pol, obs_fn, done_fn, G // world, 3, cfg.num_recurrent_layers, cfg.hidden, "cpu", world, rank, cache_instruction=big)
+    if big:
+        # every rank holds ALL ranks' records after the gather (not only rank 0), and refreshed exactly its own finished environments
+        allr = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allr, rec)
+        assert all(torch.equal(a, rec) for a in allr)
+        lo = rank * (G // world)
+        want = [[e - lo for e in ends if lo <= e < lo + G // world] for ends in ([2], [5, 6, 15])]
+        assert pol.refreshed == [w for w in want if w], (rank, pol.refreshed)
     if rank == 0:
         q.put(rec.numpy())
     dist.barrier()
@@ -105,3 +123,26 @@ def test_episode_reset_equals_fresh_state():
         shard_range(10, 4, 0)
     st, lin, ang, stop = records_to_actions(rec[0])
     assert st.shape == (G,) and ang.abs().max() <= 1 and set(stop.tolist()) <= {0.0, 1.0}
+
+
+def test_sharded_rollout_world_size_8():
+    """The driver's 8-GPU layout on CPU: 8 gloo ranks x 2 environments, an uneven `done` pattern (one rank resets both of its
+    environments, five ranks none), the per-rank cached-instruction path of rollout() -- the gathered (3, 16, 7) records must be
+    the single-process rollout's, on every rank."""
+    from robo_vln_amd.rollout import rollout
+    cfg, hi_sd, lo_sd, obs_fn, done_fn, G = _setup(16, 2048)
+    torch.set_num_threads(8)
+    single = rollout(_OraclePolicy(cfg, hi_sd, lo_sd), obs_fn, done_fn, G, 3, cfg.num_recurrent_layers, cfg.hidden, "cpu").numpy()
+    assert single.shape == (3, 16, 7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    sharded = q.get(timeout=600)
+    assert not isinstance(sharded, str), sharded
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(sharded, single, atol=2e-6, rtol=0)
