@@ -270,6 +270,10 @@ int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, cons
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
+/* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,
+ * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify).  The two must agree bit for bit. */
+int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                       int dtype, int M, int N, int K, int act, int out_f32, int impl, void* stream);
 int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype,
                      int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, void* stream);
 int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,

@@ -678,6 +678,14 @@ int hcm_op_linear(const void* x, const void* w, const float* bias, const void* r
     g.B = M; g.Cin = K; g.xC = K; g.M = M; g.N = N; g.K = K; g.Kp = K; g.ldy = N; g.ldr = N; g.act = act; g.out_f32 = out_f32;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const void* residual, void* y, int dtype, int M, int N, int K,
+                       int act, int out_f32, int impl, void* stream) {
+    IGemm g;
+    g.x = x; g.w = w; g.bias = bias; g.res = residual; g.y = y;
+    g.B = M; g.Cin = K; g.xC = K; g.M = M; g.N = N; g.K = K; g.Kp = K; g.ldy = N; g.ldr = N; g.act = act; g.out_f32 = out_f32;
+    g.impl = impl;
+    return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+}
 int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int heads, int Lq, int Lk, int ldq,
                      int ldk, int ldv, int ldo, void* stream) {
     return op_rc(launch_attention(q, k, v, out, op_dt(dtype), B, heads, Lq, Lk, ldq, ldk, ldv, ldo, B, (hipStream_t)stream));

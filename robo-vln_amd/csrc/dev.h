@@ -101,6 +101,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU for the 16-bit paths: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. 4 orders of magnitude below the
+// rounding of the fp16 / bf16 value it is stored as) in 12 instructions -- one v_rcp, one v_exp, FMAs -- instead of the ~50-instruction
+// branchy libm erff: a 256 x 256 output tile is 128 GELUs per thread, which with erff cost as much as the whole K = 768 main loop of
+// BERT's FFN1 (profiles/r2_gemm256.md).  The fp32 path keeps the exact gelu_erf.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_fast(x); }
+template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_erf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace hcm

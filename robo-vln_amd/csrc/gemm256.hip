@@ -1,0 +1,383 @@
+// Large-tile GEMM for the token-major linear layers whose output is wide (BERT's QKV and FFN1, the cross-modal FFN):
+//
+//   Y[m][n] = act( sum_k X[m][k] * W[n][k] + bias[n] )        X [M][ldx], W [N][ldw] (K contiguous), 16-bit storage, fp32 accumulate
+//
+// Why a second GEMM kernel.  igemm_dma_kernel (igemm.hip) works on 128 x 128 tiles: per 64-deep K step a CU moves 32 KB from L2 into
+// LDS and reads 96 KB of fragments back out of LDS for 2 x 256 MFMA-cycles per SIMD -- at the matrix pipe's peak that would be
+// 36 TB/s of L2 traffic and 75 % of the LDS read bandwidth, so the pipe idles (16-23 % MFMA busy, profiles/r2a_pmc_mfma_bench.md).
+// A 256 x 256 tile (8 waves as 2 x 4, 128 x 64 outputs per wave, 128 accumulator registers) halves both ratios, and the K loop is
+// built the way the CDNA4 guide's "8-phase" template is (cdna_hip_programming.md section 5, T1-T5):
+//   * per 64-deep K tile a wave runs FOUR phases -- one 64 x 32 quadrant of its output each: {fragment reads + 2 LDS-DMA pieces}
+//     -> s_barrier -> 16 MFMAs -> s_barrier;
+//   * the two wave groups (rows 0-127 / 128-255 of the tile = the two waves of every SIMD) are staggered by one barrier, so while
+//     one wave of a SIMD issues its 16 MFMAs the other one reads its next fragments and issues its DMA pieces;
+//   * both operand tiles travel L2 -> LDS by `buffer_load_dwordx4 ... lds` into two 64 KB K-tile buffers, one half-tile (16 KB =
+//     2 pieces per wave) per phase, a full K tile ahead; waits are counted (`vmcnt(4)` / `vmcnt(2)`, never 0 in the steady state), so
+//     DMA pieces stay in flight across the barriers;
+//   * LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7) on the SOURCE side of the DMA and on the fragment
+//     reads (rule 21 / T2), exactly as in igemm_dma_kernel.
+// The MFMA instruction, the k order inside a K tile and the order of the K tiles are those of igemm_dma_kernel, and so are the epilogue's
+// f32 operations (acc + bias, erf-GELU / ReLU, one rounding): the results are BIT-IDENTICAL to that kernel's (tests/test_ops_gpu.py).
+//
+// Epilogue: the accumulators (4 consecutive channels of one token per lane) go through a 16-bit LDS image of the whole 256 x 256 output
+// tile (rows padded to 528 B: conflict-free 8-byte writes), from which every thread stores 16-byte pieces of whole 512-byte rows.
+//
+// Reference ops replaced: nn.Linear of transformers' BertSelfAttention (query|key|value, concatenated) / BertIntermediate (+ GELU), as
+// called at seq2seq_highlevel_cma.py:192-195, and PositionWiseFeedForward.fc1 (transformer.py:25-43).
+#include <cstdlib>
+#include <type_traits>
+#include "kernels.h"
+#include "dev.h"
+
+namespace hcm {
+
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef int g_v4i __attribute__((ext_vector_type(4)));
+
+struct G256Dev {
+    const char* x; const char* w; const float* bias; char* y;
+    int M, N, K, ldx, ldw, ldy, act;
+    unsigned x_bytes, w_bytes;
+    int tilesM, tilesN, gm, gn;      // XCD grid: the 8 XCDs own gm x gn rectangles of the tile grid (each has a private L2)
+};
+
+template <typename T> struct GMma;
+template <> struct GMma<bf16> {
+    static __device__ __forceinline__ void run(g_f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct GMma<f16> {
+    static __device__ __forceinline__ void run(g_f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void g_dma16(unsigned lds_addr, unsigned voff, g_v4i rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void g_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ g_v4i g_make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    g_v4i r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+#define G_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+constexpr int G_BM = 256, G_BN = 256;
+constexpr unsigned G_BUF = 65536;          // one K tile: X 256 x 128 B, then W 256 x 128 B
+constexpr unsigned G_WOFF = 32768;
+constexpr int G_IMG_LD = 528;              // bytes per row of the epilogue's 16-bit tile image (512 + 16 pad)
+constexpr size_t G_LDS = (size_t)G_BM * G_IMG_LD;      // 135168 >= 2 * G_BUF
+
+// one quadrant (32 channels x 64 tokens) x one 64-deep K tile: 16 MFMAs, k order = igemm_dma_kernel's (ks outer)
+template <typename T, int NQ, int MQ>
+__device__ __forceinline__ void g_quad(g_f32x4 (&acc)[4][8], const uint4 (&wf)[2][2], const uint4 (&xf)[2][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) GMma<T>::run(acc[NQ * 2 + i][MQ * 4 + j], wf[ks][i], xf[ks][j]);
+}
+
+// SCHED: how the 8 DMA pieces a wave requests per K tile are spread over the four phases (0: 2/2/2/2; 1: 0/3/1/4 -- the pieces go where
+// the phase has few fragment reads: 12/4/8/0).  DBG (timing experiments only, results are then wrong): 1 no DMA in the loop, 2 no fragment
+// reads after the first tile, 4 no MFMAs.
+template <typename T, int SCHED = 0, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- tile of this block: XCD (blockIdx % 8) owns a rectangle of the tile grid
+    int tile_m, tile_n;
+    {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
+        const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
+        const int nn = n_hi - n_lo;
+        if (nn <= 0 || local >= (m_hi - m_lo) * nn) return;
+        tile_m = m_lo + local / nn;
+        tile_n = n_lo + local % nn;
+    }
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // wave (wr, wc): tokens [wr*128, +128) x channels [wc*64, +64)
+    const int rin = lane >> 3;                        // row inside an 8-row DMA piece
+    const int csrc = (lane & 7) ^ rin;                // source chunk this lane fetches (swizzle on the source side)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
+    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
+
+    // DMA pieces of this wave: per half-tile h (X-h: token rows {h*64..+64} of both row groups; W-h: channel rows {h*32..+32} of all
+    // four column groups) pieces q = 2*wave + i, i = 0, 1.  Out-of-range rows present an offset beyond num_records: hardware zero fill.
+    unsigned xsrc[2][2], wsrc[2][2], xdst[2][2], wdst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = 2 * wave + i;
+            const int xrow = (q >> 3) * 128 + h * 64 + (q & 7) * 8;
+            const int wrow = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
+            const int m = m0 + xrow + rin, n = n0 + wrow + rin;
+            xsrc[h][i] = m < p.M ? (unsigned)(m * p.ldx + csrc * 8) * 2u : 0x80000000u;
+            wsrc[h][i] = n < p.N ? (unsigned)(n * p.ldw + csrc * 8) * 2u : 0x80000000u;
+            xdst[h][i] = lds_base + (unsigned)xrow * 128u;
+            wdst[h][i] = lds_base + G_WOFF + (unsigned)wrow * 128u;
+        }
+    auto dma_x = [&](int h, unsigned buf, unsigned kbyte) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g_dma16(xdst[h][i] + buf, xsrc[h][i] + kbyte, rx);
+    };
+    auto dma_w = [&](int h, unsigned buf, unsigned kbyte) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g_dma16(wdst[h][i] + buf, wsrc[h][i] + kbyte, rw);
+    };
+    // piece q of a K tile in request order: X-h0[0,1], W-h0[0,1], W-h1[0,1], X-h1[0,1] (the order the next tile's phases need them)
+    auto piece = [&](int q, unsigned buf, unsigned kbyte) {
+        const int i = q & 1;
+        if (q < 2) g_dma16(xdst[0][i] + buf, xsrc[0][i] + kbyte, rx);
+        else if (q < 4) g_dma16(wdst[0][i] + buf, wsrc[0][i] + kbyte, rw);
+        else if (q < 6) g_dma16(wdst[1][i] + buf, wsrc[1][i] + kbyte, rw);
+        else g_dma16(xdst[1][i] + buf, xsrc[1][i] + kbyte, rx);
+    };
+
+    g_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    // prologue: the whole first K tile
+    dma_x(0, 0, 0); dma_w(0, 0, 0); dma_w(1, 0, 0); dma_x(1, 0, 0);
+    g_wait_vmcnt<0>();
+    G_BAR();
+    if (wr == 1) G_BAR();                              // stagger the second row group by one barrier interval
+
+    const int fr = lane & 15, fg = lane >> 4;
+    uint4 xf[2][4], wf0[2][2], wf1[2][2];
+    auto rd_x = [&](int mq, unsigned buf) {
+        const char* sx = smem + buf;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wr * 128 + mq * 64 + j * 16 + fr;
+                xf[ks][j] = *reinterpret_cast<const uint4*>(sx + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            }
+    };
+    auto rd_w = [&](uint4 (&wf)[2][2], int nq, unsigned buf) {
+        const char* sw = smem + buf + G_WOFF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wc * 64 + nq * 32 + i * 16 + fr;
+                wf[ks][i] = *reinterpret_cast<const uint4*>(sw + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            }
+    };
+
+    // K tile t lives in buffer t & 1; tile t+1 is requested into the other buffer while t is consumed (that buffer's last reader,
+    // the second row group's phase 3 of tile t-1, finished two barrier intervals before the first request)
+    // SCHED 2: the two DMA pieces of a phase are issued from INSIDE its MFMA cluster (after the 4th and the 12th MFMA), where an LDS-DMA
+    // instruction costs ~60 cycles of issue instead of 100-185 in a phase that is also reading fragments (MI355X_MICROARCH.md, cycle table)
+    auto mma_phase_dma = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2], auto LIVE, int q0, unsigned buf, unsigned kbyte) {
+        constexpr int nq = decltype(NQ)::value, mq = decltype(MQ)::value;
+        constexpr bool live = decltype(LIVE)::value;
+        G_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        int cnt = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    GMma<T>::run(acc[nq * 2 + i][mq * 4 + j], wf[ks][i], xf[ks][j]);
+                    ++cnt;
+                    if (live && (cnt == 4 || cnt == 12)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(q0 + (cnt == 12), buf, kbyte);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        __builtin_amdgcn_s_setprio(0);
+        G_BAR();
+    };
+    auto mma_phase = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2]) {
+        G_BAR();
+        if constexpr (!(DBG & 4)) {
+            __builtin_amdgcn_s_setprio(1);
+            g_quad<T, decltype(NQ)::value, decltype(MQ)::value>(acc, wf, xf);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        G_BAR();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto tile_body = [&](int t, auto LIVE) {
+        constexpr bool live = decltype(LIVE)::value && !(DBG & 1);
+        const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
+        const unsigned kb = (unsigned)(t + 1) * 128u;
+        const bool rd = !(DBG & 2) || t == 0;
+        if constexpr (SCHED == 0) {
+            // ---- phase 1: channels 0-31 x tokens 0-63 of the wave's block
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); }
+            mma_phase(I0{}, I0{}, wf0);
+            // ---- phase 2: channels 32-63 x tokens 0-63
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<4>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of THIS tile has landed
+            mma_phase(I1{}, I0{}, wf1);
+            // ---- phase 3: channels 32-63 x tokens 64-127
+            if (rd) rd_x(1, cur);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); }
+            mma_phase(I1{}, I1{}, wf1);
+            // ---- phase 4: channels 0-31 x tokens 64-127 (both fragment sets are in registers)
+            if (live) { piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<2>(); }     // X-h0, W-h0, W-h1 of the next tile have landed
+            mma_phase(I0{}, I1{}, wf0);
+        } else if constexpr (SCHED == 2) {
+            using LV = std::integral_constant<bool, live>;
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (its X-h1 may be in flight)
+            mma_phase_dma(I0{}, I0{}, wf0, LV{}, 0, nxt, kb);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) g_wait_vmcnt<2>(); else g_wait_vmcnt<0>();                          // X-h1 of this tile
+            mma_phase_dma(I1{}, I0{}, wf1, LV{}, 2, nxt, kb);
+            if (rd) rd_x(1, cur);
+            mma_phase_dma(I1{}, I1{}, wf1, LV{}, 4, nxt, kb);
+            if (live) g_wait_vmcnt<2>();                                                  // X-h0, W-h0 of the next tile
+            mma_phase_dma(I0{}, I1{}, wf0, LV{}, 6, nxt, kb);
+        } else {
+            // pieces where the fragment reads are few: 0 / 3 / 1 / 4
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (X-h1 may be in flight)
+            mma_phase(I0{}, I0{}, wf0);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); g_wait_vmcnt<3>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of this tile
+            mma_phase(I1{}, I0{}, wf1);
+            if (rd) rd_x(1, cur);
+            if (live) piece(3, nxt, kb);
+            mma_phase(I1{}, I1{}, wf1);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<4>(); }   // X-h0, W-h0 of the next tile
+            mma_phase(I0{}, I1{}, wf0);
+        }
+    };
+    int t = 0;
+    for (; t + 1 < nk; ++t) tile_body(t, std::true_type{});
+    tile_body(t, std::false_type{});
+    if (wr == 0) G_BAR();                              // re-align the two row groups: every fragment read is done
+
+    // ---- epilogue: acc + bias, activation, one rounding -> 16-bit tile image in LDS -> 16-byte stores of whole rows
+    {
+        float4 b4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wc * 64 + i * 16 + fg * 4;
+            b4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+                }
+                T o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                const int r = wr * 128 + j * 16 + fr;
+                const int cb = (wc * 64 + i * 16 + fg * 4) * 2;
+                *reinterpret_cast<uint2*>(smem + r * G_IMG_LD + cb) = *reinterpret_cast<const uint2*>(o4);
+            }
+    }
+    __syncthreads();
+    {
+        const int chunk = tid & 31;                    // 16-byte piece of a 512-byte row
+        const int n = n0 + chunk * 8;
+        if (n < p.N) {                                 // N % 8 == 0 (launcher)
+#pragma unroll 4
+            for (int pass = 0; pass < 16; ++pass) {
+                const int r = pass * 16 + (tid >> 5);
+                const int m = m0 + r;
+                if (m < p.M)
+                    *reinterpret_cast<uint4*>(p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const uint4*>(smem + r * G_IMG_LD + chunk * 16);
+            }
+        }
+    }
+}
+
+bool gemm256_applicable(const IGemm& g, int dt) {
+    if (dt != DT_BF16 && dt != DT_F16) return false;
+    if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
+    if (g.res || g.out_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0) return false;
+    const int Kp = g.Kp ? g.Kp : g.K, ldx = g.xC ? g.xC : g.Cin, ldy = g.ldy ? g.ldy : g.N;
+    if (g.K % 64 || Kp % 8 || ldx % 8 || ldy % 8 || g.N % 8) return false;
+    if ((size_t)g.M * ldx * 2 >= 0x7FFFFFF0ull || (size_t)g.N * Kp * 2 >= 0x7FFFFFF0ull) return false;   // offsets + the out-of-range sentinel
+    // worth it when the tile grid fills a good part of the chip with whole tiles: wide outputs over many rows
+    const long tiles = (long)((g.M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
+    return g.N >= 1024 && g.M >= 2048 && tiles >= 96 && g.K >= 256;
+}
+
+hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
+    if (!gemm256_applicable(g, dt)) return hipErrorInvalidValue;
+    G256Dev d;
+    d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.y = (char*)g.y;
+    d.M = g.M; d.N = g.N; d.K = g.K; d.ldx = g.xC ? g.xC : g.Cin; d.ldw = g.Kp ? g.Kp : g.K; d.ldy = g.ldy ? g.ldy : g.N; d.act = g.act;
+    d.x_bytes = (unsigned)(((size_t)(g.M - 1) * d.ldx + g.K) * 2);
+    d.w_bytes = (unsigned)((size_t)g.N * d.ldw * 2);
+    d.tilesM = (g.M + G_BM - 1) / G_BM;
+    d.tilesN = (g.N + G_BN - 1) / G_BN;
+    // XCD grid: the factorisation of 8 with the fewest workgroups on the busiest XCD, then the smallest per-XCD operand footprint
+    int best_cnt = 1 << 30, best_fp = 1 << 30;
+    d.gm = 8; d.gn = 1;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+        const int gn = 8 / gm;
+        int cnt = 0, fp = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int xm = x / gn, xn = x % gn;
+            const int nm = (xm + 1) * d.tilesM / gm - xm * d.tilesM / gm, nn = (xn + 1) * d.tilesN / gn - xn * d.tilesN / gn;
+            if (nm * nn > cnt) cnt = nm * nn;
+            if (nm + nn > fp) fp = nm + nn;
+        }
+        if (cnt < best_cnt || (cnt == best_cnt && fp < best_fp)) { best_cnt = cnt; best_fp = fp; d.gm = gm; d.gn = gn; }
+    }
+    // g.impl >> 4 selects experiment builds (f16 only): 1 = SCHED 1; 2/3/4 = SCHED 0 with DBG 1/2/4; 5/6/7 = SCHED 1 with DBG 1/2/4
+    const int var = g.impl >> 4;
+    const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256_kernel<bf16>) : reinterpret_cast<const void*>(gemm256_kernel<f16>);
+    if (dt == DT_F16 && var) {
+        switch (var) {
+            case 1: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 1, 0>); break;
+            case 2: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 1>); break;
+            case 3: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 2>); break;
+            case 4: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 4>); break;
+            case 5: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 5>); break;
+            case 6: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 6>); break;
+            case 7: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 7>); break;
+            case 8: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 3>); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
+    {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    void* args[] = {&d};
+    return hipLaunchKernel(fn, dim3(8 * best_cnt), dim3(512), args, G_LDS, s);
+}
+
+}  // namespace hcm

@@ -292,7 +292,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
         }
         if (p.out_f32 || sizeof(T) == 4) {
             float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
@@ -525,7 +525,7 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
         }
         if (p.out_f32 || sizeof(T) == 4) {
             float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
@@ -2056,6 +2056,11 @@ static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best
 }
 
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
+    if ((g.impl & 15) == 2) return launch_gemm256(g, dt, s);
+    if (g.impl == 0) {
+        static const bool no256 = getenv("HCM_NO_GEMM256") != nullptr;
+        if (!no256 && gemm256_applicable(g, dt)) return launch_gemm256(g, dt, s);
+    }
     IGemmDev d;
     d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.res = (const char*)g.res; d.y = (char*)g.y;
     d.B = g.B; d.H = g.H; d.W = g.W; d.Cin = g.Cin; d.xC = g.xC ? g.xC : g.Cin;

@@ -46,8 +46,12 @@ struct IGemm {
     // (sample, 64-row pixel block, group) -> cs_part[((b * cs_hw / 64 + block) * cs_G + group) * 2]; cs_hw % 64 == 0, 32 % cs_cg == 0.
     // launch_groupnorm_apply then normalises without a statistics pass over the map.
     float* cs_part = nullptr; int cs_cg = 0, cs_hw = 0, cs_G = 0;
+    int impl = 0;                // 0: launch_igemm chooses; 1: igemm_dma_kernel / igemm_kernel only; 2: the 256 x 256-tile kernel of gemm256.hip only
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
+// 256 x 256-tile, 8-phase GEMM for wide token-major linear layers (gemm256.hip); bit-identical to launch_igemm's kernels
+bool gemm256_applicable(const IGemm& g, int dt);
+hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s);
 // Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,
 // C1 = 64 or 128 (igemm.hip: bneck23_kernel).  Weights as for launch_igemm: w2 [C1][9*C1] (k = (kh*3+kw)*C1 + ci), w3 [4*C1][C1].
 struct Bneck23 {
