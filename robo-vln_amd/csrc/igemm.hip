@@ -2055,7 +2055,52 @@ static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best
     return rc;
 }
 
+#ifdef HCM_DEV_KNOBS
+// make DEV=1 builds: HCM_IGEMM_TIME=1 brackets every launch with events (synchronising: stand-alone durations) and prints a per-shape
+// table at exit -- how profiles/r2_igemm_shapes.md was made
+static hipError_t launch_igemm_impl(const IGemm& g, int dt, hipStream_t s);
+namespace {
+struct ShapeTime { double us = 0; long n = 0; double flop = 0; };
+std::unordered_map<std::string, ShapeTime> g_shape_time;
+struct ShapeTimePrinter {
+    ~ShapeTimePrinter() {
+        if (g_shape_time.empty()) return;
+        std::vector<std::pair<std::string, ShapeTime>> v(g_shape_time.begin(), g_shape_time.end());
+        std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.second.us > b.second.us; });
+        double tot = 0;
+        for (auto& kv : v) tot += kv.second.us;
+        fprintf(stderr, "| shape | launches | total us | avg us | TFLOP/s |\n|---|---|---|---|---|\n");
+        for (auto& kv : v)
+            fprintf(stderr, "| %s | %ld | %.0f | %.1f | %.0f |\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.us / kv.second.n,
+                    kv.second.flop / kv.second.us / 1e6);
+        fprintf(stderr, "total %.0f us\n", tot);
+    }
+} g_shape_time_printer;
+}
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
+    static const bool timing = getenv("HCM_IGEMM_TIME") != nullptr;
+    if (!timing) return launch_igemm_impl(g, dt, s);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, s);
+    hipError_t rc = launch_igemm_impl(g, dt, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    char key[160];
+    snprintf(key, sizeof key, "dt%d M=%d N=%d K=%d g=%d %dx%d s%d%s%s%s", dt, g.M, g.N, g.K, g.groups, g.KH, g.KW, g.stride, g.res ? " res" : "",
+             g.gn_gamma ? " gn" : "", g.cs_part ? " cs" : "");
+    ShapeTime& t = g_shape_time[key];
+    t.us += ms * 1e3; t.n += 1; t.flop += 2.0 * g.M * g.N * g.K * (g.groups > 1 ? g.groups : 1);
+    return rc;
+}
+static hipError_t launch_igemm_impl(const IGemm& g, int dt, hipStream_t s) {
+#else
+hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
+#endif
     if ((g.impl & 15) == 2) return launch_gemm256(g, dt, s);
     if (g.impl == 0) {
         static const bool no256 = getenv("HCM_NO_GEMM256") != nullptr;
