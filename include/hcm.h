@@ -50,7 +50,11 @@ enum hcm_query_what {
     HCM_WEIGHT_BYTES = 5,
     HCM_MAX_BATCH = 6,
     HCM_GRAPH_LAUNCHES = 7,        /* hcm_act calls served by a captured hipGraph replay */
-    HCM_EAGER_LAUNCHES = 8
+    HCM_EAGER_LAUNCHES = 8,
+    HCM_FP16_FALLBACK = 9,         /* bit 0: BERT, bit 1: the depth trunks were re-built on bf16 tiles after a range calibration */
+    HCM_CALIB_MAX_BERT = 10,       /* max |x| (rounded down) over the GEMM outputs of BERT / the depth trunks in the last calibration forward */
+    HCM_CALIB_MAX_DEPTH = 11,
+    HCM_CALIB_NONFINITE = 12       /* non-finite values seen in the last calibration forward */
 };
 
 /* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,
@@ -77,7 +81,9 @@ typedef struct hcm_config {
     int32_t ablate_depth;               /* working flags of both models: the encoder output is multiplied by 0 */
     int32_t ablate_rgb;                 /* (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135, config/default.py:92-93) */
     int32_t reserved[8];                /* [0..3]: storage-type override (hcm_dtype + 1, 0 = default) for the depth trunk /
-                                           BERT / cross-modal block / RGB trunk; see DESIGN.md section 5 */
+                                           BERT / cross-modal block / RGB trunk; see DESIGN.md section 5.
+                                           [4]: keep the f32 host copies of the weights after hcm_finalize so that hcm_calibrate can
+                                           re-build a sub-network (release them with hcm_release_host_weights) */
 } hcm_config;
 
 /* Replaces model construction, hierarchical_trainer.py:315-328 (Seq2Seq_HighLevel_CMA.__init__
@@ -165,6 +171,14 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
  * leaving the other environments' cached tensors untouched.  Needs a previous hcm_act / hcm_act_ex step at this batch size. */
 int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
                             const int32_t* env_indices, int n, void* stream);
+
+/* fp16 range safety (no reference counterpart: the reference is fp32).  In the 16-bit mode BERT and the GroupNorm depth trunks store
+ * activations as fp16, whose range ends at 65504.  hcm_finalize runs one forward on a synthetic batch with range hooks on every GEMM output
+ * of those sub-networks; hcm_calibrate does the same on the caller's own observations (device pointers as for hcm_act; zero recurrent
+ * state; synchronises the stream).  A sub-network whose max |x| exceeds 2^14 or that produced a non-finite value is re-built on bf16 tiles
+ * (needs the host copies of the weights: hcm_config.reserved[4], else HCM_ERR_STATE) and hcm_query(HCM_FP16_FALLBACK) reports it. */
+int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L, void* stream);
+int hcm_release_host_weights(hcm_handle h);
 
 int hcm_query(hcm_handle h, int what, int64_t* out);
 

@@ -12,7 +12,8 @@ HCM_HIGH, HCM_LOW, HCM_CMA = 0, 1, 2
 HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
- HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES) = range(9)
+ HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES, HCM_FP16_FALLBACK, HCM_CALIB_MAX_BERT, HCM_CALIB_MAX_DEPTH,
+ HCM_CALIB_NONFINITE) = range(13)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 HCM_ACT_REUSE_INSTRUCTION = 1
 
@@ -57,6 +58,8 @@ EXPORTS = {
     "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "hcm_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hcm_release_host_weights": (C.c_int, [C.c_void_p]),
     "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "hcm_last_error": (C.c_char_p, [C.c_void_p]),
     "hcm_destroy": (None, [C.c_void_p]),

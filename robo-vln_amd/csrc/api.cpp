@@ -32,6 +32,12 @@ static int fail(hcm_ctx* h, int code, const std::string& msg) {
 
 #define REQUIRE(cond, code, msg) do { if (!(cond)) return fail(h, code, msg); } while (0)
 
+static int check_fwd(hcm_ctx* h, int B);
+static int check_len(hcm_ctx* h, int L);
+static void drop_instruction_cache(hcm_ctx* h);
+static bool rgb_dt_ok(int d);
+static bool ids_dt_ok(int d);
+
 // hipGraph cache shared by the fused entry points: `key` = every argument that the enqueued work depends on (batch, dtypes,
 // all pointers, the stream); `run` enqueues the work on h->stream.  A key is run eagerly the first time it is seen (that also
 // performs the one-time kernel attribute setup) and captured -- forked side streams included -- the second time; later
@@ -252,6 +258,107 @@ static void dry_run(hcm_ctx* h, int B) {
     }
 }
 
+// ---- fp16 range calibration: BERT and the GroupNorm depth trunks store activations as fp16 (3 more mantissa
+// bits than bf16 at the same MFMA rate, needed for the 1e-2 record tolerance), whose range ends at 65504.  One forward with the range
+// hooks on measures max |x| over every GEMM output of those sub-networks; a sub-network whose maximum exceeds 2^14 (a factor 4 of
+// head-room) or that produced a non-finite value is re-built on bf16 tiles (same range as fp32) and the fact is reported through
+// hcm_query(HCM_FP16_FALLBACK).
+static void free_device_weights(hcm_ctx* h) {
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    h->dev_allocs.clear();
+    h->weight_bytes = 0;
+    h->hi = hcm::HighW();
+    h->lo = hcm::LowW();
+}
+static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, int L, hipStream_t stream) {
+    const hcm_config& c = h->cfg;
+    if (h->kind != 0 || (h->dt_bert != DT_F16 && h->dt_depth != DT_F16)) return HCM_OK;          // nothing stored as fp16
+    const size_t R = c.rnn_type == HCM_LSTM ? 2 : 1;
+    const size_t n_hid = R * (size_t)B * c.hidden * 4;
+    char* tmp = nullptr;
+    const size_t total = 4 * n_hid + (size_t)B * 64 * 4 + 4096;
+    if (hipMalloc((void**)&tmp, total) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc of calibration scratch failed");
+    (void)hipMemsetAsync(tmp, 0, total, stream);
+    float* hh = (float*)tmp; float* lh = (float*)(tmp + n_hid); float* hh2 = (float*)(tmp + 2 * n_hid); float* lh2 = (float*)(tmp + 3 * n_hid);
+    float* mask = (float*)(tmp + 4 * n_hid); float* rec = mask + B; int64_t* st = (int64_t*)(rec + 16 * (size_t)B);
+    (void)hipMemsetAsync(h->calib_buf, 0, 16, stream);
+    const bool conc = h->concurrent;
+    h->concurrent = false;                       // one stream: the hooks are plain launches in program order
+    h->stream = stream;
+    h->cur_L = L;
+    h->cur_lens = nullptr;
+    h->calib = true;
+    drop_instruction_cache(h);
+    std::string err;
+    try {
+        if (c.build_high && c.build_low)
+            run_step(h, true, true, rgb, rgb_dt, depth, ids, ids_dt, B, hh, lh, mask, nullptr, rec, 7, rec + 4, 7, rec + 6, 7, hh2, lh2);
+        else if (c.build_high)
+            run_step(h, true, false, rgb, rgb_dt, depth, ids, ids_dt, B, hh, nullptr, mask, nullptr, rec, c.num_actions, nullptr, 0, nullptr, 0, hh2, nullptr);
+        else
+            run_step(h, false, true, rgb, rgb_dt, depth, nullptr, DT_I64, B, nullptr, lh, mask, st, nullptr, 0, rec, c.lo_actions, rec + 8, 1, nullptr, lh2);
+    } catch (const std::exception& e) { err = e.what(); }
+    h->calib = false;
+    h->concurrent = conc;
+    unsigned out[4] = {0, 0, 0, 0};
+    const hipError_t se = hipStreamSynchronize(stream);
+    if (se == hipSuccess) (void)hipMemcpy(out, h->calib_buf, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (!err.empty()) return fail(h, HCM_ERR_HIP, "calibration forward failed: " + err);
+    if (se != hipSuccess) return fail(h, HCM_ERR_HIP, "calibration forward failed to complete");
+    int rebuild = 0;
+    for (int i = 0; i < 2; ++i) {
+        std::memcpy(&h->calib_max[i], &out[2 * i], 4);
+        h->calib_bad[i] = out[2 * i + 1];
+        const bool is_f16 = (i == 0 ? h->dt_bert : h->dt_depth) == DT_F16;
+        if (is_f16 && (h->calib_bad[i] || h->calib_max[i] > 16384.0f)) rebuild |= 1 << i;
+    }
+    if (!rebuild) return HCM_OK;
+    if (!h->host_weights)
+        return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
+                    " depth) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
+    if (rebuild & 1) h->dt_bert = DT_BF16;
+    if (rebuild & 2) h->dt_depth = DT_BF16;
+    h->fp16_fallback |= rebuild;
+    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);      // captured with the old weight pointers
+    h->graphs.clear();
+    h->seen_keys.clear();
+    try {
+        free_device_weights(h);
+        if (c.build_high) prepare_high(h);
+        if (c.build_low) prepare_low(h);
+    } catch (const std::exception& e) {
+        return fail(h, HCM_ERR_HIP, std::string("re-building a sub-network on bf16 tiles failed: ") + e.what());
+    }
+    return HCM_OK;
+}
+// deterministic synthetic calibration batch for hcm_finalize: frames of mid-range noise, ids spread over the vocabulary
+static int calibrate_synthetic(hcm_ctx* h) {
+    const hcm_config& c = h->cfg;
+    const int B = c.max_batch < 2 ? 1 : 2, L = c.instr_len < 32 ? c.instr_len : 32;
+    const size_t n_rgb = (size_t)B * c.rgb_h * c.rgb_w * 3, n_dep = (size_t)B * c.depth_h * c.depth_w, n_ids = (size_t)B * L;
+    std::vector<unsigned char> rgb(n_rgb);
+    std::vector<float> dep(n_dep);
+    std::vector<int64_t> ids(n_ids);
+    uint32_t s = 0x9E3779B9u;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    for (auto& v : rgb) v = (unsigned char)(next() >> 24);
+    for (auto& v : dep) v = (float)(next() >> 8) * (1.0f / 16777216.0f);
+    for (auto& v : ids) v = 1000 + (int64_t)(next() % (uint32_t)(c.bert_vocab > 1001 ? c.bert_vocab - 1000 : 1));
+    for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 101; ids[(size_t)b * L + L - 1] = 102; }
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, n_rgb + n_dep * 4 + n_ids * 8 + 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc of the calibration batch failed");
+    char* d_dep = d + ((n_rgb + 15) & ~(size_t)15);
+    char* d_ids = d_dep + n_dep * 4;
+    (void)hipMemcpy(d, rgb.data(), n_rgb, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_dep, dep.data(), n_dep * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_ids, ids.data(), n_ids * 8, hipMemcpyHostToDevice);
+    const int rc = calibrate_run(h, d, HCM_U8, (const float*)d_dep, d_ids, HCM_I64, B, L, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d);
+    return rc;
+}
+
 int hcm_finalize(hcm_handle h) {
     REQUIRE(h, HCM_ERR_ARG, "null handle");
     REQUIRE(!h->finalized, HCM_ERR_STATE, "hcm_finalize called twice");
@@ -279,6 +386,12 @@ int hcm_finalize(hcm_handle h) {
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
+        if (hipMalloc((void**)&h->calib_buf, 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+        // fp16 range check on a synthetic batch; a real batch can follow through hcm_calibrate (reserved[4]: keep the host weights for it)
+        if (h->kind == 0 && !getenv("HCM_NO_CALIB")) {
+            const int rc = calibrate_synthetic(h);
+            if (rc != HCM_OK) return rc;
+        }
         // one tuning step at max_batch on scratch inputs: every conv / linear shape of the plan picks its fastest
         // tile + staging variant (igemm.hip); steady-state calls then never synchronise the host
         // (opt-in: HCM_TUNE=1.  Isolated per-kernel timings rank variants differently from the concurrent multi-stream
@@ -326,10 +439,31 @@ int hcm_finalize(hcm_handle h) {
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, std::string("hcm_finalize: ") + e.what());
     }
-    // host copies are no longer needed
+    // host copies are no longer needed -- unless the caller wants to calibrate on its own observations (hcm_config.reserved[4])
+    if (!h->cfg.reserved[4]) {
+        for (int m = 0; m < 3; ++m)
+            for (auto& kv : h->sd[m]) { std::vector<float>().swap(kv.second.f); }
+        h->host_weights = false;
+    }
+    h->finalized = true;
+    return HCM_OK;
+}
+
+int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L, void* stream) {
+    int rc = check_fwd(h, B);
+    if (rc) return rc;
+    REQUIRE(h->kind == 0, HCM_ERR_STATE, "hcm_calibrate: not an HCM handle");
+    REQUIRE(rgb && depth && (ids || !h->cfg.build_high), HCM_ERR_ARG, "null pointer");
+    REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
+    if (h->cfg.build_high && (rc = check_len(h, L))) return rc;
+    return calibrate_run(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h->cfg.build_high ? L : 1, (hipStream_t)stream);
+}
+
+int hcm_release_host_weights(hcm_handle h) {
+    REQUIRE(h, HCM_ERR_ARG, "null handle");
     for (int m = 0; m < 3; ++m)
         for (auto& kv : h->sd[m]) { std::vector<float>().swap(kv.second.f); }
-    h->finalized = true;
+    h->host_weights = false;
     return HCM_OK;
 }
 
@@ -514,6 +648,10 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_MAX_BATCH: *out = h->cfg.max_batch; break;
         case HCM_GRAPH_LAUNCHES: *out = h->graph_launches; break;
         case HCM_EAGER_LAUNCHES: *out = h->eager_launches; break;
+        case HCM_FP16_FALLBACK: *out = h->fp16_fallback; break;
+        case HCM_CALIB_MAX_BERT: *out = (int64_t)h->calib_max[0]; break;
+        case HCM_CALIB_MAX_DEPTH: *out = (int64_t)h->calib_max[1]; break;
+        case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1]; break;
         default: return fail(h, HCM_ERR_ARG, "hcm_query: unknown selector");
     }
     return HCM_OK;
@@ -526,6 +664,7 @@ void hcm_destroy(hcm_handle h) {
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
+    if (h->calib_buf) (void)hipFree(h->calib_buf);
     if (h->len_buf) (void)hipFree(h->len_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);

@@ -783,6 +783,31 @@ hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ range check (fp16 calibration)
+// slot[0] = max |x| as float bits (non-negative floats order like unsigned ints), slot[1] = count of non-finite elements
+template <typename T>
+__global__ void absmax_kernel(const T* __restrict__ x, int rows, int cols, int ld, unsigned* __restrict__ slot) {
+    const size_t total = (size_t)rows * cols;
+    float mx = 0.f;
+    unsigned bad = 0;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const float v = Tr<T>::ld(x + (e / cols) * (size_t)ld + e % cols);
+        if (!(fabsf(v) <= 3.0e38f)) ++bad; else mx = fmaxf(mx, fabsf(v));
+    }
+    mx = wave_max(mx);
+    bad += __shfl_xor(bad, 32, 64); bad += __shfl_xor(bad, 16, 64); bad += __shfl_xor(bad, 8, 64);
+    bad += __shfl_xor(bad, 4, 64); bad += __shfl_xor(bad, 2, 64); bad += __shfl_xor(bad, 1, 64);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(slot, __float_as_uint(mx));
+        if (bad) atomicAdd(slot + 1, bad);
+    }
+}
+hipError_t launch_absmax(const void* x, int dt, int rows, int cols, int ld, unsigned* slot, hipStream_t s) {
+    const size_t total = (size_t)rows * cols;
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(absmax_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, rows, cols, ld, slot));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ split-K reduction
 // y[m][n] = act(sum_s part[s][m][n] + bias[n]) in a fixed order (deterministic); part is f32 [S][M][N], y is T or f32 at ldy.
 template <typename T>

@@ -33,6 +33,12 @@ struct Fwd {
             throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
         }
     }
+    // fp16 calibration: which range slot the launches being enqueued belong to (-1: none)
+    int calib_slot = -1;
+    void calib_check(const void* y, int ydt, int rows, int cols, int ld) {
+        if (dry || !ctx->calib || calib_slot < 0 || ydt != DT_F16) return;
+        ck(launch_absmax(y, ydt, rows, cols, ld, ctx->calib_buf + 2 * calib_slot, s), "calibration range check");
+    }
     void* alloc_t(size_t elems) { return ar.alloc(elems * esz); }
     float* alloc_f(size_t elems) { return (float*)ar.alloc(elems * 4); }
 
@@ -95,6 +101,7 @@ struct Fwd {
             g.groups = w.groups; g.g_x = w.Cin; g.g_w = (long long)w.Cout * w.Kp; g.g_b = w.Cout; g.g_y = w.Cout;
         }
         ck(launch_igemm(g, w.dt, s), "conv igemm");
+        calib_check(out, w.dt, g.M, w.groups * w.Cout, w.groups * w.Cout);
     }
     // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
     // Skinny long-K layers (the M = batch projections behind the encoders, SimpleCNN's 25088-wide FC) would run on a few
@@ -123,9 +130,11 @@ struct Fwd {
             g.groups = S; g.g_x = Ks; g.g_w = Ks; g.g_b = 0; g.g_y = (long long)M * w.N;
             ck(launch_igemm(g, wd, s), "linear igemm (split-K)");
             ck(launch_splitk_reduce(part, w.bias, y, wd, S, M, w.N, ldy, act, out_f32 ? 1 : 0, s), "split-K reduce");
+            if (!out_f32) calib_check(y, wd, M, w.N, ldy);
             return;
         }
         ck(launch_igemm(g, wd, s), "linear igemm");
+        if (!out_f32) calib_check(y, wd, M, w.N, ldy);
     }
     void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu) {
         float* stats = alloc_f(gn_stats_floats(B, HW, G));
@@ -204,6 +213,7 @@ struct Fwd {
                 g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = ACT_NONE;
                 if (stem_stats) { g.cs_part = stem_stats; g.cs_cg = c1 / G; g.cs_hw = Ho * Wo; g.cs_G = G; }
                 ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
+                calib_check(slot[0], w.dt, g.M, w.Cout, w.Cout);
             }
         } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
@@ -323,6 +333,12 @@ struct Fwd {
         return trunk(t, Stem{rgb, rgb_dt, 1.0f / 255.0f, H, W, 3}, B, Ho, Wo, tapname);
     }
     Act depth_trunk(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
+        calib_slot = 1;
+        Act o = depth_trunk_(t, depth, B, tapname);
+        calib_slot = -1;
+        return o;
+    }
+    Act depth_trunk_(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
         const int H = ctx->cfg.depth_h / 2, W = ctx->cfg.depth_w / 2;
         const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
         static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
@@ -713,7 +729,9 @@ struct Fwd {
     // BERT (:189-195) -> emb
     void hi_bert(const void* ids, int ids_dt, int B, HiBufs& hb) {
         use(ctx->dt_bert);
+        calib_slot = 0;
         bert(ctx->hi.bert, ids, ids_dt, B, hb.emb, ctx->cur_lens);
+        calib_slot = -1;
         tap("hi.bert", hb.emb, true, {B, ctx->cur_L, ctx->cfg.bert_hidden});
         hi_ins_pre(B, hb);
     }
@@ -797,7 +815,9 @@ struct Fwd {
         const LowW& w = ctx->lo;
         use(ctx->dt_depth);
         if (w.depth_simple) {
+            calib_slot = 1;
             simple_cnn(w.depth_s, depth, DT_F32, 1.0f, B, lb.xh, lb.ldx);
+            calib_slot = -1;
         } else {
             Act o = depth_trunk(w.depth, depth, B, "lo.depth");
             linear(w.depth_fc, o.p, B, o.H * o.W * o.C, lb.xh, lb.ldx, ACT_RELU, true);     // visual_fc

@@ -164,6 +164,8 @@ hipError_t launch_attn1q(const float* q, int ldq, const float* k, int ldk, const
 hipError_t launch_argmax(const float* logits, int64_t* pred, int B, int n, int ld, hipStream_t s);
 // xh[b][col0 + j] = emb[subtask[b]][j]
 hipError_t launch_embed_rows(const float* emb, const int64_t* idx, float* y, int B, int D, int ld, int col0, int nrows, hipStream_t s);
+// fp16 range calibration: slot[0] = max(slot[0], bits of max |x|), slot[1] += number of non-finite elements; x is [rows][ld], cols used
+hipError_t launch_absmax(const void* x, int dt, int rows, int cols, int ld, unsigned* slot, hipStream_t s);
 // generic converts
 hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s);
 hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s);

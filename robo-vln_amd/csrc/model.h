@@ -194,5 +194,13 @@ struct hcm_ctx {
     bool reuse_instruction = false;
     int last_hi_batch = -1, last_hi_L = -1;   // shape of the cached instruction stream; -1 = none (invalidated by every other entry point)
     int cur_L = 0;                  // instruction length of the current call (<= cfg.instr_len)
+    // fp16 range calibration (hcm_finalize's synthetic batch, hcm_calibrate's caller batch): while `calib` is set the forward code
+    // reduces max |x| / non-finite counts of every GEMM output of the fp16 sub-networks into calib_buf[2 * slot] (0 BERT, 1 depth trunks)
+    bool calib = false;
+    unsigned* calib_buf = nullptr;       // device, 4 words
+    int fp16_fallback = 0;               // bit 0: BERT was re-built on bf16 tiles, bit 1: the depth trunks
+    float calib_max[2] = {0.f, 0.f};     // last calibration's max |x| per sub-network
+    unsigned calib_bad[2] = {0u, 0u};
+    bool host_weights = true;            // the f32 host copies of the state_dicts are still held (needed to re-build a sub-network)
     const int* cur_lens = nullptr;  // optional per-environment instruction lengths of the current call (device, [B]); null = all L
 };

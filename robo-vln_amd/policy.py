@@ -27,10 +27,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None, max_instr_len=None):
+def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None, max_instr_len=None, keep_host_weights=False):
     s = _lib.HcmConfigStruct()
     for name, p in (sub_precision or {}).items():
         s.reserved[_SUB_SLOTS[name]] = _SUB_DT[p] + 1
+    s.reserved[4] = int(bool(keep_host_weights))
     s.struct_size = C.sizeof(_lib.HcmConfigStruct)
     s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
     s.max_batch = max_batch
@@ -67,7 +68,7 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="bf16", device=None, sub_precision=None, graph=False, max_instr_len=None):
+                 precision="bf16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False):
         """precision: "bf16" (16-bit storage + MFMA with fp32 accumulate; by default the GroupNorm depth trunk uses
         fp16 tiles and everything else bf16, recurrent cells/heads fp32) or "fp32".  `sub_precision` overrides the
         storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
@@ -78,6 +79,9 @@ class HCMEngine:
         (B or 1, L <= max_instr_len) ids, as the reference model does (its eval loop feeds the unpadded tokens of the episode's
         instruction, common/utils.py:18-20).  Default: cfg.instr_len.  BERT's position table allows up to 512."""
         self.max_instr_len = int(max_instr_len or cfg.instr_len)
+        # fp16 range safety: hcm_finalize checks the fp16 sub-networks (BERT, depth trunks) on a synthetic batch and re-builds on bf16
+        # tiles what would overflow (`fp16_fallback`); keep_host_weights=True keeps the f32 host copies so that `calibrate(observations)`
+        # can repeat the check -- and the re-build -- on real observations
         self._graph = bool(graph)
         self._gstream = None
         self._static = None
@@ -91,7 +95,7 @@ class HCMEngine:
         self.has_high = high_level_state_dict is not None
         self.has_low = low_level_state_dict is not None
         with torch.cuda.device(self.device):
-            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision, self.max_instr_len)
+            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision, self.max_instr_len, keep_host_weights)
             _lib.check(self._lib.hcm_create(C.byref(st), C.byref(self._h)))
             try:
                 # load_state_dict(strict=True) semantics (hierarchical_trainer.py:343-345)
@@ -119,6 +123,28 @@ class HCMEngine:
     @property
     def num_recurrent_layers(self):
         return self.query(_lib.HCM_NUM_RECURRENT_LAYERS)
+
+    @property
+    def fp16_fallback(self):
+        """Sub-networks the range calibration moved from fp16 to bf16 storage: subset of {"bert", "depth"}."""
+        bits = self.query(_lib.HCM_FP16_FALLBACK)
+        return {n for b, n in ((1, "bert"), (2, "depth")) if bits & b}
+
+    def calibration_report(self):
+        return {"bert_max_abs": self.query(_lib.HCM_CALIB_MAX_BERT), "depth_max_abs": self.query(_lib.HCM_CALIB_MAX_DEPTH),
+                "non_finite": self.query(_lib.HCM_CALIB_NONFINITE), "fp16_fallback": sorted(self.fp16_fallback)}
+
+    def calibrate(self, observations, release_host_weights=True):
+        """Range-check the fp16 sub-networks on these observations (hcm_calibrate); returns calibration_report().  Needs
+        keep_host_weights=True at construction to be able to re-build a sub-network on bf16 tiles."""
+        with torch.cuda.device(self.device):
+            rgb, depth, ids, _, B = self._obs(observations, self.has_high)
+            _lib.check(self._lib.hcm_calibrate(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), _ptr(ids),
+                                               _TORCH_DT[ids.dtype] if ids is not None else _lib.HCM_I64, B, ids.shape[1] if ids is not None else 1,
+                                               self._stream()), self._h)
+            if release_host_weights:
+                _lib.check(self._lib.hcm_release_host_weights(self._h), self._h)
+        return self.calibration_report()
 
     def close(self):
         if self._h:
