@@ -747,9 +747,58 @@ struct Fwd {
         const VlaW& v = w.vla;
         const int rows = B * L;
         void* I = hb.I;
-        // the two Visual_Ling_Attn calls (rgb, depth) are independent until the recurrent input: run them on two streams
+        // Fused form (16-bit cross-modal block): ONE launch per layer for both Visual_Ling_Attn calls does attention (layer 0: the keys are
+        // the few visual tokens) + fc_o + residual + LayerNorm + FFN + residual + LayerNorm (+ the cross_pooler mean on the last layer) with
+        // the block's activations resident in LDS (vla_fused.hip); deeper layers keep their key/value projection and the L x L attention as
+        // launches of their own.  HCM_NO_VLA_FUSE=1 selects the launch-per-op form below (A/B and the toggle test).
+        static const bool no_vla_fuse = getenv("HCM_NO_VLA_FUSE") != nullptr;
+        const bool fused = !no_vla_fuse && vla_post_ok(dt, d, c.vla_heads, c.d_ff);
         const bool fork = ctx->concurrent && !ctx->taps_on;
         hipStream_t main_s = s;
+        if (fused) {
+            if (fork) fork_join_begin(2);
+            void* outb[2][2];
+            void* attb[2] = {nullptr, nullptr};
+            void* kvb[2] = {nullptr, nullptr};
+            for (int st = 0; st < 2; ++st) {
+                outb[st][0] = alloc_t((size_t)B * Lm * d);
+                outb[st][1] = alloc_t((size_t)B * Lm * d);
+                if (v.layers.size() > 1) { attb[st] = alloc_t((size_t)B * Lm * d); kvb[st] = alloc_t((size_t)B * Lm * 2 * d); }
+            }
+            const int S2[2] = {16, dS};
+            const bool pool_in_kernel = L <= 80;
+            for (size_t l = 0; l < v.layers.size(); ++l) {
+                const VlaLayerW& ly = v.layers[l];
+                const bool last = l + 1 == v.layers.size();
+                VlaPost q;
+                q.q = hb.Q[l]; q.I = I; q.B = B; q.L = L; q.d_ff = c.d_ff; q.lens = ctx->cur_lens;
+                q.wo = ly.o.w; q.bo = ly.o.bias; q.w1 = ly.ff1.w; q.b1 = ly.ff1.bias; q.w2 = ly.ff2.w; q.b2 = ly.ff2.bias;
+                q.g1 = ly.ln_att.gamma; q.be1 = ly.ln_att.beta; q.g2 = ly.ln_ff.gamma; q.be2 = ly.ln_ff.beta;
+                q.fuse_att = l == 0 && S2[0] <= 32 && S2[1] <= 32;
+                for (int st = 0; st < 2; ++st) {
+                    const int Lk = l == 0 ? S2[st] : L;
+                    const void* kvl = hb.kv0[st];
+                    if (l > 0) { linear(ly.kv, outb[st][(l - 1) & 1], B * L, d, kvb[st], 2 * d, ACT_NONE, false); kvl = kvb[st]; }
+                    if (!q.fuse_att) {
+                        void* att = attb[st] ? attb[st] : (attb[st] = alloc_t((size_t)B * Lm * d));
+                        if (!dry) ck(launch_attention(hb.Q[l], kvl, (const char*)kvl + (size_t)d * esz, att, dt, B, c.vla_heads, L, Lk, d, 2 * d, 2 * d, d, B, s,
+                                                      l > 0 ? ctx->cur_lens : nullptr), "vla attention");
+                        q.att[st] = att;
+                    }
+                    q.kv[st] = kvl; q.Lk[st] = Lk;
+                    q.out[st] = outb[st][l & 1];
+                    if (last && pool_in_kernel) { q.pooled[st] = xh + w.rnn.xcol(c.rgb_out + c.depth_out + st * d); q.ld_pool = ldx; }
+                }
+                if (!dry) ck(launch_vla_post(q, dt, s), "fused cross-modal layer");
+            }
+            const size_t lastl = (v.layers.size() - 1) & 1;
+            for (int st = 0; st < 2; ++st) {
+                tap(st == 0 ? "hi.vla_rgb" : "hi.vla_depth", outb[st][lastl], true, {B, L, d});
+                if (!pool_in_kernel && !dry)
+                    ck(launch_mean_rows(outb[st][lastl], xh + w.rnn.xcol(c.rgb_out + c.depth_out + st * d), dt, B, L, d, d, ldx, 1, s, ctx->cur_lens), "cross_pooler");
+            }
+        } else {
+        // the two Visual_Ling_Attn calls (rgb, depth) are independent until the recurrent input: run them on two streams
         if (fork) fork_join_begin(2);
         for (int stream = 0; stream < 2; ++stream) {
             if (fork) on(stream == 0 ? main_s : ctx->aux[0]);
@@ -783,6 +832,7 @@ struct Fwd {
             tap(stream == 0 ? "hi.vla_rgb" : "hi.vla_depth", out, true, {B, L, d});
             // cross_pooler: mean over all L tokens (:209-210) -> xh columns
             if (!dry) ck(launch_mean_rows(out, xh + w.rnn.xcol(c.rgb_out + c.depth_out + stream * d), dt, B, L, d, d, ldx, 1, s, ctx->cur_lens), "cross_pooler");
+        }
         }
         // meanwhile (third stream): the early halves of both recurrent steps
         float* hi_pre = nullptr;

@@ -132,6 +132,24 @@ hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, con
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads,
                             int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s, const int* klens = nullptr);
 
+// One cross-modal layer after the projections, both visual streams in one launch (vla_fused.hip): [attention when Lk <= 32] ->
+// fc_o + residual I -> LayerNorm -> fc1 + ReLU -> fc2 + residual -> LayerNorm [-> mean over the instruction's tokens].  16-bit storage types,
+// d_model 256, 4 heads, d_ff a multiple of 256.  Per-stream pointers are indexed by blockIdx.y.
+struct VlaPost {
+    const void* q = nullptr;                 // fc_q(I)  [B][L][256]   (in-kernel attention only)
+    const void* I = nullptr;                 // query stream = residual [B][L][256]
+    const void* kv[2] = {nullptr, nullptr};  // fc_k | fc_v of the keys  [B][Lk][512]   (in-kernel attention only)
+    const void* att[2] = {nullptr, nullptr}; // attention output [B][L][256]            (when the attention ran as its own launch)
+    void* out[2] = {nullptr, nullptr};       // layer output [B][L][256]
+    float* pooled[2] = {nullptr, nullptr};   // mean over the tokens -> pooled[b * ld_pool + c] (only when L <= 80), or null
+    const void *wo = nullptr, *w1 = nullptr, *w2 = nullptr;       // [256][256], [d_ff][256], [256][d_ff]
+    const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+    const int* lens = nullptr;               // per-environment token counts (ragged batches) or null
+    int B = 0, L = 0, Lk[2] = {0, 0}, d_ff = 1024, fuse_att = 0, ld_pool = 0, streams = 2;
+};
+bool vla_post_ok(int dt, int d_model, int heads, int d_ff);
+hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s);
+
 // RNN input assembly: xh[b][x_cols + j] = h_in[0][b][j] * mask[b]   (f32)
 hipError_t launch_rnn_prep(const float* h_in, const float* mask, float* xh, int B, int Hd, int ld, int col0, hipStream_t s);
 struct Heads {            // up to two small linear heads on the new hidden state
