@@ -37,6 +37,7 @@ typedef int g_v4i __attribute__((ext_vector_type(4)));
 
 struct G256Dev {
     const char* x; const char* w; const float* bias; char* y;
+    const char* res; int ldr;        // optional residual [M][ldr] (T), added in f32 before the activation and the one rounding
     int M, N, K, ldx, ldw, ldy, act;
     unsigned x_bytes, w_bytes;
     int tilesM, tilesN, gm, gn;      // XCD grid: the 8 XCDs own gm x gn rectangles of the tile grid (each has a private L2)
@@ -277,6 +278,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
     tile_body(t, std::false_type{});
     if (wr == 0) G_BAR();                              // re-align the two row groups: every fragment read is done
 
+    if (p.res) {
+        // ---- residual epilogue: y = act(acc + bias + res), one rounding -- the order of f32 operations of igemm_epilogue.  The accumulators
+        // go through an f32 LDS image of HALF the tile at a time (128 rows x 256 channels, rows padded to 1040 B); in the row pass every
+        // thread adds bias + 8 residual channels read as one 16-byte piece, applies the activation, rounds and stores 16 bytes.
+        constexpr int LDF = 260;                       // floats per image row
+        float* sc = reinterpret_cast<float*>(smem);
+        const int chunk = tid & 31, n = n0 + chunk * 8;
+        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+        for (int half = 0; half < 2; ++half) {
+            // the residual rows of this half: requested before the image is written, consumed after the barrier
+            uint4 rr[8];
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int m = m0 + half * 128 + pass * 16 + (tid >> 5);
+                rr[pass] = make_uint4(0u, 0u, 0u, 0u);
+                if (m < p.M && n < p.N) rr[pass] = *reinterpret_cast<const uint4*>(p.res + ((size_t)m * p.ldr + n) * 2);
+            }
+            if (wr == half) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<float4*>(sc + (j * 16 + fr) * LDF + wc * 64 + i * 16 + fg * 4) =
+                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 16 + (tid >> 5);
+                const int m = m0 + half * 128 + r;
+                if (m < p.M && n < p.N) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(sc + r * LDF + chunk * 8), a1 = *reinterpret_cast<const float4*>(sc + r * LDF + chunk * 8 + 4);
+                    float v[8] = {a0.x + bias8[0], a0.y + bias8[1], a0.z + bias8[2], a0.w + bias8[3], a1.x + bias8[4], a1.y + bias8[5], a1.z + bias8[6], a1.w + bias8[7]};
+                    float r8[8];
+                    cvt_chunk<T>(rr[pass], r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+                    }
+                    st_chunk(reinterpret_cast<T*>(p.y + ((size_t)m * p.ldy + n) * 2), v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // ---- epilogue: acc + bias, activation, one rounding -> 16-bit tile image in LDS -> 16-byte stores of whole rows
     {
         float4 b4[4];
@@ -324,19 +380,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
 bool gemm256_applicable(const IGemm& g, int dt) {
     if (dt != DT_BF16 && dt != DT_F16) return false;
     if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
-    if (g.res || g.out_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0) return false;
-    const int Kp = g.Kp ? g.Kp : g.K, ldx = g.xC ? g.xC : g.Cin, ldy = g.ldy ? g.ldy : g.N;
-    if (g.K % 64 || Kp % 8 || ldx % 8 || ldy % 8 || g.N % 8) return false;
+    if (g.out_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0) return false;
+    const int Kp = g.Kp ? g.Kp : g.K, ldx = g.xC ? g.xC : g.Cin, ldy = g.ldy ? g.ldy : g.N, ldr = g.ldr ? g.ldr : g.N;
+    if (g.K % 64 || Kp % 8 || ldx % 8 || ldy % 8 || g.N % 8 || (g.res && ldr % 8)) return false;
     if ((size_t)g.M * ldx * 2 >= 0x7FFFFFF0ull || (size_t)g.N * Kp * 2 >= 0x7FFFFFF0ull) return false;   // offsets + the out-of-range sentinel
     // worth it when the tile grid fills a good part of the chip with whole tiles: wide outputs over many rows
     const long tiles = (long)((g.M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
-    return g.N >= 1024 && g.M >= 2048 && tiles >= 96 && g.K >= 256;
+    // (HCM_GEMM256_MIN_TILES / HCM_GEMM256_MIN_N: A/B knobs for the in-step choice of the narrow-output layers)
+    static const int min_tiles = getenv("HCM_GEMM256_MIN_TILES") ? atoi(getenv("HCM_GEMM256_MIN_TILES")) : 96;
+    static const int min_n = getenv("HCM_GEMM256_MIN_N") ? atoi(getenv("HCM_GEMM256_MIN_N")) : 512;
+    return g.N >= min_n && g.M >= 2048 && tiles >= min_tiles && g.K >= 256;
 }
 
 hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
     if (!gemm256_applicable(g, dt)) return hipErrorInvalidValue;
     G256Dev d;
     d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.y = (char*)g.y;
+    d.res = (const char*)g.res; d.ldr = g.ldr ? g.ldr : g.N;
     d.M = g.M; d.N = g.N; d.K = g.K; d.ldx = g.xC ? g.xC : g.Cin; d.ldw = g.Kp ? g.Kp : g.K; d.ldy = g.ldy ? g.ldy : g.N; d.act = g.act;
     d.x_bytes = (unsigned)(((size_t)(g.M - 1) * d.ldx + g.K) * 2);
     d.w_bytes = (unsigned)((size_t)g.N * d.ldw * 2);

@@ -56,20 +56,27 @@ template <typename T> __device__ __forceinline__ void v_ld4(const char* p, float
     for (int e = 0; e < 4; ++e) v[e] = Tr<T>::ld(&o[e]);
 }
 
-// acc[i][j] += W[n = nbase + i*16 + fr][k0 + ks*32 + fg*8 ..] x A[row j*16 + fr][ks*32 + fg*8 ..] for ks = 0..7 (256 of K)
+// acc[i][j] += W[n = nbase + i*16 + fr][k0 + ks*32 + fg*8 ..] x A[row j*16 + fr][ks*32 + fg*8 ..] for ks = 0..7 (256 of K).
+// All 16 weight fragments of the call are requested up front (64 VGPRs): the loads are L2 hits of ~500 cycles each, and issued one k-step
+// at a time they were the kernel's critical path (82 us per launch; MFMA work is 11 us).
 template <typename T>
-__device__ __forceinline__ void v_gemm256(v_f32x4 (&acc)[2][V_MF], const T* __restrict__ W, int ldw, int nbase, int k0, const char* sA, int fr, int fg) {
+__device__ __forceinline__ void v_wload(uint4 (&wf)[8][2], const T* __restrict__ W, int ldw, int nbase, int k0, int fr, int fg) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[ks][i] = *reinterpret_cast<const uint4*>(W + (size_t)(nbase + i * 16 + fr) * ldw + k0 + ks * 32 + fg * 8);
+}
+template <typename T>
+__device__ __forceinline__ void v_mma256(v_f32x4 (&acc)[2][V_MF], const uint4 (&wf)[8][2], const char* sA, int fr, int fg) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        uint4 wf[2], xf[V_MF];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const uint4*>(W + (size_t)(nbase + i * 16 + fr) * ldw + k0 + ks * 32 + fg * 8);
+        uint4 xf[V_MF];
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) xf[j] = *reinterpret_cast<const uint4*>(sA + (j * 16 + fr) * V_LDA + (ks * 32 + fg * 8) * 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < V_MF; ++j) VMma<T>::run(acc[i][j], wf[i], xf[j]);
+            for (int j = 0; j < V_MF; ++j) VMma<T>::run(acc[i][j], wf[ks][i], xf[j]);
     }
 }
 
@@ -128,6 +135,9 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     const T* I = reinterpret_cast<const T*>(p.I) + ((size_t)b * p.L + r0) * V_D;
     T* out = reinterpret_cast<T*>(p.out[st]) + ((size_t)b * p.L + r0) * V_D;
 
+    const int nb = wave * 32;                          // this wave's 32 output channels of every 256-wide GEMM
+    uint4 wf[8][2];
+    v_wload<T>(wf, reinterpret_cast<const T*>(p.wo), V_D, nb, 0, fr, fg);      // fc_o's fragments travel while the attention runs
     // ---- attention output of the block into sA (rows >= nrow: zeros)
     if (p.fuse_att) {
         const int Lk = p.Lk[st];
@@ -197,7 +207,6 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     }
     __syncthreads();
 
-    const int nb = wave * 32;                          // this wave's 32 output channels of every 256-wide GEMM
     float v[2][V_MF][4];
     // ---- x1 = LayerNorm(I + att Wo^T + bo)
     {
@@ -206,7 +215,8 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) acc[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
-        v_gemm256<T>(acc, reinterpret_cast<const T*>(p.wo), V_D, nb, 0, sA, fr, fg);
+        v_mma256<T>(acc, wf, sA, fr, fg);
+        v_wload<T>(wf, reinterpret_cast<const T*>(p.w1), V_D, nb, 0, fr, fg);   // fc1 slice 0: in flight during the LayerNorm
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int n = nb + i * 16 + fg * 4;
@@ -241,7 +251,8 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) acc1[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
-        v_gemm256<T>(acc1, reinterpret_cast<const T*>(p.w1), V_D, c * 256 + nb, 0, sX, fr, fg);
+        v_mma256<T>(acc1, wf, sX, fr, fg);
+        v_wload<T>(wf, reinterpret_cast<const T*>(p.w2), p.d_ff, nb, c * 256, fr, fg);   // fc2 k-range c: in flight during the ReLU epilogue + barrier
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float4 bb = *reinterpret_cast<const float4*>(p.b1 + c * 256 + nb + i * 16 + fg * 4);
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             }
         }
         __syncthreads();
-        v_gemm256<T>(acc2, reinterpret_cast<const T*>(p.w2), p.d_ff, nb, c * 256, sA, fr, fg);
+        v_mma256<T>(acc2, wf, sA, fr, fg);
+        if (c + 1 < nslice) v_wload<T>(wf, reinterpret_cast<const T*>(p.w1), V_D, (c + 1) * 256 + nb, 0, fr, fg);
         __syncthreads();
     }
     // ---- out = LayerNorm(x1 + ffn + b2)

@@ -468,14 +468,17 @@ def test_conv2d_groupnorm_large_map_epilogue_stats(prec, cfg):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape,act", [
-    ((5120, 3072, 768), 2),      # BERT FFN1 at B=64, L=80 (GELU)
-    ((5120, 2304, 768), 0),      # BERT QKV
-    ((5000, 1160, 320), 1),      # ragged: last token tile 136 rows, last channel tile 136 columns, odd number of K tiles (ReLU)
-    ((2048, 3072, 256), 0),      # shortest K the launcher accepts, whole tiles
-    ((20480, 3072, 768), 2),     # configs[4]: B=128, L=160
+@pytest.mark.parametrize("shape,act,with_res", [
+    ((5120, 3072, 768), 2, False),      # BERT FFN1 at B=64, L=80 (GELU)
+    ((5120, 2304, 768), 0, False),      # BERT QKV
+    ((5000, 1160, 320), 1, False),      # ragged: last token tile 136 rows, last channel tile 136 columns, odd number of K tiles (ReLU)
+    ((2048, 3072, 256), 0, False),      # shortest K the launcher accepts, whole tiles
+    ((20480, 3072, 768), 2, False),     # configs[4]: B=128, L=160
+    ((20480, 768, 3072), 0, True),      # configs[4] FFN2: residual epilogue (f32 half-tile image)
+    ((20480, 768, 768), 0, True),       # configs[4] attention output projection
+    ((9000, 1160, 320), 1, True),       # ragged tiles + residual + ReLU
 ])
-def test_gemm256_bit_identical_to_igemm(prec, shape, act):
+def test_gemm256_bit_identical_to_igemm(prec, shape, act, with_res):
     """The 256 x 256-tile 8-phase kernel (csrc/gemm256.hip) runs the same MFMA instruction over the same k order and the same f32
     epilogue operations as the 128-wide implicit-GEMM kernel: the two outputs must be equal bit for bit (and right: vs torch fp32)."""
     lib, L = _lib()
@@ -486,11 +489,16 @@ def test_gemm256_bit_identical_to_igemm(prec, shape, act):
     bias = _rnd(N, seed=7)
     ref = x.float() @ w.float().t() + bias
     ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    res = _rnd(M, N, seed=8).to(tdt) if with_res else None
+    if with_res:
+        ref = x.float() @ w.float().t() + bias + res.float()
+        ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
     xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    rd = res.cuda() if with_res else None
     outs = []
     for impl in (1, 2):
         y = torch.full((M, N), float("nan"), device="cuda", dtype=tdt)
-        rc = lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), None, _p(y), code, M, N, K, act, 0, impl, None)
+        rc = lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, M, N, K, act, 0, impl, None)
         assert rc == 0, (impl, rc)
         torch.cuda.synchronize()
         outs.append(y)
@@ -500,7 +508,7 @@ def test_gemm256_bit_identical_to_igemm(prec, shape, act):
     # run-to-run determinism under repeated launches (DMA / barrier races would show as flicker)
     for _ in range(5):
         y = torch.empty((M, N), device="cuda", dtype=tdt)
-        assert lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), None, _p(y), code, M, N, K, act, 0, 2, None) == 0
+        assert lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, M, N, K, act, 0, 2, None) == 0
         torch.cuda.synchronize()
         assert torch.equal(y, outs[1])
 
