@@ -222,7 +222,8 @@ def build_probe_workload(args):
     cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, cfg.depth_hw, 128), "probe_cnn", 0)
     vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
     prec = "fp16" if args.precision == "bf16" else "fp32"
-    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec)
+    # (graph replay needs the inputs in the probe's static buffers: the 98 MB copy per step costs more than the launch gaps it removes)
+    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec, graph=False)
     tdt = torch.float16 if prec == "fp16" else torch.float32
     sets = []
     for k in range(2):

@@ -282,6 +282,10 @@ int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const flo
 int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                                  int Cout, float scale, void* scratch, void* half_map, void* stream);
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
+/* SimpleDepthCNN's first layer, Conv2d(1, 32, 8, stride 4) (+ bias, activation) on a raw f32 depth frame (B,H,H,1) through the packed-frame
+ * path of the model code; w is the OHWI weight [32][64] in `dtype` (16-bit), scratch holds B*H*H + 64 elements of `dtype` (simple_cnns.py:76-84). */
+int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias, void* y, int dtype, int B, int H, int act, void* scratch,
+                           void* stream);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
 /* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,

@@ -776,6 +776,24 @@ int hcm_op_stem_conv(const void* x, int x_dtype, const void* w, const float* bia
     g.x_scale = scale; g.x_rowrun = rowrun;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+/* SimpleCNN's first layer on a depth frame (simple_cnns.py:76-84: Conv2d(1, 32, 8, stride 4) + ReLU) through the packed path of the model
+ * code (forward.cpp: simple_cnn): the f32 frame is converted once to the storage type; a kernel row of an output pixel is then one
+ * contiguous run of 8 elements, so the conv is an LDS-DMA implicit GEMM over "virtual pixels" of 4 real ones (KH = 8, KW = 1, Cin = 8,
+ * pixel stride 4, K = 64).  w is the plain OHWI weight [32][8*8]; scratch holds B*H*H + 64 elements of `dtype`. */
+int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias, void* y, int dtype, int B, int H, int act, void* scratch,
+                           void* stream) {
+    const int dt = op_dt(dtype);
+    if (!scratch || dt == DT_F32 || H % 4 || H < 8) return HCM_ERR_ARG;
+    int rc = op_rc(launch_convert_from_f32(depth, scratch, dt, (size_t)B * H * H, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    const int h1 = (H - 8) / 4 + 1;
+    IGemm g;
+    g.x = scratch; g.w = w; g.bias = bias; g.y = y;
+    g.B = B; g.H = H; g.W = H / 4; g.Cin = 8; g.xC = 4;
+    g.Ho = h1; g.Wo = h1; g.KH = 8; g.KW = 1; g.stride = 4; g.stride_w = 1; g.pad = 0;
+    g.M = B * h1 * h1; g.N = 32; g.K = 64; g.Kp = 64; g.ldy = 32; g.ldr = 32; g.act = act;
+    return op_rc(launch_igemm(g, dt, (hipStream_t)stream));
+}
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W) { return (int64_t)hcm::pack_frame_elems(B, H, W) * 2; }
 int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                             int Cout, float scale, int act, void* scratch, void* stream) {
@@ -810,8 +828,40 @@ int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, cons
     if (rc != HCM_OK) return rc;
     return op_rc(launch_vpool3s2(half_map, y, dt, B, g.Ho, g.Wo / 2, Cout, (hipStream_t)stream));
 }
+// scratch of the operator entry points that need a temporary (split-K partials, converted frames): grown on demand, test / probe use only
+static void* op_scratch(size_t bytes) {
+    static void* buf = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); }
+        if (hipMalloc(&buf, bytes) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
+        cap = bytes;
+    }
+    return buf;
+}
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y, int dtype, int M, int N, int K,
                   int act, int out_f32, void* stream) {
+    // skinny long-K layers (M = batch rows behind a Flatten: SimpleCNN's 25088-wide FC) are split along K exactly as the model path does
+    // (forward.cpp: Fwd::linear): grouped launch over K slices into f32 partials, fixed-order reduction with bias + activation
+    if (!residual && M <= 256 && K >= 2048) {
+        const int CHw = dtype == HCM_F32 ? 4 : 8;
+        int S = 1;
+        const long blocks = (long)((M + 63) / 64) * ((N + 31) / 32);
+        while (S < 16 && blocks * S < 256 && K % (2 * S * 64) == 0 && K / (2 * S) >= 256) S *= 2;
+        if (K % (S * CHw)) S = 1;
+        if (S > 1) {
+            float* part = (float*)op_scratch((size_t)S * M * N * 4);
+            if (!part) return HCM_ERR_NOMEM;
+            const int Ks = K / S;
+            IGemm g;
+            g.x = x; g.w = w; g.y = part;
+            g.B = M; g.Cin = Ks; g.xC = K; g.M = M; g.N = N; g.K = Ks; g.Kp = K; g.ldy = N; g.ldr = N; g.act = ACT_NONE; g.out_f32 = 1;
+            g.groups = S; g.g_x = Ks; g.g_w = Ks; g.g_b = 0; g.g_y = (long long)M * N;
+            int rc = op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
+            if (rc != HCM_OK) return rc;
+            return op_rc(launch_splitk_reduce(part, bias, y, op_dt(dtype), S, M, N, N, act, out_f32, (hipStream_t)stream));
+        }
+    }
     IGemm g;
     g.x = x; g.w = w; g.bias = bias; g.res = residual; g.y = y;
     g.B = M; g.Cin = K; g.xC = K; g.M = M; g.N = N; g.K = K; g.Kp = K; g.ldy = N; g.ldr = N; g.act = act; g.out_f32 = out_f32;

@@ -34,7 +34,11 @@ def sinusoid_table(L, d):
 class DepthCnnVlaProbe:
     """cnn_sd: SimpleDepthCNN state_dict (keys cnn.{0,2,4,7}.{weight,bias}); vla_sd: Visual_Ling_Attn state_dict (N = 1)."""
 
-    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="bf16", device="cuda"):
+    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="bf16", device="cuda", graph=False):
+        """graph=True: forward() is captured once per batch size into a hipGraph (torch.cuda.CUDAGraph over the library's launches on
+        the capture stream) with engine-owned static input / output buffers, and replayed: the ~16 dependent launches then cost one."""
+        self._graph = bool(graph)
+        self._graphs = {}
         self.lib = _lib.lib()
         self.code, self.tdt = _DT[precision]
         self.dev = torch.device(device)
@@ -49,6 +53,7 @@ class DepthCnnVlaProbe:
         w0p = np.zeros((32, (k0 + 31) // 32 * 32), np.float32)
         w0p[:, :k0] = w0
         self.c0, self.c0_k, self.c0_kp, self.b0 = W(w0p), k0, w0p.shape[1], F32(g(cnn_sd, "cnn.0.bias"))
+        self.c0_plain = W(w0)                               # [32][64]: the packed-frame path of the 16-bit builds
         self.c1, self.b1 = W(g(cnn_sd, "cnn.2.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.2.bias"))
         self.c2, self.b2 = W(g(cnn_sd, "cnn.4.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.4.bias"))
         h1 = (depth_hw - 8) // 4 + 1
@@ -78,39 +83,72 @@ class DepthCnnVlaProbe:
         if rc != 0:
             raise RuntimeError(f"libhcm operator failed: {rc}")
 
+    @staticmethod
+    def _st():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
     def _lin(self, x, wb, M, act=0, res=None):
         w, b = wb
         y = torch.empty(M, w.shape[0], device=self.dev, dtype=self.tdt)
-        self._ck(self.lib.hcm_op_linear(_p(x), _p(w), _p(b), _p(res), _p(y), self.code, M, w.shape[0], w.shape[1], act, 0, None))
+        self._ck(self.lib.hcm_op_linear(_p(x), _p(w), _p(b), _p(res), _p(y), self.code, M, w.shape[0], w.shape[1], act, 0, self._st()))
         return y
 
     def _ln(self, x, gb, rows, post=None, post_rows=0):
         y = torch.empty(rows, self.d, device=self.dev, dtype=self.tdt)
-        self._ck(self.lib.hcm_op_layernorm_post(_p(x), None, _p(gb[0]), _p(gb[1]), _p(post), post_rows, _p(y), self.code, rows, self.d, 1e-5, None))
+        self._ck(self.lib.hcm_op_layernorm_post(_p(x), None, _p(gb[0]), _p(gb[1]), _p(post), post_rows, _p(y), self.code, rows, self.d, 1e-5, self._st()))
         return y
 
     def forward(self, depth, ins):
         """depth (B,H,W,1) f32 on the device, ins (B,L,768) in the storage type -> (B,L,d)."""
+        if not self._graph:
+            return self._forward(depth, ins)
+        B = depth.shape[0]
+        g = self._graphs.get(B)
+        if g is None:
+            st = {"depth": depth.clone(), "ins": ins.clone()}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                        # warm-up outside the capture (one-time kernel attribute setup, scratch growth)
+                for _ in range(2):
+                    self._forward(st["depth"], st["ins"])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = self._forward(st["depth"], st["ins"])
+            g = self._graphs[B] = (graph, st)
+        graph, st = g
+        st["depth"].copy_(depth, non_blocking=True)
+        st["ins"].copy_(ins, non_blocking=True)
+        graph.replay()
+        return st["out"]
+
+    def _forward(self, depth, ins):
         L_, lib, code = _lib, self.lib, self.code
         B = depth.shape[0]
         e = lambda *s: torch.empty(*s, device=self.dev, dtype=self.tdt)
         y0 = e(B, self.h1, self.h1, 32)
-        self._ck(lib.hcm_op_stem_conv(_p(depth), L_.HCM_F32, _p(self.c0), _p(self.b0), _p(y0), code, B, self.hw, self.hw, 1, 32, 8, 8, 4, 0,
-                                      self.c0_k, self.c0_kp, 0, 1.0, L_.ACT_RELU, None))
+        if self.tdt != torch.float32 and self.hw % 4 == 0:
+            scratch = e(B * self.hw * self.hw + 64)
+            self._ck(lib.hcm_op_depth_conv8x8s4(_p(depth), _p(self.c0_plain), _p(self.b0), _p(y0), code, B, self.hw, L_.ACT_RELU, _p(scratch), self._st()))
+        else:
+            self._ck(lib.hcm_op_stem_conv(_p(depth), L_.HCM_F32, _p(self.c0), _p(self.b0), _p(y0), code, B, self.hw, self.hw, 1, 32, 8, 8, 4, 0,
+                                          self.c0_k, self.c0_kp, 0, 1.0, L_.ACT_RELU, self._st()))
         y1 = e(B, self.h2, self.h2, 64)
-        self._ck(lib.hcm_op_conv2d(_p(y0), _p(self.c1), _p(self.b1), None, _p(y1), code, B, self.h1, self.h1, 32, 64, 4, 4, 2, 0, L_.ACT_RELU, None))
+        self._ck(lib.hcm_op_conv2d(_p(y0), _p(self.c1), _p(self.b1), None, _p(y1), code, B, self.h1, self.h1, 32, 64, 4, 4, 2, 0, L_.ACT_RELU, self._st()))
         y2 = e(B, self.h3, self.h3, 32)
-        self._ck(lib.hcm_op_conv2d(_p(y1), _p(self.c2), _p(self.b2), None, _p(y2), code, B, self.h2, self.h2, 64, 32, 3, 3, 1, 0, L_.ACT_NONE, None))
+        self._ck(lib.hcm_op_conv2d(_p(y1), _p(self.c2), _p(self.b2), None, _p(y2), code, B, self.h2, self.h2, 64, 32, 3, 3, 1, 0, L_.ACT_NONE, self._st()))
         tok = self._lin(y2, (self.fc, self.fcb), B, act=L_.ACT_RELU)                 # (B, 128): the one visual token
         rows = B * self.L
         V = self._ln(self._lin(tok, self.vis_fc, B, act=L_.ACT_RELU), self.ln, B)     # (B, 1, d)
         I = self._ln(self._lin(ins.reshape(rows, -1), self.ins_fc, rows, act=L_.ACT_RELU), self.ln, rows, self.pe, self.L)
-        q = self._lin(I, self.fq, rows)
+        # one visual token = one key: softmax over a single score is exactly 1, so the attention output is the value row whatever the
+        # query is -- fc_q(I) (transformer.py:116) cannot reach the output and is not computed; the attention kernel still runs, with I
+        # standing in for the queries (any finite values give the same result bit for bit)
         kv = self._lin(V, self.fkv, B)                                               # (B, 1, 2d)
         att = e(rows, self.d)
         esz = kv.element_size()
-        self._ck(lib.hcm_op_attention(_p(q), _p(kv), C.c_void_p(kv.data_ptr() + self.d * esz), _p(att), code, B, self.heads, self.L, 1,
-                                      self.d, 2 * self.d, 2 * self.d, self.d, None))
+        self._ck(lib.hcm_op_attention(_p(I), _p(kv), C.c_void_p(kv.data_ptr() + self.d * esz), _p(att), code, B, self.heads, self.L, 1,
+                                      self.d, 2 * self.d, 2 * self.d, self.d, self._st()))
         o = self._ln(self._lin(att, self.fo, rows, res=I), self.ln_att, rows)
         f = self._lin(self._lin(o, self.f1, rows, act=L_.ACT_RELU), self.f2, rows, res=o)
         return self._ln(f, self.ln_ff, rows).reshape(B, self.L, self.d)
