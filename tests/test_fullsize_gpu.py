@@ -111,6 +111,12 @@ def test_config3_full_size_probe(precision):
     one = probe.forward(d_dev[7:8].contiguous(), i_dev[7:8].contiguous())
     torch.cuda.synchronize()
     assert (one.float() - out[7:8].float()).abs().max().item() <= (4e-3 if precision == "fp16" else 3e-2)
+    # graph replay (all launches of the probe captured once) equals the eager launches bit for bit
+    gp = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=precision, graph=True)
+    for _ in range(2):
+        g_out = gp.forward(d_dev, i_dev)
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, out)
 
 
 def test_config3_encoder_low_level_model_full_size():
