@@ -90,9 +90,10 @@ def _time_op(run, n=60, warm=30):
 
 
 def dominant_kernel_probe(batch, L=80):
-    """The kernel with the largest share of a step's kernel time is the implicit-GEMM kernel `igemm_dma_kernel` on the fp16 BERT
-    shapes (profiles/r2_kernel_trace_bench.md): 12 launches each of QKV (768 -> 2304), attention-output (768 -> 768), FFN1
-    (768 -> 3072, GELU) and FFN2 (3072 -> 768) over M = batch * L token rows.  Each is timed live here through the library's operator
+    """The launches with the largest share of a step's kernel time are the GEMMs of the fp16 BERT encoder
+    (profiles/r2b_kernel_trace_bench.md): 12 launches each of QKV (768 -> 2304) and FFN1 (768 -> 3072, GELU) on the 256 x 256-tile
+    8-phase kernel `gemm256_kernel`, and of attention-output (768 -> 768) and FFN2 (3072 -> 768) on `igemm_dma_kernel` (at B = 64 their
+    output is too narrow for 256-wide tiles), over M = batch * L token rows.  Each is timed live here through the library's operator
     entry point (same kernel, same tile choice as inside the step) and priced against the dense 16-bit MFMA peak: algorithmic FLOPs
     per launch = 2*M*N*K.  The FFN1 launch is the single most expensive one and is the `roofline` of the JSON line."""
     import ctypes as C
@@ -440,11 +441,11 @@ def main():
                     dk = dominant_kernel_probe(B, L)
                     top = dk["ffn1"]
                     k_tr = (tr or {}).get("dominant_kernel_GB_per_launch")
-                    # the JSON line's `roofline` is the DOMINANT KERNEL (igemm_dma_kernel on the BERT FFN1 shape), live HIP-event timing;
+                    # the JSON line's `roofline` is the DOMINANT KERNEL (gemm256_kernel on the BERT FFN1 shape), live HIP-event timing;
                     # the whole-step view and the HBM-bound probe ride along as labelled sub-objects
                     roof = {"bound": "mfma", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_peak"],
                             "traffic": k_tr, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)" if k_tr else None,
-                            "scope": "dominant kernel: igemm_dma_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
+                            "scope": "dominant kernel: gemm256_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
                                      f"{top['gflop_per_launch']} algorithmic GFLOP per launch, 12 launches per step",
                             "bert_gemms": dk, "whole_step": whole}
                     roof["hbm_probe"] = hbm_kernel_probe(B)
