@@ -66,7 +66,11 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         obs = obs_fn(t, lo, hi)
         reuse = cache_instruction and t > 0
         if reuse and prev_done is not None and bool(prev_done.any()):
-            policy.engine.refresh_instruction(obs["instruction"], torch.nonzero(prev_done).flatten().cpu().numpy())
+            idx = torch.nonzero(prev_done).flatten().cpu().numpy()
+            if obs.get("instruction_lengths") is not None:      # ragged batch: the refreshed rows keep their own token counts
+                policy.engine.refresh_instruction(obs["instruction"], idx, obs["instruction_lengths"])
+            else:
+                policy.engine.refresh_instruction(obs["instruction"], idx)
         rec, hh, lh = (policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, reuse_instruction=True) if reuse
                        else policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks))
         if world > 1:
