@@ -288,6 +288,15 @@ int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias,
                            void* stream);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
+/* One cross-modal layer after the projections for `streams` (1 or 2) visual streams in one launch (csrc/vla_fused.hip;
+ * InterModuleAttnLayer.forward, models/transformer/transformer.py:209-221): [kv != NULL: softmax(q k^T / 8) v over Lk[s] <= 32 keys, kv[s] =
+ * (B, Lk[s], 512) = fc_k | fc_v; else att[s] (B, L, 256) is the attention output] -> LayerNorm(I + . Wo^T + bo) -> LayerNorm(x1 + relu(x1 W1^T + b1)
+ * W2^T + b2) -> out[s] (B, L, 256); pooled[s] (optional, L <= 80): mean over each environment's first lens[b] (or L) tokens -> pooled[s][b * ld_pool + c].
+ * 16-bit dtypes; kv / att / out / pooled are HOST arrays of `streams` device pointers. */
+int hcm_op_vla_layer(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out, float* const* pooled,
+                     int ld_pool, const void* wo, const float* bo, const void* w1, const float* b1, const void* w2, const float* b2, const float* g1,
+                     const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
+                     void* stream);
 /* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,
  * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify).  The two must agree bit for bit. */
 int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const void* residual, void* y,

@@ -333,7 +333,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
         }
         return;
     }
-    // ---- epilogue: acc + bias, activation, one rounding -> 16-bit tile image in LDS -> 16-byte stores of whole rows
+    // ---- epilogue: acc + bias, activation, one rounding -> 16-bit tile image in LDS -> 16-byte stores of whole rows.
+    // In two halves of the wave's rows (fragments 0-3 / 4-7, i.e. tile rows {0-63, 128-191} / {64-127, 192-255}): the stores of the first
+    // half are in flight while the second half's bias / activation / rounding arithmetic runs (FFN1's 128 GELUs per thread are ~6 us of
+    // VALU work, the tile's 128 KB of stores ~7 us of drain).
     {
         float4 b4[4];
 #pragma unroll
@@ -341,37 +344,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
             const int n = n0 + wc * 64 + i * 16 + fg * 4;
             b4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
-                if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
-                }
-                T o4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
-                const int r = wr * 128 + j * 16 + fr;
-                const int cb = (wc * 64 + i * 16 + fg * 4) * 2;
-                *reinterpret_cast<uint2*>(smem + r * G_IMG_LD + cb) = *reinterpret_cast<const uint2*>(o4);
-            }
-    }
-    __syncthreads();
-    {
         const int chunk = tid & 31;                    // 16-byte piece of a 512-byte row
         const int n = n0 + chunk * 8;
-        if (n < p.N) {                                 // N % 8 == 0 (launcher)
-#pragma unroll 4
-            for (int pass = 0; pass < 16; ++pass) {
-                const int r = pass * 16 + (tid >> 5);
-                const int m = m0 + r;
-                if (m < p.M)
-                    *reinterpret_cast<uint4*>(p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const uint4*>(smem + r * G_IMG_LD + chunk * 16);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = half * 4 + jj;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+                    }
+                    T o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    const int r = wr * 128 + j * 16 + fr;
+                    const int cb = (wc * 64 + i * 16 + fg * 4) * 2;
+                    *reinterpret_cast<uint2*>(smem + r * G_IMG_LD + cb) = *reinterpret_cast<const uint2*>(o4);
+                }
+            }
+            __syncthreads();
+            if (n < p.N) {                             // N % 8 == 0 (launcher)
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int rr = pass * 16 + (tid >> 5);                      // 0..127 over the half's rows
+                    const int r = (rr >> 6) * 128 + half * 64 + (rr & 63);
+                    const int m = m0 + r;
+                    if (m < p.M)
+                        *reinterpret_cast<uint4*>(p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const uint4*>(smem + r * G_IMG_LD + chunk * 16);
+                }
             }
         }
     }

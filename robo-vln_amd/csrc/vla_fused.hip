@@ -11,8 +11,13 @@
 // leave the CU between these steps: attention output, x1 and the 256-wide slices of the 1024-wide FFN intermediate live in LDS as
 // 16-bit MFMA operands (rows padded to 528 B: conflict-free fragment reads), the two LayerNorms reduce over the 8 waves through a
 // small LDS table, the FFN runs in four 256-column slices (slice c of fc1 feeds k-range c of fc2, accumulated in registers).  Weights
-// are the MFMA A operand and stream straight from L2 into fragment registers (1 MB per layer, shared by all workgroups); a lane's
-// accumulator holds 4 consecutive channels of one token, as everywhere in this library.
+// are the MFMA A operand: the layer's 1.15 MB travel L2 -> LDS as ONE stream of 36 K tiles (256 output rows x 64 k = 32 KB each: fc_o,
+// then per slice fc1[c] and fc2[:, c]) by `buffer_load ... lds` into a 2 x 32 KB ring, a tile ahead of its use across the GEMM
+// boundaries (XOR-swizzled 128-B rows as in igemm.hip); a lane's accumulator holds 4 consecutive channels of one token, as everywhere
+// in this library.  (First version: weight fragments as plain global loads of 16 rows x 64 B per instruction -- 80 us per launch at
+// B = 64, bound by the texture-address path; staged through LDS in full 128-B rows, with the
+// in-kernel attention on MFMA, the same launch takes 42 us: ~19 of them are the weight stream itself at the ~62 GB/s one CU draws from L2
+// -- every workgroup needs all 1.15 MB -- 3.6 the attention, ~13 the LayerNorm / epilogue / store phases, 6.5 launch + operand staging.)
 //
 // Against the seven launches it replaces (attention, fc_o, LayerNorm, fc1, fc2, LayerNorm, mean) the GEMMs use the same MFMA
 // instruction over the same k order on the same rounded operands; the LayerNorm / mean reductions have a different (fixed) order, so
@@ -40,7 +45,21 @@ template <> struct VMma<f16> {
 
 constexpr int V_D = 256, V_RB = 80, V_MF = 5, V_LDA = 528;          // model width, rows per workgroup, 16-row fragments, LDS row bytes
 constexpr int V_KVMAX = 32;                                         // keys of the in-kernel attention
-constexpr size_t V_LDS = (size_t)2 * V_RB * V_LDA + (size_t)V_KVMAX * 1024 + (size_t)8 * V_RB * 2 * sizeof(float);
+constexpr int V_WT = 32768;                                         // one weight K tile: 256 rows x 128 B
+constexpr size_t V_LDS = (size_t)2 * V_RB * V_LDA + (size_t)8 * V_RB * 2 * sizeof(float) + (size_t)2 * V_WT;      // K|V overlays the x1 buffer
+static_assert((size_t)4 * 32 * 128 + (size_t)4 * 64 * 36 * 2 <= (size_t)V_RB * V_LDA, "K and V^T staging must fit the x1 buffer");
+typedef int v_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void v_dma16(unsigned lds_addr, unsigned voff, v_v4i rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ v_v4i v_make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    v_v4i r;
+    r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu); r[2] = (int)bytes; r[3] = 0x00020000;
+    return r;
+}
 
 template <typename T> __device__ __forceinline__ void v_st4(char* p, const float (&v)[4]) {
     T o[4];
@@ -56,35 +75,30 @@ template <typename T> __device__ __forceinline__ void v_ld4(const char* p, float
     for (int e = 0; e < 4; ++e) v[e] = Tr<T>::ld(&o[e]);
 }
 
-// acc[i][j] += W[n = nbase + i*16 + fr][k0 + ks*32 + fg*8 ..] x A[row j*16 + fr][ks*32 + fg*8 ..] for ks = 0..7 (256 of K).
-// All 16 weight fragments of the call are requested up front (64 VGPRs): the loads are L2 hits of ~500 cycles each, and issued one k-step
-// at a time they were the kernel's critical path (82 us per launch; MFMA work is 11 us).
+// One weight K tile (in LDS, swizzled 128-B rows) x the matching 64 columns of the activation block: 2 k-steps of 32
 template <typename T>
-__device__ __forceinline__ void v_wload(uint4 (&wf)[8][2], const T* __restrict__ W, int ldw, int nbase, int k0, int fr, int fg) {
+__device__ __forceinline__ void v_mma_tile(v_f32x4 (&acc)[2][V_MF], const char* sw, const char* sAct, int kt, int nb, int fr, int fg) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 wf[2], xf[V_MF];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wf[ks][i] = *reinterpret_cast<const uint4*>(W + (size_t)(nbase + i * 16 + fr) * ldw + k0 + ks * 32 + fg * 8);
-}
-template <typename T>
-__device__ __forceinline__ void v_mma256(v_f32x4 (&acc)[2][V_MF], const uint4 (&wf)[8][2], const char* sA, int fr, int fg) {
+        for (int i = 0; i < 2; ++i) {
+            const int r = nb + i * 16 + fr;
+            wf[i] = *reinterpret_cast<const uint4*>(sw + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+        }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        uint4 xf[V_MF];
-#pragma unroll
-        for (int j = 0; j < V_MF; ++j) xf[j] = *reinterpret_cast<const uint4*>(sA + (j * 16 + fr) * V_LDA + (ks * 32 + fg * 8) * 2);
+        for (int j = 0; j < V_MF; ++j) xf[j] = *reinterpret_cast<const uint4*>(sAct + (j * 16 + fr) * V_LDA + (kt * 64 + ks * 32 + fg * 8) * 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < V_MF; ++j) VMma<T>::run(acc[i][j], wf[ks][i], xf[j]);
+            for (int j = 0; j < V_MF; ++j) VMma<T>::run(acc[i][j], wf[i], xf[j]);
     }
 }
 
 // LayerNorm over the 256 channels of every row of the block: a lane holds v[i][j][e] = channel wave*32 + i*16 + fg*4 + e of row j*16 + fr.
 // Per row: sums over the lane's 8 values -> the 4 lane groups (xor 16, 32) -> the 8 waves through sRed; fixed order, no atomics.
 template <typename T>
-__device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float* __restrict__ gamma, const float* __restrict__ beta, float* sRed, int wave,
-                                            int fr, int fg) {
+__device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float4 (&gg)[2], const float4 (&bb)[2], float* sRed, int wave, int fr, int fg) {
 #pragma unroll
     for (int j = 0; j < V_MF; ++j) {
         float a = 0.f, q = 0.f;
@@ -100,9 +114,8 @@ __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float*
     float g4[2][4], b4[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + wave * 32 + i * 16 + fg * 4), b = *reinterpret_cast<const float4*>(beta + wave * 32 + i * 16 + fg * 4);
-        g4[i][0] = g.x; g4[i][1] = g.y; g4[i][2] = g.z; g4[i][3] = g.w;
-        b4[i][0] = b.x; b4[i][1] = b.y; b4[i][2] = b.z; b4[i][3] = b.w;
+        g4[i][0] = gg[i].x; g4[i][1] = gg[i].y; g4[i][2] = gg[i].z; g4[i][3] = gg[i].w;
+        b4[i][0] = bb[i].x; b4[i][1] = bb[i].y; b4[i][2] = bb[i].z; b4[i][3] = bb[i].w;
     }
 #pragma unroll
     for (int j = 0; j < V_MF; ++j) {
@@ -119,83 +132,175 @@ __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float*
     __syncthreads();                 // sRed may be written again
 }
 
+template <typename T> __device__ __forceinline__ uint32_t v_pack2(float a, float b) {
+    T t[2];
+    Tr<T>::st(&t[0], a);
+    Tr<T>::st(&t[1], b);
+    return (uint32_t)t[0].v | ((uint32_t)t[1].v << 16);
+}
+
+// softmax(Q K^T / 8) V for the block's 80 rows over Lk <= 32 keys, 4 heads of 64, on MFMA -- the scheme of attention_mfma_kernel
+// (attention.hip): transposed scores S^T = K Q^T (A operand = K rows from LDS, B operand = Q rows from global), so a lane holds 4 keys of
+// ONE query per 16-key tile and the softmax reduces in registers plus two cross-lane steps; the exponentiated scores are already in
+// A-operand position for P.V (V staged transposed).  Units of (head, 16-query tile) are dealt round-robin to the 8 waves; the output goes
+// to the LDS operand image sA instead of global memory.  sK: [4 heads][32 keys][64] T, 128-B rows with the chunk index XOR (row & 7);
+// sVt: [4 heads][64][36] T.  Rows / keys beyond nrow / Lk: zeros in, nothing out of range read.
+template <typename T>
+__device__ __forceinline__ void v_attention_mfma(const T* __restrict__ q, const T* __restrict__ kv, int Lk, int nrow, char* sK, T* sVt, char* sA, int tid) {
+    constexpr int VS = 36;
+    // stage K (swizzled rows) and V^T for all four heads; keys >= Lk are zero
+    for (int e = tid; e < 4 * 32 * 8; e += 512) {
+        const int c = e & 7, row = (e >> 3) & 31, h = e >> 8;
+        uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < Lk) {
+            kk = *reinterpret_cast<const uint4*>(kv + (size_t)row * 512 + h * 64 + c * 8);
+            vv = *reinterpret_cast<const uint4*>(kv + (size_t)row * 512 + 256 + h * 64 + c * 8);
+        }
+        *reinterpret_cast<uint4*>(sK + (h * 32 + row) * 128 + ((c ^ (row & 7)) << 4)) = kk;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T t;
+            t.v = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+            sVt[(size_t)(h * 64 + c * 8 + j) * VS + row] = t;
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    for (int unit = wave; unit < 4 * V_MF; unit += 8) {
+        const int h = unit / V_MF, qt = unit - h * V_MF;
+        int qrow = qt * 16 + fr;
+        if (qrow >= nrow) qrow = nrow - 1;                       // clamped: garbage for rows that are zeroed below
+        const T* qp = q + (size_t)qrow * V_D + h * 64;
+        const uint4 q0 = *reinterpret_cast<const uint4*>(qp + fg * 8);
+        const uint4 q1 = *reinterpret_cast<const uint4*>(qp + 32 + fg * 8);
+        v_f32x4 sc[2];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = t * 16 + fr;
+            const char* kr = sK + (h * 32 + r) * 128;
+            const uint4 k0 = *reinterpret_cast<const uint4*>(kr + (((0 + fg) ^ (r & 7)) << 4));
+            const uint4 k1 = *reinterpret_cast<const uint4*>(kr + (((4 + fg) ^ (r & 7)) << 4));
+            sc[t] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
+            VMma<T>::run(sc[t], k0, q0);
+            VMma<T>::run(sc[t], k1, q1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = t * 16 + fg * 4 + e;
+                const float sv = key < Lk ? sc[t][e] * 0.125f : -3.0e38f;          // 1 / sqrt(64); padded keys masked
+                sc[t][e] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float pv = __expf(sc[t][e] - mx); sc[t][e] = pv; sum += pv; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        uint4 pa;
+        pa.x = v_pack2<T>(sc[0][0], sc[0][1]); pa.y = v_pack2<T>(sc[0][2], sc[0][3]);
+        pa.z = v_pack2<T>(sc[1][0], sc[1][1]); pa.w = v_pack2<T>(sc[1][2], sc[1][3]);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int dtile = 0; dtile < 4; ++dtile) {
+            const T* vr = sVt + (size_t)(h * 64 + dtile * 16 + fr) * VS + fg * 4;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+            v_f32x4 o = (v_f32x4){0.f, 0.f, 0.f, 0.f};
+            VMma<T>::run(o, pa, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            // o[e] belongs to query qt*16 + fg*4 + e, column dtile*16 + fr; its normaliser lives in lane (fg*4 + e)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float inv_q = __shfl(inv, fg * 4 + e, 64);
+                const int row = qt * 16 + fg * 4 + e;
+                T ov;
+                Tr<T>::st(&ov, row < nrow ? o[e] * inv_q : 0.f);
+                *reinterpret_cast<T*>(sA + row * V_LDA + (h * 64 + dtile * 16 + fr) * 2) = ov;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                   // attention output, later the FFN intermediate slice, last the output image
     char* sX = smem + V_RB * V_LDA;                    // x1 = LayerNorm(I + att Wo^T)
-    char* sKV = sX + V_RB * V_LDA;                     // K | V of the in-kernel attention: [Lk][512] T
-    float* sRed = reinterpret_cast<float*>(sKV + V_KVMAX * 1024);
+    char* sKV = sX;                                    // K | V of the in-kernel attention: [Lk][512] T (dead before x1 is written)
+    float* sRed = reinterpret_cast<float*>(sX + V_RB * V_LDA);
+    char* sW = reinterpret_cast<char*>(sRed) + 8 * V_RB * 2 * sizeof(float);      // weight K-tile ring: 2 x 32 KB
     const int st = blockIdx.y;
     const int nblk = (p.L + V_RB - 1) / V_RB;
     const int b = blockIdx.x / nblk, r0 = (blockIdx.x - b * nblk) * V_RB;
     const int nrow = p.L - r0 < V_RB ? p.L - r0 : V_RB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
     const T* q = reinterpret_cast<const T*>(p.q) + ((size_t)b * p.L + r0) * V_D;
     const T* I = reinterpret_cast<const T*>(p.I) + ((size_t)b * p.L + r0) * V_D;
     T* out = reinterpret_cast<T*>(p.out[st]) + ((size_t)b * p.L + r0) * V_D;
 
     const int nb = wave * 32;                          // this wave's 32 output channels of every 256-wide GEMM
-    uint4 wf[8][2];
-    v_wload<T>(wf, reinterpret_cast<const T*>(p.wo), V_D, nb, 0, fr, fg);      // fc_o's fragments travel while the attention runs
+    // ---- the layer's weights as one stream of K tiles: tile t < 4: fc_o k-range t; then per 256-column slice c of the FFN four tiles
+    // of fc1 rows [256c, 256c+256) and four tiles of fc2 k-range [256c + 64v, +64)
+    const int nslice = p.d_ff / 256;
+    const int n_tiles = 4 + 8 * nslice;
+    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sW;
+    const v_v4i r_o = v_make_rsrc(p.wo, 256u * 256u * 2u), r_1 = v_make_rsrc(p.w1, (unsigned)p.d_ff * 256u * 2u), r_2 = v_make_rsrc(p.w2, 256u * (unsigned)p.d_ff * 2u);
+    const int rin = lane >> 3, csrc = (lane & 7) ^ rin;
+    auto dma_tile = [&](int t) {
+        if (t >= n_tiles) return;
+        const unsigned dst = lds_w + (unsigned)(t & 1) * V_WT;
+        int row0 = 0, k0 = t * 64, ld = 256, which = 0;
+        if (t >= 4) {
+            const int u = t - 4, c = u >> 3, v8 = u & 7;
+            if (v8 < 4) { which = 1; row0 = c * 256; k0 = v8 * 64; ld = 256; }
+            else { which = 2; row0 = 0; k0 = c * 256 + (v8 - 4) * 64; ld = p.d_ff; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave * 4 + i;                                         // 8-row piece of the 256-row tile
+            const unsigned off = (unsigned)((row0 + q * 8 + rin) * ld + k0 + csrc * 8) * 2u;
+            if (which == 0) v_dma16(dst + q * 1024, off, r_o); else if (which == 1) v_dma16(dst + q * 1024, off, r_1); else v_dma16(dst + q * 1024, off, r_2);
+        }
+    };
+    int wt = 0;                                        // next tile to consume
+    // consume tile `wt` against columns [64 kt, +64) of the activation block; the following tile is requested first and has landed
+    // (every wave's pieces: vmcnt(0) + barrier) when the call returns
+    auto w_step = [&](v_f32x4 (&acc)[2][V_MF], const char* sAct, int kt) {
+        if (!(p.dbg & 2)) dma_tile(wt + 1);
+        if (!(p.dbg & 4)) v_mma_tile<T>(acc, sW + (wt & 1) * V_WT, sAct, kt, nb, fr, fg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++wt;
+    };
+    dma_tile(0);                                       // fc_o's first tile travels while the attention runs
+    // Every small per-channel vector this lane will need (biases, LayerNorm gains) and its residual rows of I are requested NOW: left at
+    // their points of use they were ~10 dependent L2 / HBM round trips on the workgroup's critical path (25 us of an otherwise empty kernel).
+    float4 p_bo[2], p_b2[2], p_g1[2], p_be1[2], p_g2[2], p_be2[2], p_b1[2];
+    uint2 p_res[2][V_MF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = nb + i * 16 + fg * 4;
+        p_bo[i] = *reinterpret_cast<const float4*>(p.bo + n); p_b2[i] = *reinterpret_cast<const float4*>(p.b2 + n);
+        p_g1[i] = *reinterpret_cast<const float4*>(p.g1 + n); p_be1[i] = *reinterpret_cast<const float4*>(p.be1 + n);
+        p_g2[i] = *reinterpret_cast<const float4*>(p.g2 + n); p_be2[i] = *reinterpret_cast<const float4*>(p.be2 + n);
+        p_b1[i] = *reinterpret_cast<const float4*>(p.b1 + n);
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) {
+            const int row = j * 16 + fr;
+            p_res[i][j] = make_uint2(0u, 0u);
+            if (row < nrow) p_res[i][j] = *reinterpret_cast<const uint2*>(I + (size_t)row * V_D + n);
+        }
+    }
     // ---- attention output of the block into sA (rows >= nrow: zeros)
     if (p.fuse_att) {
         const int Lk = p.Lk[st];
         const T* kv = reinterpret_cast<const T*>(p.kv[st]) + (size_t)b * Lk * 512;
-        for (int e = tid; e < Lk * 64; e += 512)
-            *reinterpret_cast<uint4*>(sKV + e * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(kv) + (size_t)e * 16);
-        __syncthreads();
-        for (int task = tid; task < V_RB * 4; task += 512) {
-            const int row = task >> 2, head = task & 3;
-            float o[64];
-#pragma unroll
-            for (int d = 0; d < 64; ++d) o[d] = 0.f;
-            if (row < nrow) {
-                float qv[64];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float t8[8];
-                    ld_chunk(q + (size_t)row * V_D + head * 64 + c * 8, t8);
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) qv[c * 8 + d] = t8[d] * 0.125f;               // 1 / sqrt(64)
-                }
-                // online softmax over the (few) keys: running maximum m, normaliser l, un-normalised output o
-                float m = -3.0e38f, l = 0.f;
-                for (int k = 0; k < Lk; ++k) {
-                    const T* kp = reinterpret_cast<const T*>(sKV + k * 1024) + head * 64;
-                    float s = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float t8[8];
-                        ld_chunk(kp + c * 8, t8);
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) s += qv[c * 8 + d] * t8[d];
-                    }
-                    const float mn = fmaxf(m, s);
-                    const float alpha = __expf(m - mn), pk = __expf(s - mn);
-                    l = l * alpha + pk;
-                    const T* vp = kp + 256;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float t8[8];
-                        ld_chunk(vp + c * 8, t8);
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) o[c * 8 + d] = o[c * 8 + d] * alpha + pk * t8[d];
-                    }
-                    m = mn;
-                }
-                const float inv = 1.0f / l;
-#pragma unroll
-                for (int d = 0; d < 64; ++d) o[d] *= inv;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float t8[8];
-#pragma unroll
-                for (int d = 0; d < 8; ++d) t8[d] = o[c * 8 + d];
-                st_chunk(reinterpret_cast<T*>(sA + row * V_LDA) + head * 64 + c * 8, t8);
-            }
-        }
+        if (!(p.dbg & 1)) v_attention_mfma<T>(q, kv, Lk, nrow, sKV, reinterpret_cast<T*>(sKV + 4 * 32 * 128), sA, tid);
     } else {
         const T* att = reinterpret_cast<const T*>(p.att[st]) + ((size_t)b * p.L + r0) * V_D;
         for (int e = tid; e < V_RB * 32; e += 512) {
@@ -205,7 +310,9 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             *reinterpret_cast<uint4*>(sA + row * V_LDA + c * 16) = v;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.dbg & 16) return;
 
     float v[2][V_MF][4];
     // ---- x1 = LayerNorm(I + att Wo^T + bo)
@@ -215,28 +322,27 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) acc[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
-        v_mma256<T>(acc, wf, sA, fr, fg);
-        v_wload<T>(wf, reinterpret_cast<const T*>(p.w1), V_D, nb, 0, fr, fg);   // fc1 slice 0: in flight during the LayerNorm
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) w_step(acc, sA, kt);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int n = nb + i * 16 + fg * 4;
-            const float4 bb = *reinterpret_cast<const float4*>(p.bo + n);
+            const float4 bb = p_bo[i];
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) {
-                const int row = j * 16 + fr;
-                float r4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (row < nrow) v_ld4<T>(reinterpret_cast<const char*>(I + (size_t)row * V_D + n), r4);
+                float r4[4];
+                v_ld4<T>(reinterpret_cast<const char*>(&p_res[i][j]), r4);
                 v[i][j][0] = acc[i][j][0] + bb.x + r4[0]; v[i][j][1] = acc[i][j][1] + bb.y + r4[1];
                 v[i][j][2] = acc[i][j][2] + bb.z + r4[2]; v[i][j][3] = acc[i][j][3] + bb.w + r4[3];
             }
         }
     }
-    v_layernorm<T>(v, p.g1, p.be1, sRed, wave, fr, fg);
+    v_layernorm<T>(v, p_g1, p_be1, sRed, wave, fr, fg);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) v_st4<T>(sX + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, v[i][j]);
     __syncthreads();
+    if (p.dbg & 32) return;
 
     // ---- FFN in 256-column slices of the intermediate: H_c = relu(x1 W1[c]^T + b1[c]) (-> sA), acc2 += H_c W2[:, c]^T
     v_f32x4 acc2[2][V_MF];
@@ -244,18 +350,22 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) acc2[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nslice = p.d_ff / 256;
     for (int c = 0; c < nslice; ++c) {
         v_f32x4 acc1[2][V_MF];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) acc1[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
-        v_mma256<T>(acc1, wf, sX, fr, fg);
-        v_wload<T>(wf, reinterpret_cast<const T*>(p.w2), p.d_ff, nb, c * 256, fr, fg);   // fc2 k-range c: in flight during the ReLU epilogue + barrier
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) w_step(acc1, sX, kt);
+        float4 b1c[2] = {p_b1[0], p_b1[1]};
+        if (c + 1 < nslice) {                          // the next slice's fc1 bias: requested a slice ahead
+#pragma unroll
+            for (int i = 0; i < 2; ++i) p_b1[i] = *reinterpret_cast<const float4*>(p.b1 + (c + 1) * 256 + nb + i * 16 + fg * 4);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.b1 + c * 256 + nb + i * 16 + fg * 4);
+            const float4 bb = b1c[i];
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) {
                 const float h[4] = {fmaxf(acc1[i][j][0] + bb.x, 0.f), fmaxf(acc1[i][j][1] + bb.y, 0.f), fmaxf(acc1[i][j][2] + bb.z, 0.f),
@@ -264,15 +374,15 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             }
         }
         __syncthreads();
-        v_mma256<T>(acc2, wf, sA, fr, fg);
-        if (c + 1 < nslice) v_wload<T>(wf, reinterpret_cast<const T*>(p.w1), V_D, (c + 1) * 256 + nb, 0, fr, fg);
-        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) w_step(acc2, sA, kt);         // (its last barrier also frees sA for the next slice)
     }
+    if (p.dbg & 64) return;
     // ---- out = LayerNorm(x1 + ffn + b2)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = nb + i * 16 + fg * 4;
-        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + n);
+        const float4 bb = p_b2[i];
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) {
             float r4[4];
@@ -281,7 +391,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             v[i][j][2] = acc2[i][j][2] + bb.z + r4[2]; v[i][j][3] = acc2[i][j][3] + bb.w + r4[3];
         }
     }
-    v_layernorm<T>(v, p.g2, p.be2, sRed, wave, fr, fg);
+    v_layernorm<T>(v, p_g2, p_be2, sRed, wave, fr, fg);
     // rounded output -> LDS image -> 16-byte row stores; pooled mean over the instruction's own tokens from the rounded values
     int len = p.L;
     if (p.lens) { len = p.lens[b]; len = len < 1 ? 1 : len > p.L ? p.L : len; }
@@ -340,6 +450,8 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
         attr_done = true;
     }
     VlaPost q = p;
+    static const int dbg = getenv("HCM_VLA_DBG") ? atoi(getenv("HCM_VLA_DBG")) : 0;      // timing experiments (results then wrong)
+    q.dbg = dbg;
     void* args[] = {&q};
     const int nblk = (p.L + V_RB - 1) / V_RB;
     return hipLaunchKernel(fn, dim3(p.B * nblk, p.streams), dim3(512), args, V_LDS, s);

@@ -520,3 +520,67 @@ def test_gemm256_rejects_shapes_it_does_not_cover():
     y = torch.zeros(64, 768, device="cuda", dtype=torch.float16)
     assert lib.hcm_op_linear_impl(_p(x), _p(w), None, None, _p(y), 5, 64, 768, 768, 0, 0, 2, None) == -1       # too small: not applicable
     assert lib.hcm_op_linear_impl(_p(x), _p(w), None, None, _p(y), 5, 64, 768, 768, 0, 0, 0, None) == 0        # the library's choice still works
+
+
+def _vla_layer_ref(q, I, kv, att, W, L, lens):
+    """torch fp32 restatement of one cross-modal layer on 16-bit-rounded inputs (transformer.py:81-126,:25-43,:209-221)."""
+    B = I.shape[0]
+    if kv is not None:
+        Lk = kv.shape[1]
+        qh = q.view(B, L, 4, 64).permute(0, 2, 1, 3)
+        kh = kv[..., :256].reshape(B, Lk, 4, 64).permute(0, 2, 3, 1)
+        vh = kv[..., 256:].reshape(B, Lk, 4, 64).permute(0, 2, 1, 3)
+        a = torch.softmax(qh @ kh / 8.0, -1) @ vh
+        att = a.permute(0, 2, 1, 3).reshape(B, L, 256)
+    x1 = F.layer_norm(I + att @ W["wo"].t() + W["bo"], (256,), W["g1"], W["be1"], 1e-5)
+    y = F.layer_norm(x1 + F.relu(x1 @ W["w1"].t() + W["b1"]) @ W["w2"].t() + W["b2"], (256,), W["g2"], W["be2"], 1e-5)
+    if lens is None:
+        pooled = y.mean(1)
+    else:
+        pooled = torch.stack([y[b, :int(lens[b])].mean(0) for b in range(B)])
+    return y, pooled
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,L,Lk,fuse,ragged", [(3, 80, (16, 16), True, False), (2, 37, (16, 4), True, True), (2, 100, None, False, False), (5, 20, (1, 32), True, False)])
+def test_fused_cross_modal_layer_op(prec, B, L, Lk, fuse, ragged):
+    """vla_fused.hip through hcm_op_vla_layer against a torch fp32 restatement: in-kernel attention over 1-32 keys or a given attention
+    output, both streams, two row blocks (L = 100), ragged pooled mean."""
+    lib, Lm = _lib()
+    code, tdt, tol = DT[prec]
+    d, dff = 256, 1024
+    W = {"wo": _rnd(d, d, seed=1) * (3.0 / d) ** 0.5, "w1": _rnd(dff, d, seed=2) * (3.0 / d) ** 0.5, "w2": _rnd(d, dff, seed=3) * (3.0 / dff) ** 0.5,
+         "bo": _rnd(d, seed=4) * 0.1, "b1": _rnd(dff, seed=5) * 0.1, "b2": _rnd(d, seed=6) * 0.1,
+         "g1": _rnd(d, seed=7) * 0.5 + 1.0, "be1": _rnd(d, seed=8) * 0.1, "g2": _rnd(d, seed=9) * 0.5 + 1.0, "be2": _rnd(d, seed=10) * 0.1}
+    for k in ("wo", "w1", "w2"):
+        W[k] = W[k].to(tdt).float()
+    I = _rnd(B, L, d, seed=11).to(tdt).float()
+    q = _rnd(B, L, d, seed=12).to(tdt).float()
+    lens = torch.tensor([L, max(1, L // 3), L - 1, 2, L][:B], dtype=torch.int32) if ragged else None
+    dev = lambda t, dt=None: t.to("cuda", dt if dt is not None else tdt).contiguous()
+    Wd = {k: dev(v, tdt if k in ("wo", "w1", "w2") else torch.float32) for k, v in W.items()}
+    Id, qd = dev(I), dev(q)
+    outs = [torch.full((B, L, d), float("nan"), device="cuda", dtype=tdt) for _ in range(2)]
+    pooled = [torch.full((B, 300), float("nan"), device="cuda") for _ in range(2)] if L <= 80 else None
+    refs, ins = [], []
+    for s_ in range(2):
+        if fuse:
+            kv = _rnd(B, Lk[s_], 512, seed=20 + s_).to(tdt).float()
+            refs.append(_vla_layer_ref(q, I, kv, None, W, L, lens)); ins.append(dev(kv))
+        else:
+            att = _rnd(B, L, d, seed=30 + s_).to(tdt).float()
+            refs.append(_vla_layer_ref(q, I, None, att, W, L, lens)); ins.append(dev(att))
+    arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    rc = lib.hcm_op_vla_layer(_p(qd), _p(Id), arr(ins) if fuse else None, (C.c_int * 2)(*Lk) if fuse else None, None if fuse else arr(ins), arr(outs),
+                              arr([p[:, 17:] for p in pooled]) if pooled else None, 300, _p(Wd["wo"]), _p(Wd["bo"]), _p(Wd["w1"]), _p(Wd["b1"]), _p(Wd["w2"]),
+                              _p(Wd["b2"]), _p(Wd["g1"]), _p(Wd["be1"]), _p(Wd["g2"]), _p(Wd["be2"]), _p(lens.cuda()) if ragged else None, code, B, L, dff, 2, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for s_ in range(2):
+        y, pm = refs[s_]
+        err = (outs[s_].float().cpu() - y).abs().max().item()
+        assert err <= (3e-2 if prec == "bf16" else 6e-3), (s_, err)           # LayerNorm outputs of magnitude ~3 in 16-bit storage
+        if pooled:
+            perr = (pooled[s_][:, 17:17 + d].cpu() - pm).abs().max().item()
+            assert perr <= (8e-3 if prec == "bf16" else 2e-3), (s_, perr)
+            assert torch.isnan(pooled[s_][:, :17]).all() and torch.isnan(pooled[s_][:, 17 + d:]).all()      # nothing written outside its columns
