@@ -784,6 +784,8 @@ int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias,
                            void* stream) {
     const int dt = op_dt(dtype);
     if (!scratch || dt == DT_F32 || H % 4 || H < 8) return HCM_ERR_ARG;
+    static const bool no_direct = getenv("HCM_NO_DEPTH_CONV0") != nullptr;       // A/B aid: the convert + implicit-GEMM route
+    if (!no_direct && depth_conv8x8s4_ok(dt, H, act)) return op_rc(launch_depth_conv8x8s4(depth, w, bias, y, dt, B, H, act, (hipStream_t)stream));
     int rc = op_rc(launch_convert_from_f32(depth, scratch, dt, (size_t)B * H * H, (hipStream_t)stream));
     if (rc != HCM_OK) return rc;
     const int h1 = (H - 8) / 4 + 1;

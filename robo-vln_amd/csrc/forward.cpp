@@ -364,8 +364,13 @@ struct Fwd {
             // pixel is then one contiguous run of 8 pixels and the conv an ordinary LDS-DMA implicit GEMM over "virtual
             // pixels" of 4 real ones (the stride): KH = 8, KW = 1, Cin = 8*cp, pixel stride 4*cp elements
             const int cp = w.cin == 3 ? 4 : 1;
-            void* pk = alloc_t((size_t)B * H * H * cp + 64);
-            if (!dry) {
+            static const bool no_direct = getenv("HCM_NO_DEPTH_CONV0") != nullptr;
+            const bool direct = cp == 1 && !no_direct && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 && depth_conv8x8s4_ok(dt, H, ACT_RELU);
+            void* pk = direct ? nullptr : alloc_t((size_t)B * H * H * cp + 64);
+            if (direct) {
+                // depth: one pass over the raw f32 frame (simplecnn.hip), bit-identical to convert + implicit GEMM
+                if (!dry) ck(launch_depth_conv8x8s4((const float*)x, w.c0_packed.w, w.c0_packed.bias, y0, dt, B, H, ACT_RELU, s), "simple cnn conv0 (direct)");
+            } else if (!dry) {
                 if (cp == 4) ck(launch_pack_frame(x, x_dt, pk, dt, B, H, H, scale, s, 0), "pack frame");
                 else ck(launch_convert_from_f32((const float*)x, pk, dt, (size_t)B * H * H, s), "depth convert");
                 IGemm g;

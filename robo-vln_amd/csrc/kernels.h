@@ -188,6 +188,9 @@ hipError_t launch_absmax(const void* x, int dt, int rows, int cols, int ld, unsi
 // generic converts
 hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s);
 hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s);
+// simplecnn.hip: Conv2d(1, 32, 8, stride 4) + bias + activation from the raw f32 depth frame (B,H,H,1), w = [32][64] in the 16-bit storage type
+bool depth_conv8x8s4_ok(int dt, int H, int act);
+hipError_t launch_depth_conv8x8s4(const float* x, const void* w, const float* bias, void* y, int dt, int B, int H, int act, hipStream_t s);
 // storage-type conversion between sub-networks (e.g. fp16 depth tokens -> bf16 cross-modal block)
 hipError_t launch_convert(const void* x, int dt_in, void* y, int dt_out, size_t n, hipStream_t s);
 

@@ -117,6 +117,20 @@ def test_config3_full_size_probe(precision):
         g_out = gp.forward(d_dev, i_dev)
         torch.cuda.synchronize()
         assert torch.equal(g_out, out)
+    # more distinct input buffers than the in-place captures: the remaining ones go through the static-input graph
+    keep = []
+    for k in range(gp._INPLACE + 2):
+        dk, ik = d_dev.clone(), i_dev.clone()
+        keep.append((dk, ik))
+        g_out = gp.forward(dk, ik)
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, out), k
+    assert (B,) in gp._graphs
+    # the one-launch cross-modal layer against the launch-per-op form: LayerNorm reduction order only
+    up = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=precision, fused_layer=False, overlap=False)
+    u_out = up.forward(d_dev, i_dev)
+    torch.cuda.synchronize()
+    assert (u_out.float() - out.float()).abs().max().item() <= (1.6e-2 if precision == "fp16" else 6.4e-2)      # a few ulps at |x| ~ 4
 
 
 def test_config3_encoder_low_level_model_full_size():

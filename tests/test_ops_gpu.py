@@ -584,3 +584,32 @@ def test_fused_cross_modal_layer_op(prec, B, L, Lk, fuse, ragged):
             perr = (pooled[s_][:, 17:17 + d].cpu() - pm).abs().max().item()
             assert perr <= (8e-3 if prec == "bf16" else 2e-3), (s_, perr)
             assert torch.isnan(pooled[s_][:, :17]).all() and torch.isnan(pooled[s_][:, 17 + d:]).all()      # nothing written outside its columns
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 256, 1), (3, 36, 1), (1, 8, 0), (5, 100, 1), (2, 64, 0)])
+def test_depth_conv8x8s4_direct(prec, cfg):
+    """SimpleDepthCNN's first layer straight from the raw f32 frame (simplecnn.hip) vs torch on the storage-rounded operands, incl. frames
+    whose last row block is partial (36 -> 8 rows, 100 -> 24), the single-pixel map (8 -> 1x1) and first / last pixels of the tensor; and
+    bit for bit against the element-wise gather route (hcm_op_stem_conv) it replaces."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, relu = cfg
+    x = torch.rand(B, H, H, 1, generator=torch.Generator().manual_seed(H)) * 3.0
+    w = (_rnd(32, 1, 8, 8, seed=4) * (3.0 / 64) ** 0.5).to(tdt).float()
+    bias = _rnd(32, seed=5)
+    ref = F.conv2d(x.to(tdt).float().permute(0, 3, 1, 2), w, bias, stride=4)
+    if relu:
+        ref = F.relu(ref)
+    h1 = ref.shape[2]
+    wd, bd, xd = w.permute(0, 2, 3, 1).reshape(32, 64).to(tdt).cuda(), bias.cuda(), x.cuda()
+    y = torch.full((B, h1, h1, 32), float("nan"), device="cuda", dtype=tdt)
+    scratch = torch.empty(B * H * H + 64, device="cuda", dtype=tdt)
+    act = L.ACT_RELU if relu else L.ACT_NONE
+    assert lib.hcm_op_depth_conv8x8s4(_p(xd), _p(wd), _p(bd), _p(y), code, B, H, act, _p(scratch), None) == 0
+    y2 = torch.full_like(y, float("nan"))
+    assert lib.hcm_op_stem_conv(_p(xd), L.HCM_F32, _p(wd), _p(bd), _p(y2), code, B, H, H, 1, 32, 8, 8, 4, 0, 64, 64, 0, 1.0, act, None) == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(y, y2)

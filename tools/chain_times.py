@@ -1,0 +1,27 @@
+"""Which encoder chain bounds the step: act() at B=64 with chains dropped (HCM_SKIP bit mask of `make DEV=1` builds: 1|2 RGB trunks,
+4 depth trunks, 8 BERT), one sub-process per mask because the knob is read once.  usage: python tools/chain_times.py [B]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r"""
+import os, sys, time, torch
+sys.path.insert(0, %r)
+import hcm_pkg; hcm_pkg.load()
+from robo_vln_amd import synth
+from robo_vln_amd.config import HCMConfig
+from robo_vln_amd.policy import HCMEngine
+B = int(sys.argv[1]); cfg = HCMConfig().validate()
+hi, lo = synth.make_weights(cfg, seed=0)
+eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16", graph=True)
+obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, rgb_uint8=True).items()}
+R = cfg.num_recurrent_layers
+hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
+for _ in range(5): eng.act(obs, hh, lh, m)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(30): eng.act(obs, hh, lh, m)
+torch.cuda.synchronize(); print("%%.3f" %% ((time.perf_counter() - t0) / 30 * 1e3))
+""" % ROOT
+B = sys.argv[1] if len(sys.argv) > 1 else "64"
+for mask, what in [(0, "full step"), (3, "no RGB"), (4, "no depth"), (8, "no BERT"), (12, "RGB only"), (11, "depth only"), (7, "BERT only"), (15, "tail only")]:
+    env = dict(os.environ, HCM_DEV_LIB="1", HCM_SKIP=str(mask))
+    r = subprocess.run([sys.executable, "-c", CHILD, B], env=env, capture_output=True, text=True, cwd=ROOT)
+    print(f"HCM_SKIP={mask:2d} {what:12s}: {r.stdout.strip() or r.stderr[-300:]} ms")

@@ -13,7 +13,7 @@ cfg = HCMConfig(vla_layers=1).validate(); B, L = 256, cfg.instr_len
 cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, 256, 128), "probe_cnn", 0)
 vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
 tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[prec]
-probe = DepthCnnVlaProbe(cnn_sd, vla_sd, precision=prec)
+probe = DepthCnnVlaProbe(cnn_sd, vla_sd, precision=prec, fused_layer=os.environ.get("PROBE_UNFUSED") is None, overlap=os.environ.get("PROBE_SERIAL") is None, graph=os.environ.get("PROBE_GRAPH") is not None)
 depth = torch.rand(B, 256, 256, 1, device="cuda"); ins = (torch.rand(B, L, 768, device="cuda") * 2 - 1).to(tdt)
 for _ in range(3): out = probe.forward(depth, ins)
 torch.cuda.synchronize()
