@@ -175,6 +175,10 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank):
     from robo_vln_amd.policy import HCMEngine
     cfg = baseline_config(cfg_idx)
     B = args.batch or BATCH[cfg_idx]
+    if args.total_batch:                                      # strong scaling: the environments of ONE rollout split over the ranks
+        if args.total_batch % world:
+            raise SystemExit("--total-batch must be a multiple of the number of ranks")
+        B = args.total_batch // world
     hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank
     hi_only = cfg_idx == 4
     eng = HCMEngine(cfg, hi_sd, None if hi_only else lo_sd, max_batch=B, precision=args.precision, graph=not args.no_graph and not hi_only)
@@ -253,6 +257,8 @@ def main():
     ap.add_argument("--prewarm", type=int, default=40, help="untimed clock-ramp steps before the W warm-up steps (0 for profiler runs)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the additional sustained measurement reported as `sustained` (0 = skip)")
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the BASELINE size of the config)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: total environments, split evenly over the ranks (BASELINE configs[2]: 512); "
+                                                               "default 0 = weak scaling at --batch per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--reuse-instruction", action="store_true",
                     help="NOT the headline configuration: steps after the first skip BERT (instructions unchanged; hcm_act_ex flag)")
@@ -400,7 +406,7 @@ def main():
             "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr" if args.config == 1 else
                       f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
             "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None,
             "dtype": ("bf16+fp16 (16-bit MFMA, fp32 accumulate; DESIGN.md section 5)" if args.precision == "bf16" else "fp32") if args.config != 3
                      else (prec3 + " storage / MFMA, fp32 accumulate"),
             "data": "synthetic (random-init weights, random RGB-D frames and token ids, two observation sets resident in HBM used alternately)",

@@ -26,6 +26,11 @@ CASES = {
     # working ablation flags of both models (seq2seq_highlevel_cma.py:185-188, seq2seq_lowlevel.py:132-135)
     "ablate_depth_128": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2, ablate_depth=True), 2, 2, "both"),
     "ablate_rgb_128": (dict(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2, ablate_rgb=True), 2, 2, "both"),
+    # depth frames of 64*k pixels with k not a power of two: habitat's ResNetEncoder then has compression channel counts that are not a
+    # power of two -- 192 px -> 3x3 map x 228 channels, 320 px -> 5x5 x 82 (resnet_encoders.py:37-62)
+    "depth192_128": (dict(rgb_hw=128, depth_hw=192, instr_len=20, bert_layers=2), 2, 2, "both"),
+    "depth320_128": (dict(rgb_hw=128, depth_hw=320, instr_len=20, bert_layers=1), 1, 1, "both"),
+    "depth384_128": (dict(rgb_hw=128, depth_hw=384, instr_len=20, bert_layers=1), 1, 1, "both"),        # 6x6 x 57 (an odd count)
 }
 
 # The reference's eval loop feeds the model the UNPADDED token ids of the episode's instruction as a (1, L) tensor
@@ -118,6 +123,8 @@ CMA_CASES = {
     "cma_gru_uni_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, rnn_type="GRU", bidirectional=False), 3, 3),
     # full frame size, L=80
     "cma_256_L80": (dict(), 1, 2),
+    # 192-pixel depth frames: 3x3 map x 228 compression channels
+    "cma_depth192_L12": (dict(rgb_hw=128, depth_hw=192, instr_len=12), 2, 2),
 }
 
 

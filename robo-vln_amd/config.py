@@ -64,9 +64,10 @@ class HCMConfig:
         if self.d_model % self.vla_heads:
             raise ValueError("d_model must be divisible by h")
         if self.depth_encoder == "VlnResnetDepthEncoder":
-            k = self.depth_hw // 64
-            if self.depth_hw % 64 or k < 1 or (k & (k - 1)):
-                raise ValueError("depth frame size must be 64 * 2^k for the ResNet depth encoder (compression channels 2048 / (H/64)^2)")
+            # habitat's ResNetEncoder sizes its compression conv from (H // 2) / 32 (resnet_encoders.py:37-62): only multiples of 64
+            # give the map that formula predicts (192 -> 3x3 x 228 channels, 256 -> 4x4 x 128, 320 -> 5x5 x 82)
+            if self.depth_hw % 64 or not 64 <= self.depth_hw <= 1024:
+                raise ValueError("depth frame size must be a multiple of 64 for the ResNet depth encoder")
         return self
 
     @property

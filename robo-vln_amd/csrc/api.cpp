@@ -120,8 +120,8 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     REQUIRE(cfg->hidden == 512 || cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
     REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
     if (cfg->depth_encoder == HCM_ENC_RESNET)
-        REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && ((cfg->depth_h / 64) & (cfg->depth_h / 64 - 1)) == 0, HCM_ERR_UNSUPPORTED,
-                "depth frame size must be 64 * 2^k (the compression conv's channel count 2048 / (H/64)^2 must stay a multiple of 8)");
+        REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && cfg->depth_h <= 1024, HCM_ERR_UNSUPPORTED,
+                "depth frame size must be a multiple of 64 (habitat's ResNetEncoder: final map (H/2)/32, resnet_encoders.py:37-62)");
     if (cfg->rgb_encoder == HCM_ENC_RESNET)
         REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
@@ -172,8 +172,7 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
             "bad INSTRUCTION_ENCODER sizes");
     REQUIRE(cfg->instr_len >= 1 && cfg->instr_len <= 256, HCM_ERR_UNSUPPORTED, "1 <= instr_len <= 256");
     REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
-    REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && ((cfg->depth_h / 64) & (cfg->depth_h / 64 - 1)) == 0, HCM_ERR_UNSUPPORTED,
-            "depth frame size must be 64 * 2^k");
+    REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && cfg->depth_h <= 1024, HCM_ERR_UNSUPPORTED, "depth frame size must be a multiple of 64");
     REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
     REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0 && cfg->num_actions >= 1, HCM_ERR_UNSUPPORTED, "bad output sizes");

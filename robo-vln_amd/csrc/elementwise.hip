@@ -285,7 +285,7 @@ hipError_t launch_fill_cols(const float* tab, void* y, int dt, int B, int S, int
 // normalises, adds the residual, applies ReLU and stores.  No atomics, no memset, no stats buffer.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, int HW, int C, int G, int CS, float eps, int relu) {
+                                                        const float* __restrict__ beta, int HW, int C, int G, int CS, float eps, int relu, int cg_true) {
     constexpr int CH = Tr<T>::CH;
     __shared__ float s_p1[4][1024], s_p2[4][1024];                         // per-wave partials (fixed summation order)
     __shared__ float s_sum[1024], s_sq[1024], s_mean[1024], s_rstd[1024];  // per channel of the slab (CS <= 1024)
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
         const int g0 = (ch / Cg) * Cg;       // first channel of this channel's group (inside the slab)
         float a = 0.f, q = 0.f;
         for (int j = 0; j < Cg; ++j) { a += s_sum[g0 + j]; q += s_sq[g0 + j]; }
-        const float inv_n = 1.0f / ((float)HW * (float)Cg);
+        const float inv_n = 1.0f / ((float)HW * (float)(cg_true > 0 ? cg_true : Cg));     // cg_true: the group's other channels are zero padding
         const float mean = a * inv_n;
         const float var = fmaxf(q * inv_n - mean * mean, 0.f);
         const float rstd = rsqrtf(var + eps);
@@ -469,14 +469,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
 }
 
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats, int dt, int B,
-                            int HW, int C, int G, float eps, int relu, hipStream_t s) {
+                            int HW, int C, int G, float eps, int relu, hipStream_t s, int cg_true) {
     const int CH = dt_chunk(dt);
     if (C % CH || C % G) return hipErrorInvalidValue;
     const int Cg = C / G;
+    if (cg_true < 0 || cg_true > Cg) return hipErrorInvalidValue;
     static const int two_pass = getenv("HCM_GN_TWO") ? atoi(getenv("HCM_GN_TWO")) : 1;
     const int P = gn_partials(HW);
     const int cprw = C / CH;
-    if (two_pass && stats && P > 0 && !(cprw & (cprw - 1)) && cprw <= 128 && C <= 512 && G <= 256 && HW % P == 0 &&
+    if (two_pass && !cg_true && stats && P > 0 && !(cprw & (cprw - 1)) && cprw <= 128 && C <= 512 && G <= 256 && HW % P == 0 &&
         (HW >= 1024 || C <= 256)) {             // 16 x 16 maps with 512 channels: the slab kernel is faster (13 vs 21 us)
         HCM_DISPATCH_T(dt, {
             hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(P, B), dim3(256), 0, s, (const T*)x, stats, HW, C, G, P);
@@ -492,7 +493,7 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
     const int cpr = CS / CH;
     if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) return hipErrorInvalidValue;
     const int grid = B * (C / CS);
-    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, CS, eps, relu));
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, CS, eps, relu, cg_true));
     return hipGetLastError();
 }
 

@@ -62,9 +62,16 @@ struct Fwd {
     // conv followed by GroupNorm (+ residual + ReLU): one launch when the output map is small enough for the fused
     // epilogue (igemm.hip), else conv + the stand-alone GroupNorm kernels
     void conv_gn(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, const NormW& n, int G, bool relu, int Ho,
-                 int Wo) {
+                 int Wo, int cg_true = 0) {
         static const bool no_fuse = getenv("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
+        if (cg_true) {
+            // zero-padded output channels (compression conv of 64*k-pixel frames, k not a power of two): the statistics count the real
+            // channels of each group only -- the stand-alone slab kernel knows how
+            conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
+            gn(out, res, n, in.B, hw, C, G, relu, cg_true);
+            return;
+        }
         // the fused epilogue needs 64x128 tiles: not worth it when that leaves a long-K conv on a handful of workgroups
         // (the 3x3 compression conv: K = 18432 on 32 workgroups, 119 us fused vs 63 + 8 us separate)
         const long blocks = (long)((in.B * hw + 63) / 64) * ((w.Cout + 127) / 128) * w.groups;
@@ -136,10 +143,10 @@ struct Fwd {
         ck(launch_igemm(g, wd, s), "linear igemm");
         if (!out_f32) calib_check(y, wd, M, w.N, ldy);
     }
-    void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu) {
+    void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu, int cg_true = 0) {
         float* stats = alloc_f(gn_stats_floats(B, HW, G));
         if (dry) return;
-        ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, 1e-5f, relu ? 1 : 0, s), "groupnorm");
+        ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, 1e-5f, relu ? 1 : 0, s, cg_true), "groupnorm");
     }
     void ln(const void* x, const void* res, const NormW& n, const float* post, int post_rows, void* y, int rows, int D, float eps) {
         if (dry) return;
@@ -320,7 +327,7 @@ struct Fwd {
         }
         if (t.gn) {
             int fr = (xi + 1) & 3;
-            conv_gn(t.compress, x, slot[fr], 1, 1, nullptr, t.n_compress, t.pair ? 2 : 1, true, x.H, x.W);
+            conv_gn(t.compress, x, slot[fr], 1, 1, nullptr, t.n_compress, t.pair ? 2 : 1, true, x.H, x.W, t.compress_true);
             x = Act{slot[fr], B, x.H, x.W, CO(t.compress)};
         }
         return x;

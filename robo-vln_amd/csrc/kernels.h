@@ -118,7 +118,7 @@ hipError_t launch_groupnorm_apply(void* x, const void* res, const float* gamma, 
                                   int HW, int C, int G, float eps, int relu, hipStream_t s);
 bool groupnorm_apply_ok(int dt, int HW, int C, int G);
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats,
-                            int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s);
+                            int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s, int cg_true = 0);   // cg_true > 0: real channels per group, the rest are zero padding
 // LayerNorm rows: y = LN(x (+res)) * gamma + beta (+ post[row % post_rows][:])
 hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, const float* beta,
                             const float* post, int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s);

@@ -53,6 +53,7 @@ struct TrunkW {
     std::vector<BottleneckW> blocks;
     ConvW compress;            // habitat: 3x3 compression conv
     NormW n_compress;
+    int compress_true = 0;     // > 0: real channels (per model) of the compression conv when its output is padded to a power of two
     int out_c = 0;
 };
 struct SimpleCnnW {

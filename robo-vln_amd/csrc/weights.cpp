@@ -84,6 +84,17 @@ int depth_compress_channels(const hcm_config& c) {
     const int fs = depth_final_spatial(c);
     return (int)std::lround(2048.0 / (fs * fs));
 }
+// Frames of 64*k pixels with k not a power of two give channel counts like 228 (192 px), 82 (320), 57 (384): the compression conv, its
+// GroupNorm and the token rows run on the next power of two (zero weight rows, gamma = beta = 0: the extra channels are exact zeros), the
+// statistics count the real channels only, and the consumers' weight columns are laid out to match (zero columns under the padding).
+int depth_compress_padded(const hcm_config& c) {
+    const int cc = depth_compress_channels(c);
+    int p = 8;
+    while (p < cc) p *= 2;
+    return p;
+}
+// column n of a depth token row [compression channels | padding | 64 position-embedding channels] -> the reference's channel, -1 = padding
+static int depth_tok_src(int n, int cc, int ccp) { return n < cc ? n : n < ccp ? -1 : n - (ccp - cc); }
 
 void build_spec_high(hcm_ctx* ctx) {
     const hcm_config& c = ctx->cfg;
@@ -229,14 +240,16 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // conv weight OIHW (+ optional per-channel scale) -> [O][Kp] with k = (kh*KW+kw)*I + ci
 static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vector<float>* scale,
-                       const std::vector<float>* bias) {
+                       const std::vector<float>* bias, int cout_pad = 0) {
     ConvW c;
     c.dt = dt;
     c.Cout = (int)w.shape[0]; c.Cin = (int)w.shape[1]; c.KH = (int)w.shape[2]; c.KW = (int)w.shape[3];
     c.K = c.KH * c.KW * c.Cin;
     c.Kp = round_up(c.K, 32);
+    const int co = c.Cout;
+    if (cout_pad > c.Cout) c.Cout = cout_pad;                 // zero rows: output channels that are exactly 0 (bias-free convs only)
     std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
-    for (int o = 0; o < c.Cout; ++o) {
+    for (int o = 0; o < co; ++o) {
         const float sc = scale ? (*scale)[o] : 1.f;
         for (int i = 0; i < c.Cin; ++i)
             for (int kh = 0; kh < c.KH; ++kh)
@@ -266,21 +279,23 @@ static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const s
     return make_conv(dt, up, w, &scale, &bias);
 }
 
-static NormW make_norm(hcm_ctx* ctx, Uploader& up, int model, const std::string& p) {
+static NormW make_norm(hcm_ctx* ctx, Uploader& up, int model, const std::string& p, int pad_to = 0) {
     NormW n;
-    const HostTensor& g = T_(ctx, model, p + ".weight");
-    n.gamma = up.f32(g.f);
-    n.beta = up.f32(T_(ctx, model, p + ".bias").f);
-    n.C = (int)g.shape[0];
+    std::vector<float> g = T_(ctx, model, p + ".weight").f, b = T_(ctx, model, p + ".bias").f;
+    if ((int)g.size() < pad_to) { g.resize(pad_to, 0.f); b.resize(pad_to, 0.f); }
+    n.gamma = up.f32(g);
+    n.beta = up.f32(b);
+    n.C = (int)g.size();
     return n;
 }
 
 // Linear weight [N][K] (rows optionally concatenated from several tensors), K zero-padded to a multiple of 32.
-// `perm` (size K) maps new column j -> source column perm[j].
+// `perm` maps new column j -> source column perm[j] (-1: a zero column); its size is the new K.
 static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs,
                         int dt, const std::vector<int>* perm = nullptr) {
     LinW l;
-    l.K = (int)ws[0]->shape[1];
+    const int Ksrc = (int)ws[0]->shape[1];
+    l.K = perm ? (int)perm->size() : Ksrc;                   // a perm may also widen the row: entries of -1 are zero columns
     l.Kp = round_up(l.K, 32);
     l.dt = dt;
     int N = 0;
@@ -291,7 +306,10 @@ static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, 
     for (auto* w : ws) {
         const int n = (int)w->shape[0];
         for (int i = 0; i < n; ++i, ++row)
-            for (int j = 0; j < l.K; ++j) r[(size_t)row * l.Kp + j] = w->f[(size_t)i * l.K + (perm ? (*perm)[j] : j)];
+            for (int j = 0; j < l.K; ++j) {
+                const int src = perm ? (*perm)[j] : j;
+                if (src >= 0) r[(size_t)row * l.Kp + j] = w->f[(size_t)i * Ksrc + src];
+            }
     }
     l.w = up.typed(r, dt);
     if (!bs.empty()) {
@@ -416,23 +434,27 @@ static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
             }
             t.blocks.push_back(b);
         }
-    t.compress = make_conv(dt, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr);
-    t.n_compress = make_norm(ctx, up, model, pre + "compression.1");
+    const int cc = depth_compress_channels(ctx->cfg), ccp = depth_compress_padded(ctx->cfg);
+    t.compress = make_conv(dt, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr, ccp);
+    t.n_compress = make_norm(ctx, up, model, pre + "compression.1", ccp);
+    t.compress_true = ccp != cc ? cc : 0;
     t.out_c = t.compress.Cout;
     return t;
 }
 
 // ---- hi|lo pair of the GroupNorm depth trunk (see HighW::depth_pair)
-static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const HostTensor& b, bool concat_n) {
+static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const HostTensor& b, bool concat_n, int cout_pad = 0) {
     ConvW c;
     c.dt = dt;
     c.Cout = (int)a.shape[0]; c.Cin = (int)a.shape[1]; c.KH = (int)a.shape[2]; c.KW = (int)a.shape[3];
     c.K = c.KH * c.KW * c.Cin;
     c.Kp = round_up(c.K, 32);
+    const int co = c.Cout;
+    if (cout_pad > c.Cout) c.Cout = cout_pad;                 // per model: zero rows behind each model's own
     std::vector<float> r((size_t)2 * c.Cout * c.Kp, 0.f);
     const HostTensor* ws[2] = {&a, &b};
     for (int g = 0; g < 2; ++g)
-        for (int o = 0; o < c.Cout; ++o)
+        for (int o = 0; o < co; ++o)
             for (int i = 0; i < c.Cin; ++i)
                 for (int kh = 0; kh < c.KH; ++kh)
                     for (int kw = 0; kw < c.KW; ++kw)
@@ -443,13 +465,13 @@ static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const Hos
     else c.groups = 2;
     return c;
 }
-static NormW make_norm_pair(hcm_ctx* ctx, Uploader& up, const std::string& p) {
+static NormW make_norm_pair(hcm_ctx* ctx, Uploader& up, const std::string& p, int pad_to = 0) {
     NormW n;
     std::vector<float> g = T_(ctx, HCM_HIGH, p + ".weight").f, b = T_(ctx, HCM_HIGH, p + ".bias").f;
-    const HostTensor& g2 = T_(ctx, HCM_LOW, p + ".weight");
-    const HostTensor& b2 = T_(ctx, HCM_LOW, p + ".bias");
-    g.insert(g.end(), g2.f.begin(), g2.f.end());
-    b.insert(b.end(), b2.f.begin(), b2.f.end());
+    std::vector<float> g2 = T_(ctx, HCM_LOW, p + ".weight").f, b2 = T_(ctx, HCM_LOW, p + ".bias").f;
+    if ((int)g.size() < pad_to) { g.resize(pad_to, 0.f); b.resize(pad_to, 0.f); g2.resize(pad_to, 0.f); b2.resize(pad_to, 0.f); }
+    g.insert(g.end(), g2.begin(), g2.end());
+    b.insert(b.end(), b2.begin(), b2.end());
     n.C = (int)g.size();
     n.gamma = up.f32(g);
     n.beta = up.f32(b);
@@ -462,7 +484,7 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     t.pair = true;
     t.groups = ctx->cfg.depth_baseplanes / 2;
     t.cin1 = 1;
-    auto W2 = [&](const std::string& k, bool cat) { return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat); };
+    auto W2 = [&](const std::string& k, bool cat, int pad = 0) { return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat, pad); };
     const std::string bb = pre + "backbone.";
     t.conv1 = W2(bb + "conv1.0.weight", true);
     if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, HCM_HIGH, bb + "conv1.0.weight"), &T_(ctx, HCM_LOW, bb + "conv1.0.weight")});
@@ -482,8 +504,10 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
             }
             t.blocks.push_back(b);
         }
-    t.compress = W2(pre + "compression.0.weight", false);
-    t.n_compress = make_norm_pair(ctx, up, pre + "compression.1");
+    const int cc = depth_compress_channels(ctx->cfg), ccp = depth_compress_padded(ctx->cfg);
+    t.compress = W2(pre + "compression.0.weight", false, ccp);
+    t.n_compress = make_norm_pair(ctx, up, pre + "compression.1", ccp);
+    t.compress_true = ccp != cc ? cc : 0;
     t.out_c = t.compress.Cout;      // per model
     return t;
 }
@@ -688,7 +712,8 @@ void prepare_high(hcm_ctx* ctx) {
     h.depth_pe = make_pe_view(up, T_(ctx, M, "depth_encoder.spatial_embeddings.weight"));
     const int fs = depth_final_spatial(c);
     h.depth_S = fs * fs;
-    h.depth_C = depth_compress_channels(c) + 64;
+    const int cc = depth_compress_channels(c), ccp = depth_compress_padded(c);
+    h.depth_C = ccp + 64;                       // token row: [compression channels | padding | position embedding]
     // BERT
     const std::string e = "embedding_layer.embeddings.";
     h.bert.word = up.f32(T_(ctx, M, e + "word_embeddings.weight").f);
@@ -713,14 +738,21 @@ void prepare_high(hcm_ctx* ctx) {
     }
     // Conv1d(k=1) weights (out,in,1) are linear layers over the token axis
     h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
-    h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla);
+    {
+        std::vector<int> perm((size_t)h.depth_C);
+        for (int n = 0; n < h.depth_C; ++n) perm[n] = depth_tok_src(n, cc, ccp);
+        h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla, &perm);
+    }
     h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
     {
         // depth_linear: Flatten of (B, dC, S) -> column c*S + s; ours [B][S][dC] -> s*dC + c
         const int S = h.depth_S, dC = h.depth_C;
         std::vector<int> perm((size_t)S * dC);
         for (int s = 0; s < S; ++s)
-            for (int ch = 0; ch < dC; ++ch) perm[(size_t)s * dC + ch] = ch * S + s;
+            for (int ch = 0; ch < dC; ++ch) {
+                const int src = depth_tok_src(ch, cc, ccp);
+                perm[(size_t)s * dC + ch] = src < 0 ? -1 : src * S + s;
+            }
         h.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt_vla, &perm);
     }
     // Visual_Ling_Attn
@@ -791,10 +823,10 @@ void prepare_low(hcm_ctx* ctx) {
     if (!l.depth_simple) {
         l.depth = make_gn_trunk(ctx, up, M, "depth_encoder.visual_encoder.");
         // visual_fc: Flatten of (B, cc, fs, fs) -> c*S + s ; ours s*cc + c
-        const int fs = depth_final_spatial(c), S = fs * fs, cc = depth_compress_channels(c);
-        std::vector<int> perm((size_t)S * cc);
+        const int fs = depth_final_spatial(c), S = fs * fs, cc = depth_compress_channels(c), ccp = depth_compress_padded(c);
+        std::vector<int> perm((size_t)S * ccp);
         for (int s = 0; s < S; ++s)
-            for (int ch = 0; ch < cc; ++ch) perm[(size_t)s * cc + ch] = ch * S + s;
+            for (int ch = 0; ch < ccp; ++ch) perm[(size_t)s * ccp + ch] = ch < cc ? ch * S + s : -1;
         l.depth_fc = make_linear(up, {&T_(ctx, M, "depth_encoder.visual_fc.1.weight")}, {&T_(ctx, M, "depth_encoder.visual_fc.1.bias")}, ctx->dt_depth, &perm);
     } else {
         l.depth_s = make_simple_cnn(ctx, ctx->dt_depth, up, M, "depth_encoder.", 1, c.depth_h);
@@ -828,7 +860,8 @@ void prepare_cma(hcm_ctx* ctx) {
     w.depth_pe = make_pe_view(up, T_(ctx, M, "depth_encoder.spatial_embeddings.weight"));
     const int fs = depth_final_spatial(c);
     w.depth_S = fs * fs;
-    w.depth_C = depth_compress_channels(c) + 64;
+    const int cc = depth_compress_channels(c), ccp = depth_compress_padded(c);
+    w.depth_C = ccp + 64;
     w.emb = up.f32(T_(ctx, M, "instruction_encoder.embedding_layer.weight").f);
     w.dirs = m.bidirectional ? 2 : 1;
     for (int d = 0; d < w.dirs; ++d) {
@@ -858,11 +891,18 @@ void prepare_cma(hcm_ctx* ctx) {
         const int S = w.depth_S, dC = w.depth_C;          // Flatten of (B, dC, S): column c*S + s; ours [B][S][dC]
         std::vector<int> perm((size_t)S * dC);
         for (int s = 0; s < S; ++s)
-            for (int ch = 0; ch < dC; ++ch) perm[(size_t)s * dC + ch] = ch * S + s;
+            for (int ch = 0; ch < dC; ++ch) {
+                const int src = depth_tok_src(ch, cc, ccp);
+                perm[(size_t)s * dC + ch] = src < 0 ? -1 : src * S + s;
+            }
         w.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt_vla, &perm);
     }
     w.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
-    w.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla);
+    {
+        std::vector<int> perm((size_t)w.depth_C);
+        for (int n = 0; n < w.depth_C; ++n) perm[n] = depth_tok_src(n, cc, ccp);
+        w.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla, &perm);
+    }
     w.state_q = make_linear(up, {&T_(ctx, M, "state_q.weight")}, {&T_(ctx, M, "state_q.bias")}, DT_F32);
     w.text_k = make_linear(up, {&T_(ctx, M, "text_k.weight")}, {&T_(ctx, M, "text_k.bias")}, DT_F32);
     w.text_q = make_linear(up, {&T_(ctx, M, "text_q.weight")}, {&T_(ctx, M, "text_q.bias")}, DT_F32);

@@ -46,11 +46,14 @@ def test_create_rejects_broken_reference_flags():
     assert rc == -6 and b"output_shape" in l.hcm_last_error(None)
     with pytest.raises(ValueError):
         HCMConfig(use_prev_action=True).validate()
-    # depth frames whose compression conv would get a non-vector channel count (192 -> 2048 / 9 = 228) are rejected up front
-    l, rc, h = _create(HCMConfig(), depth_h=192, depth_w=192)
+    # depth frames: any multiple of 64 (habitat's ResNetEncoder sizes its compression conv from (H/2)/32; 192 -> 3x3 x 228 channels);
+    # other sizes give a final map the reference's own visual_fc / spatial embedding shapes do not match, and are rejected up front
+    l, rc, h = _create(HCMConfig(), depth_h=224, depth_w=224)
     assert rc == -6 and b"depth frame size" in l.hcm_last_error(None)
     with pytest.raises(ValueError):
-        HCMConfig(depth_hw=192).validate()
+        HCMConfig(depth_hw=224).validate()
+    c192 = HCMConfig(depth_hw=192).validate()
+    assert c192.depth_final_spatial() == 3 and c192.depth_compress_channels() == 228
 
 
 def test_strict_state_dict_keys_and_shapes():
