@@ -10,7 +10,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 3072
 act = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 VARS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else []
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for K in (768, 3072):
+for K in [int(k) for k in os.environ.get('KS', '768,3072').split(',')]:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).half(); w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.06).half(); b = torch.rand(N, device="cuda")
     y = torch.empty(M, N, device="cuda", dtype=torch.float16)
     out = []
