@@ -246,6 +246,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
             // ---- phase 4: channels 0-31 x tokens 64-127 (both fragment sets are in registers)
             if (live) { piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<2>(); }     // X-h0, W-h0, W-h1 of the next tile have landed
             mma_phase(I0{}, I1{}, wf0);
+        } else if constexpr (SCHED == 3) {
+            // early requests, late waits: the whole next tile is requested in phases 1 and 2 (4 + 4 pieces) and every wait sits one phase
+            // before the first read of what it waits for -- every piece has >= 3 phases (~0.8 us) between request and first use, where
+            // SCHED 0 gives W-h1 one phase (~0.28 us: less than an L2 hit's latency under load).
+            //   before phase 2 reads W-h1 of THIS tile (pieces 4, 5; requested in phase 2 of the previous tile): younger = 6, 7 + 0-3 of the next
+            //   before phase 3 reads X-h1 of THIS tile (6, 7): younger = 0-7 of the next tile
+            //   before the next phase 1 reads X-h0 / W-h0 of the next tile (0-3): younger = 4-7 of the next tile
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<6>(); } else { g_wait_vmcnt<2>(); }
+            mma_phase(I0{}, I0{}, wf0);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<8>(); } else { g_wait_vmcnt<0>(); }
+            mma_phase(I1{}, I0{}, wf1);
+            if (rd) rd_x(1, cur);
+            mma_phase(I1{}, I1{}, wf1);
+            if (live) g_wait_vmcnt<4>();
+            mma_phase(I0{}, I1{}, wf0);
         } else if constexpr (SCHED == 2) {
             using LV = std::integral_constant<bool, live>;
             if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
@@ -436,6 +453,8 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
             case 6: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 6>); break;
             case 7: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 7>); break;
             case 8: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 3>); break;
+            case 9: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 0>); break;
+            case 10: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 4>); break;
             default: return hipErrorInvalidValue;
         }
     }

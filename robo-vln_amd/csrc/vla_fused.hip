@@ -16,8 +16,8 @@
 // boundaries (XOR-swizzled 128-B rows as in igemm.hip); a lane's accumulator holds 4 consecutive channels of one token, as everywhere
 // in this library.  (First version: weight fragments as plain global loads of 16 rows x 64 B per instruction -- 80 us per launch at
 // B = 64, bound by the texture-address path; staged through LDS in full 128-B rows, with the
-// in-kernel attention on MFMA, the same launch takes 42 us: ~19 of them are the weight stream itself at the ~62 GB/s one CU draws from L2
-// -- every workgroup needs all 1.15 MB -- 3.6 the attention, ~13 the LayerNorm / epilogue / store phases, 6.5 launch + operand staging.)
+// in-kernel attention on MFMA, the same launch takes 42 us: ~19 of them are the weight stream -- every workgroup needs all 1.15 MB, and a ring
+// that is one 32 KB tile ahead is a latency chain at ~62 GB/s per CU (the same CU draws 125 GB/s from L2 with more in flight) -- 3.6 the attention, ~13 the LayerNorm / epilogue / store phases, 6.5 launch + operand staging.)
 //
 // Against the seven launches it replaces (attention, fc_o, LayerNorm, fc1, fc2, LayerNorm, mean) the GEMMs use the same MFMA
 // instruction over the same k order on the same rounded operands; the LayerNorm / mean reductions have a different (fixed) order, so

@@ -1,0 +1,17 @@
+import ctypes as C, sys, os
+sys.path.insert(0, '/root/repo')
+import torch, hcm_pkg
+hcm_pkg.load()
+from robo_vln_amd import _lib
+lib = _lib.lib()
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for (M, N, K) in ((5120, 3072, 768), (5120, 2304, 768), (20480, 768, 3072), (5000, 3072, 64), (5120, 3072, 128)):
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).half(); w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.06).half(); b = torch.rand(N, device="cuda")
+    ys = []
+    for impl in (2, 2 + 16 * 9):
+        y = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        rc = lib.hcm_op_linear_impl(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), 5, M, N, K, 2, 0, impl, st)
+        assert rc == 0, rc
+        ys.append(y)
+    torch.cuda.synchronize()
+    print(M, N, K, "equal" if torch.equal(ys[0], ys[1]) else "DIFFERENT", (ys[0].float() - ys[1].float()).abs().max().item())
