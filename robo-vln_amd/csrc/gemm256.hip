@@ -401,6 +401,240 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Four-wave form of the same tile (one wave per SIMD, 128 x 128 outputs = 256 accumulator registers per wave, 2 x 2 waves) -- an EXPERIMENT
+// (hcm_op_linear_impl variant 11 / HCM_GEMM256_W4=1), bit-identical to the 8-wave form and SLOWER: 1.55-1.87 us per K tile against 1.375.
+// The idea: with 8 waves the LDS pipe moves 192 KB of fragment reads + 64 KB of DMA writes per K tile = 2048 cycles, exactly the tile's 2048
+// MFMA cycles; a 128 x 128 wave tile reads (128 + 128) rows x 4 waves = 128 KB, 1536 LDS cycles with the DMA writes,
+// which would leave the loop MFMA-bound.  With a single wave per SIMD nothing else hides a stall, so the loop is software-pipelined inside
+// the wave: the fragments of k step s+1 are read (into the other register set) and the DMA pieces of K tile t+2 are requested from between
+// the 64 MFMAs of k step s, one memory instruction after each MFMA; ONE workgroup barrier per K tile (in its middle: by then every wave holds
+// tile t's last fragments in registers, so tile t's buffer is free for tile t+2, and tile t+1 -- requested a full tile earlier -- has landed).
+// Why it loses: an LDS-DMA instruction costs the issuing wave ~60 cycles (MI355X_MICROARCH.md, cycle table), 16 pieces per wave per tile =
+// ~960 cycles that the 8-wave form hides behind the SIMD's other wave and this one adds to its only wave's 2048 MFMA cycles.  A four-wave form
+// would have to stage its operands through registers (buffer_load -> VGPR -> ds_write, 64 more registers on top of the 256 + 128 here).
+template <typename T>
+__global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tile_m, tile_n;
+    {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
+        const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
+        const int nn = n_hi - n_lo;
+        if (nn <= 0 || local >= (m_hi - m_lo) * nn) return;
+        tile_m = m_lo + local / nn;
+        tile_n = n_lo + local % nn;
+    }
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;          // wave (wr, wc): tokens [wr*128, +128) x channels [wc*128, +128)
+    const int rin = lane >> 3;
+    const int csrc = (lane & 7) ^ rin;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
+    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
+
+    // DMA pieces (8 rows x 128 B each): a K tile is 32 X pieces + 32 W pieces; wave w requests X pieces w*8 .. +8 and W pieces w*8 .. +8
+    unsigned xsrc[8], wsrc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + rin;
+        const int m = m0 + row, n = n0 + row;
+        xsrc[i] = m < p.M ? (unsigned)(m * p.ldx + csrc * 8) * 2u : 0x80000000u;
+        wsrc[i] = n < p.N ? (unsigned)(n * p.ldw + csrc * 8) * 2u : 0x80000000u;
+    }
+    const unsigned pdst = lds_base + (unsigned)(wave * 8) * 1024u;      // + i * 1024 (+ G_WOFF for W) + buffer
+    auto piece = [&](int q, unsigned buf, unsigned kbyte) {              // q = 0..15: X pieces then W pieces of this wave
+        if (q < 8) g_dma16(pdst + buf + (unsigned)q * 1024u, xsrc[q] + kbyte, rx);
+        else g_dma16(pdst + buf + G_WOFF + (unsigned)(q - 8) * 1024u, wsrc[q - 8] + kbyte, rw);
+    };
+
+    g_f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment f of a register set: f < 8 weight fragment i = f (A operand), else token fragment j = f - 8 (B operand)
+    auto rd_frag = [&](uint4 (&wf)[8], uint4 (&xf)[8], int f, int ks, unsigned buf) {
+        if (f < 8) {
+            const int r = wc * 128 + f * 16 + fr;
+            wf[f] = *reinterpret_cast<const uint4*>(smem + buf + G_WOFF + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+        } else {
+            const int r = wr * 128 + (f - 8) * 16 + fr;
+            xf[f - 8] = *reinterpret_cast<const uint4*>(smem + buf + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+        }
+    };
+    uint4 wfa[8], xfa[8], wfb[8], xfb[8];
+    const int nk = p.K / 64;
+
+    // prologue: K tiles 0 and 1 requested; tile 0 landed for everybody; k step 0 of tile 0 in register set A
+#pragma unroll
+    for (int q = 0; q < 16; ++q) piece(q, 0, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) piece(q, G_BUF, 128u);
+        g_wait_vmcnt<16>();
+    } else {
+        g_wait_vmcnt<0>();
+    }
+    G_BAR();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) rd_frag(wfa, xfa, f, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // one K tile; MORE1 / MORE2: a tile t+1 / t+2 exists (compile-time, so that the steady-state loop carries no branches between its MFMAs)
+    auto tile_body = [&](int t, auto MORE1, auto MORE2) {
+        constexpr bool more1 = decltype(MORE1)::value, more2 = decltype(MORE2)::value;
+        const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
+        // ---- first half: MFMAs of k step 0 (set A); between them the fragments of k step 1 of this tile -> set B
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                GMma<T>::run(acc[i][j], wfa[i], xfa[j]);
+                const int m = i * 8 + j;
+                if (m < 16) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_frag(wfb, xfb, m, 1, cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        // every wave is past its last read of this tile's buffer once its set-B fragments have arrived; tile t+1 (requested a tile ago) landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_wait_vmcnt<0>();
+        G_BAR();
+        // ---- second half: MFMAs of k step 1 (set B); between them k step 0 of tile t+1 -> set A and the requests of tile t+2 into this tile's buffer
+        const unsigned kb2 = (unsigned)(t + 2) * 128u;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                GMma<T>::run(acc[i][j], wfb[i], xfb[j]);
+                const int m = i * 8 + j;
+                if (more1 && m < 16) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_frag(wfa, xfa, m, 0, nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (more2 && m >= 16 && m < 32) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(m - 16, cur, kb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    {
+        int t = 0;
+        for (; t + 2 < nk; ++t) tile_body(t, std::true_type{}, std::true_type{});
+        if (t + 1 < nk) { tile_body(t, std::true_type{}, std::false_type{}); ++t; }
+        tile_body(t, std::false_type{}, std::false_type{});
+    }
+    __syncthreads();                                   // every wave is done with the operand buffers: the epilogue images reuse them
+
+    if (p.res) {
+        // residual epilogue (as in gemm256_kernel): f32 image of half the tile (the rows of one wave row), then bias + residual + activation
+        constexpr int LDF = 260;
+        float* sc = reinterpret_cast<float*>(smem);
+        const int chunk = tid & 31, n = n0 + chunk * 8;
+        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+        for (int half = 0; half < 2; ++half) {
+            if (wr == half) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        *reinterpret_cast<float4*>(sc + (j * 16 + fr) * LDF + wc * 128 + i * 16 + fg * 4) =
+                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int pass = 0; pass < 16; ++pass) {
+                const int r = pass * 8 + (tid >> 5);
+                const int m = m0 + half * 128 + r;
+                if (m < p.M && n < p.N) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(p.res + ((size_t)m * p.ldr + n) * 2);
+                    const float4 a0 = *reinterpret_cast<const float4*>(sc + r * LDF + chunk * 8), a1 = *reinterpret_cast<const float4*>(sc + r * LDF + chunk * 8 + 4);
+                    float v[8] = {a0.x + bias8[0], a0.y + bias8[1], a0.z + bias8[2], a0.w + bias8[3], a1.x + bias8[4], a1.y + bias8[5], a1.z + bias8[6], a1.w + bias8[7]};
+                    float r8[8];
+                    cvt_chunk<T>(rr, r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+                    }
+                    st_chunk(reinterpret_cast<T*>(p.y + ((size_t)m * p.ldy + n) * 2), v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // 16-bit tile image in two halves of the wave's token fragments (0-3 / 4-7: tile rows {0-63, 128-191} / {64-127, 192-255})
+    {
+        float4 b4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + wc * 128 + i * 16 + fg * 4;
+            b4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int chunk = tid & 31;
+        const int n = n0 + chunk * 8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = half * 4 + jj;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+                    }
+                    T o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    const int r = wr * 128 + j * 16 + fr;
+                    const int cb = (wc * 128 + i * 16 + fg * 4) * 2;
+                    *reinterpret_cast<uint2*>(smem + r * G_IMG_LD + cb) = *reinterpret_cast<const uint2*>(o4);
+                }
+            }
+            __syncthreads();
+            if (n < p.N) {
+#pragma unroll 4
+                for (int pass = 0; pass < 16; ++pass) {
+                    const int rr = pass * 8 + (tid >> 5);
+                    const int r = (rr >> 6) * 128 + half * 64 + (rr & 63);
+                    const int m = m0 + r;
+                    if (m < p.M)
+                        *reinterpret_cast<uint4*>(p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const uint4*>(smem + r * G_IMG_LD + chunk * 16);
+                }
+            }
+        }
+    }
+}
+
 bool gemm256_applicable(const IGemm& g, int dt) {
     if (dt != DT_BF16 && dt != DT_F16) return false;
     if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
@@ -455,15 +689,22 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
             case 8: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 3>); break;
             case 9: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 0>); break;
             case 10: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 4>); break;
+            case 11: break;                                                           // the four-wave form, selected below
             default: return hipErrorInvalidValue;
         }
+    }
+    static const bool w4_default = getenv("HCM_GEMM256_W4") != nullptr;      // A/B knob: the four-wave form for every launch
+    int threads = 512;
+    if (var == 11 || (w4_default && !var)) {
+        fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256w_kernel<bf16>) : reinterpret_cast<const void*>(gemm256w_kernel<f16>);
+        threads = 256;
     }
     {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     void* args[] = {&d};
-    return hipLaunchKernel(fn, dim3(8 * best_cnt), dim3(512), args, G_LDS, s);
+    return hipLaunchKernel(fn, dim3(8 * best_cnt), dim3(threads), args, G_LDS, s);
 }
 
 }  // namespace hcm
