@@ -282,8 +282,9 @@ int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const flo
 int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                                  int Cout, float scale, void* scratch, void* half_map, void* stream);
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
-/* SimpleDepthCNN's first layer, Conv2d(1, 32, 8, stride 4) (+ bias, activation) on a raw f32 depth frame (B,H,H,1) through the packed-frame
- * path of the model code; w is the OHWI weight [32][64] in `dtype` (16-bit), scratch holds B*H*H + 64 elements of `dtype` (simple_cnns.py:76-84). */
+/* SimpleDepthCNN's first layer, Conv2d(1, 32, 8, stride 4) (+ bias, activation) straight from a raw f32 depth frame (B,H,H,1) in one pass
+ * (csrc/simplecnn.hip; H a multiple of 4, <= 1024); w is the OHWI weight [32][64] in `dtype` (16-bit), scratch holds B*H*H + 64 elements of
+ * `dtype` (used by the convert + implicit-GEMM route only, HCM_NO_DEPTH_CONV0=1) (simple_cnns.py:76-84). */
 int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias, void* y, int dtype, int B, int H, int act, void* scratch,
                            void* stream);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
@@ -298,7 +299,8 @@ int hcm_op_vla_layer(const void* q, const void* I, const void* const* kv, const 
                      const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
                      void* stream);
 /* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,
- * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify).  The two must agree bit for bit. */
+ * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify).  The two must agree bit for bit.
+ * (impl values >= 16 select timing-experiment builds of the 256-wide kernel that exist in `make DEV=1` libraries only: HCM_ERR_HIP otherwise.) */
 int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const void* residual, void* y,
                        int dtype, int M, int N, int K, int act, int out_f32, int impl, void* stream);
 int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int dtype,

@@ -401,9 +401,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
     }
 }
 
+#ifdef HCM_DEV_KNOBS
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Four-wave form of the same tile (one wave per SIMD, 128 x 128 outputs = 256 accumulator registers per wave, 2 x 2 waves) -- an EXPERIMENT
-// (hcm_op_linear_impl variant 11 / HCM_GEMM256_W4=1), bit-identical to the 8-wave form and SLOWER: 1.55-1.87 us per K tile against 1.375.
+// Four-wave form of the same tile (one wave per SIMD, 128 x 128 outputs = 256 accumulator registers per wave, 2 x 2 waves) -- an EXPERIMENT,
+// compiled into `make DEV=1` builds only (hcm_op_linear_impl variant 11 / HCM_GEMM256_W4=1), bit-identical to the 8-wave form and SLOWER: 1.55-1.87 us per K tile against 1.375.
 // The idea: with 8 waves the LDS pipe moves 192 KB of fragment reads + 64 KB of DMA writes per K tile = 2048 cycles, exactly the tile's 2048
 // MFMA cycles; a 128 x 128 wave tile reads (128 + 128) rows x 4 waves = 128 KB, 1536 LDS cycles with the DMA writes,
 // which would leave the loop MFMA-bound.  With a single wave per SIMD nothing else hides a stall, so the loop is software-pipelined inside
@@ -635,6 +636,8 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
     }
 }
 
+#endif  // HCM_DEV_KNOBS
+
 bool gemm256_applicable(const IGemm& g, int dt) {
     if (dt != DT_BF16 && dt != DT_F16) return false;
     if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
@@ -674,9 +677,13 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
         }
         if (cnt < best_cnt || (cnt == best_cnt && fp < best_fp)) { best_cnt = cnt; best_fp = fp; d.gm = gm; d.gn = gn; }
     }
-    // g.impl >> 4 selects experiment builds (f16 only): 1 = SCHED 1; 2/3/4 = SCHED 0 with DBG 1/2/4; 5/6/7 = SCHED 1 with DBG 1/2/4
-    const int var = g.impl >> 4;
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256_kernel<bf16>) : reinterpret_cast<const void*>(gemm256_kernel<f16>);
+    int threads = 512;
+#ifdef HCM_DEV_KNOBS
+    // `make DEV=1` builds only (libhcm_dev.so): g.impl >> 4 selects the experiment builds DESIGN.md section 7 quotes (f16): 1 = SCHED 1;
+    // 2/3/4 = SCHED 0 with parts removed (DBG 1/2/4: timing only, results are wrong); 5-8 DBG combinations; 9 = SCHED 3 (early requests,
+    // bit-identical); 10 = SCHED 3 without MFMAs; 11 = the four-wave form (bit-identical).  HCM_GEMM256_W4=1: the four-wave form everywhere.
+    const int var = g.impl >> 4;
     if (dt == DT_F16 && var) {
         switch (var) {
             case 1: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 1, 0>); break;
@@ -693,12 +700,14 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
             default: return hipErrorInvalidValue;
         }
     }
-    static const bool w4_default = getenv("HCM_GEMM256_W4") != nullptr;      // A/B knob: the four-wave form for every launch
-    int threads = 512;
+    static const bool w4_default = getenv("HCM_GEMM256_W4") != nullptr;
     if (var == 11 || (w4_default && !var)) {
         fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256w_kernel<bf16>) : reinterpret_cast<const void*>(gemm256w_kernel<f16>);
         threads = 256;
     }
+#else
+    if (g.impl >> 4) return hipErrorInvalidValue;          // experiment variants exist in `make DEV=1` builds only
+#endif
     {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -1,6 +1,7 @@
 """time(K) of the 256x256 8-phase kernel at fixed M, N: slope = per-K-tile cost, intercept = prologue + epilogue + launch."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('HCM_DEV_LIB', '1')      # the experiment variants live in the `make DEV=1` library
 import torch, hcm_pkg
 hcm_pkg.load()
 from robo_vln_amd import _lib

@@ -1,5 +1,8 @@
+"""Bit-identity of an experiment build of the 256-wide GEMM kernel (VAR = variant number, `make DEV=1` library) against the shipped schedule.
+usage: VAR=9 [RES=1] python tools/gemm256_sched_check.py"""
 import ctypes as C, sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('HCM_DEV_LIB', '1')      # the experiment variants live in the `make DEV=1` library
 import torch, hcm_pkg
 hcm_pkg.load()
 from robo_vln_amd import _lib
