@@ -43,6 +43,11 @@ template <> struct VMma<f16> {
     }
 };
 
+#ifdef HCM_DEV_KNOBS
+#define V_DBG(p) ((p).dbg)
+#else
+#define V_DBG(p) 0
+#endif
 constexpr int V_D = 256, V_RB = 80, V_MF = 5, V_LDA = 528;          // model width, rows per workgroup, 16-row fragments, LDS row bytes
 constexpr int V_KVMAX = 32;                                         // keys of the in-kernel attention
 constexpr int V_WT = 32768;                                         // one weight K tile: 256 rows x 128 B
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     // consume tile `wt` against columns [64 kt, +64) of the activation block; the following tile is requested first and has landed
     // (every wave's pieces: vmcnt(0) + barrier) when the call returns
     auto w_step = [&](v_f32x4 (&acc)[2][V_MF], const char* sAct, int kt) {
-        if (!(p.dbg & 2)) dma_tile(wt + 1);
-        if (!(p.dbg & 4)) v_mma_tile<T>(acc, sW + (wt & 1) * V_WT, sAct, kt, nb, fr, fg);
+        if (!(V_DBG(p) & 2)) dma_tile(wt + 1);
+        if (!(V_DBG(p) & 4)) v_mma_tile<T>(acc, sW + (wt & 1) * V_WT, sAct, kt, nb, fr, fg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ++wt;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     if (p.fuse_att) {
         const int Lk = p.Lk[st];
         const T* kv = reinterpret_cast<const T*>(p.kv[st]) + (size_t)b * Lk * 512;
-        if (!(p.dbg & 1)) v_attention_mfma<T>(q, kv, Lk, nrow, sKV, reinterpret_cast<T*>(sKV + 4 * 32 * 128), sA, tid);
+        if (!(V_DBG(p) & 1)) v_attention_mfma<T>(q, kv, Lk, nrow, sKV, reinterpret_cast<T*>(sKV + 4 * 32 * 128), sA, tid);
     } else {
         const T* att = reinterpret_cast<const T*>(p.att[st]) + ((size_t)b * p.L + r0) * V_D;
         for (int e = tid; e < V_RB * 32; e += 512) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.dbg & 16) return;
+    if (V_DBG(p) & 16) return;
 
     float v[2][V_MF][4];
     // ---- x1 = LayerNorm(I + att Wo^T + bo)
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) v_st4<T>(sX + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, v[i][j]);
     __syncthreads();
-    if (p.dbg & 32) return;
+    if (V_DBG(p) & 32) return;
 
     // ---- FFN in 256-column slices of the intermediate: H_c = relu(x1 W1[c]^T + b1[c]) (-> sA), acc2 += H_c W2[:, c]^T
     v_f32x4 acc2[2][V_MF];
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) w_step(acc2, sA, kt);         // (its last barrier also frees sA for the next slice)
     }
-    if (p.dbg & 64) return;
+    if (V_DBG(p) & 64) return;
     // ---- out = LayerNorm(x1 + ffn + b2)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -450,8 +455,12 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
         attr_done = true;
     }
     VlaPost q = p;
-    static const int dbg = getenv("HCM_VLA_DBG") ? atoi(getenv("HCM_VLA_DBG")) : 0;      // timing experiments (results then wrong)
+#ifdef HCM_DEV_KNOBS
+    static const int dbg = getenv("HCM_VLA_DBG") ? atoi(getenv("HCM_VLA_DBG")) : 0;      // `make DEV=1` builds only: timing experiments (results then wrong)
     q.dbg = dbg;
+#else
+    q.dbg = 0;
+#endif
     void* args[] = {&q};
     const int nblk = (p.L + V_RB - 1) / V_RB;
     return hipLaunchKernel(fn, dim3(p.B * nblk, p.streams), dim3(512), args, V_LDS, s);
