@@ -157,10 +157,10 @@ def hbm_kernel_probe(batch):
             "frac": round(gbytes / ms / PEAK_HBM_TBPS, 4)}
 
 
-def pmc_traffic():
+def pmc_traffic(config=1):
     """HBM bytes from the PMC counters: written by tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
     passes of this same command (x2 gfx950 correction on FETCH_SIZE, MI355X_MICROARCH.md); never a literal in this file."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json" if config == 1 else f"pmc_traffic_cfg{config}.json")
     try:
         return json.load(open(p))
     except Exception:
@@ -401,7 +401,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = global_B * args.steps / dt
-        tr = pmc_traffic() if args.config == 1 and B == 64 else None
+        tr = pmc_traffic(args.config) if B == BATCH[args.config] and not args.total_batch else None
         out = {
             "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr" if args.config == 1 else
                       f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
@@ -422,7 +422,8 @@ def main():
         if args.config == 3:
             gb = alg_bytes / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(gb / ms, 4), "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": round(gb / ms / PEAK_HBM_TBPS, 4),
-                               "traffic": None, "basis": f"{gb * 1e3:.1f} MB algorithmic bytes per step (depth f32 in + (B,80,768) instruction tensor in + (B,80,256) out + "
+                               "traffic": (tr or {}).get("step_GB"), "traffic_unit": "GB per step (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_cfg3.json)" if tr else None,
+                               "basis": f"{gb * 1e3:.1f} MB algorithmic bytes per step (depth f32 in + (B,80,768) instruction tensor in + (B,80,256) out + "
                                "weights once, SURVEY 8d) / step time; the step is the whole probe (all its launches)"}
         else:
             gf = GFLOP[args.config]
@@ -450,7 +451,7 @@ def main():
                     # the JSON line's `roofline` is the DOMINANT KERNEL (gemm256_kernel on the BERT FFN1 shape), live HIP-event timing;
                     # the whole-step view and the HBM-bound probe ride along as labelled sub-objects
                     roof = {"bound": "mfma", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_peak"],
-                            "traffic": k_tr, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)" if k_tr else None,
+                            "traffic": k_tr, "traffic_unit": "GB per launch, averaged over this kernel's launches of the step (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic*.json)" if k_tr else None,
                             "scope": "dominant kernel: gemm256_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
                                      f"{top['gflop_per_launch']} algorithmic GFLOP per launch, 12 launches per step",
                             "bert_gemms": dk, "whole_step": whole}

@@ -16,7 +16,7 @@ def tot(path, name):
             per[k] += v; cnt[k] += 1
     return t, per, cnt
 f, pf, cf = tot(fetch, "FETCH_SIZE"); w, pw, cw = tot(write, "WRITE_SIZE")
-print(f"# HBM-side traffic per act() step (B=64), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {steps} steps in the run\n")
+print(f"# HBM-side traffic per step of the profiled bench.py configuration, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {steps} steps in the run\n")
 print(f"FETCH_SIZE sum {f/1e6:.3f} GB raw -> {2*f/1e6/steps:.3f} GB/step corrected (x2);  WRITE_SIZE sum {w/1e6:.3f} GB -> {w/1e6/steps:.3f} GB/step")
 print(f"total corrected traffic {(2*f+w)/1e6/steps:.3f} GB/step\n")
 print("| kernel | launches/step | fetch GB/step (x2 corrected) | write GB/step | MB/launch |\n|---|---|---|---|---|")
