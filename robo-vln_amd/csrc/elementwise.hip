@@ -468,6 +468,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
     }
 }
 
+// Fallback for shapes the slab kernel's layout does not cover (a group wider than 1024 channels: the 1 x 1 x 2048 compression map of
+// 64-pixel depth frames): one workgroup per (sample, group), two passes over its HW x Cg elements, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_generic_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int HW, int C, int G, float eps, int relu, int cg_true) {
+    __shared__ float s_a[256], s_q[256];
+    const int Cg = C / G, b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x;
+    T* xb = x + (size_t)b * HW * C + (size_t)g * Cg;
+    const T* rb = res ? res + (size_t)b * HW * C + (size_t)g * Cg : nullptr;
+    const int n = HW * Cg;
+    float a = 0.f, q = 0.f;
+    for (int e = tid; e < n; e += 256) {
+        const int p = e / Cg, c = e - p * Cg;
+        const float v = Tr<T>::ld(xb + (size_t)p * C + c);
+        a += v; q += v * v;
+    }
+    s_a[tid] = a; s_q[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_a[tid] += s_a[tid + o]; s_q[tid] += s_q[tid + o]; }
+        __syncthreads();
+    }
+    const float inv_n = 1.0f / ((float)HW * (float)(cg_true > 0 ? cg_true : Cg));
+    const float mean = s_a[0] * inv_n;
+    const float rstd = rsqrtf(fmaxf(s_q[0] * inv_n - mean * mean, 0.f) + eps);
+    for (int e = tid; e < n; e += 256) {
+        const int p = e / Cg, c = e - p * Cg;
+        const size_t off = (size_t)p * C + c;
+        float o = (Tr<T>::ld(xb + off) - mean) * rstd * gamma[g * Cg + c] + beta[g * Cg + c];
+        if (rb) o += Tr<T>::ld(rb + off);
+        if (relu) o = fmaxf(o, 0.f);
+        Tr<T>::st(xb + off, o);
+    }
+}
+
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats, int dt, int B,
                             int HW, int C, int G, float eps, int relu, hipStream_t s, int cg_true) {
     const int CH = dt_chunk(dt);
@@ -487,11 +522,17 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
     }
     // slab: whole groups, multiple of the chunk, power-of-two chunk count <= 32, about 32 K elements per workgroup
     int unit = Cg > CH ? Cg : CH;
-    if (unit % Cg || unit % CH) return hipErrorInvalidValue;
+    if (unit % Cg || unit % CH) {
+        HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_generic_kernel<T>, dim3(B * G), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, eps, relu, cg_true));
+        return hipGetLastError();
+    }
     int CS = unit;
     while (CS * 2 <= C && CS * 2 <= 256 && (CS * 2) / CH <= 32 && (long)HW * CS * 2 <= gn_slab_limit() && C % (CS * 2) == 0) CS *= 2;
     const int cpr = CS / CH;
-    if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) return hipErrorInvalidValue;
+    if (cpr & (cpr - 1) || cpr > 256 || CS > 1024 || C % CS) {
+        HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_generic_kernel<T>, dim3(B * G), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, eps, relu, cg_true));
+        return hipGetLastError();
+    }
     const int grid = B * (C / CS);
     HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, HW, C, G, CS, eps, relu, cg_true));
     return hipGetLastError();

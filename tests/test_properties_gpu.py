@@ -404,3 +404,36 @@ def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
     assert raw.fp16_fallback == set()
     assert not torch.isfinite(r2).all() or raw_err > 2e-2          # silently wrong (or NaN) without the safety net
     raw.close()
+
+
+@pytest.mark.parametrize("depth_hw", [64, 448, 512, 640, 1024])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_every_advertised_depth_frame_size_matches_the_oracle(depth_hw, precision):
+    """Depth frames of any multiple of 64 up to 1024 pixels: the sizes without a golden from the imported reference --
+    the smallest (1 x 1 final map x 2048 channels), the largest (16 x 16 x 8), and a few whose compression channel counts (42, 32, 20) and map
+    sizes take the padded-channel / generic-GroupNorm routes -- against the CPU oracle, both models, one fused step."""
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import HCMConfig
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=64, depth_hw=depth_hw, instr_len=12, bert_layers=1).validate()
+    B = 2
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=3)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=precision, graph=False)
+    obs_np = synth.make_observations(cfg, B, step=0, seed=3)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+    rec, hh2, lh2 = eng.act(obs, hh, lh, torch.zeros(B, device="cuda"))
+    torch.cuda.synchronize()
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    o_obs = {k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}
+    orec, ohh, olh = ora.act(o_obs, torch.zeros(R, B, cfg.hidden), torch.zeros(R, B, cfg.hidden), torch.zeros(B))
+    err = (rec.cpu() - orec).abs().max().item()
+    print(f"depth {depth_hw} [{precision}]: final map {cfg.depth_final_spatial()}^2 x {cfg.depth_compress_channels()} channels, record max-abs {err:.3e}")
+    assert err <= (1e-3 if precision == "fp32" else 1e-2)
+    for got, ref in ((hh2, ohh), (lh2, olh)):
+        rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+        assert rel <= 1e-2
+    eng.close()
