@@ -190,7 +190,10 @@ struct Fwd {
         const int c1 = t.conv1.Cout;
         const int G = t.groups * (t.pair ? 2 : 1);                 // GroupNorm groups over the (possibly paired) channels
         auto CO = [](const ConvW& w) { return w.groups * w.Cout; };   // total output channels of a (grouped) conv
-        const size_t max_elems = (size_t)B * Ho * Wo * c1;      // conv1 output == layer1 output == largest activation
+        // the largest activation: the stem conv's map, or -- when that map has an odd side, so that the pooled map is (Ho + 1) / 2 wide --
+        // layer1's output (4 x the channels on the pooled map)
+        const int Hp_ = (Ho + 2 - 3) / 2 + 1, Wp_ = (Wo + 2 - 3) / 2 + 1;
+        const size_t max_elems = std::max((size_t)B * Ho * Wo * c1, (size_t)B * Hp_ * Wp_ * 4 * c1);
         void* slot[4];
         for (auto& p : slot) p = alloc_t(max_elems);
         // 7x7/2 stem: implicit GEMM gathering straight from the raw frame (permute, /255, dtype conversion fused)

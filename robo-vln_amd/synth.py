@@ -347,7 +347,7 @@ def make_observations(cfg: HCMConfig, batch: int, step: int = 0, seed: int = 0, 
     depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
     # the instruction is per-episode, not per-step: keyed without `step`
     ids = randint("obs/instr", B * L, 1000, cfg.bert_vocab, seed).reshape(B, L)
-    lens = randint("obs/instr_len", B, max(2, L // 2), L + 1, seed)
+    lens = randint("obs/instr_len", B, min(L, max(2, L // 2)), L + 1, seed)
     for b in range(B):
         ids[b, 0] = 101
         ids[b, lens[b] - 1] = 102

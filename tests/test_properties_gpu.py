@@ -437,3 +437,48 @@ def test_every_advertised_depth_frame_size_matches_the_oracle(depth_hw, precisio
         rel = ((got.cpu() - ref).norm() / ref.norm()).item()
         assert rel <= 1e-2
     eng.close()
+
+
+_UNUSUAL = {
+    # name: (config kwargs, batch, instruction length of the call)
+    "rgb32": (dict(rgb_hw=32, depth_hw=64), 3, 12),                       # the smallest RGB frame (1 x 1 layer4 map)
+    "rgb100": (dict(rgb_hw=100, depth_hw=64), 2, 12),                     # even, not a multiple of 32: odd maps 25 / 13 / 7 / 4
+    "rgb250": (dict(rgb_hw=250, depth_hw=64), 2, 12),                     # 125-pixel stem map: none of the power-of-two fast paths
+    "rgb320": (dict(rgb_hw=320, depth_hw=64), 2, 12),                     # 10 x 10 layer4 map -> overlapping adaptive pool windows
+    "hidden256_gru": (dict(rgb_hw=64, depth_hw=64, hidden=256, rnn_type="GRU"), 5, 12),
+    "hidden768": (dict(rgb_hw=64, depth_hw=64, hidden=768), 3, 12),
+    "outs": (dict(rgb_hw=64, depth_hw=64, rgb_out=128, depth_out=64), 3, 12),
+    "rgb226": (dict(rgb_hw=226, depth_hw=64), 2, 12),                     # 113-pixel stem map, 57-pixel pooled map (one more odd pair)
+    "L1": (dict(rgb_hw=64, depth_hw=64), 3, 1),                           # one-token instruction
+    "L512": (dict(rgb_hw=64, depth_hw=64), 2, 512),                       # BERT's whole position table
+    "dff512_N3": (dict(rgb_hw=64, depth_hw=64, d_ff=512, vla_layers=3), 3, 40),
+}
+
+
+@pytest.mark.parametrize("name", list(_UNUSUAL))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_unusual_but_valid_configurations_match_the_oracle(name, precision):
+    """Corners of the configuration space the goldens do not visit (frame sizes off the fast paths, other hidden / output widths, GRU,
+    instruction lengths 1 and 512, a narrower feed-forward): one fused step of both models against the CPU oracle."""
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd.policy import HCMEngine
+    kw, B, L = _UNUSUAL[name]
+    cfg = HCMConfig(instr_len=L, bert_layers=1, **kw).validate()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=11)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=precision, max_instr_len=max(L, 16), graph=False)
+    obs_np = synth.make_observations(cfg, B, step=0, seed=11)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    R = cfg.num_recurrent_layers
+    hh = (torch.rand(R, B, cfg.hidden) - 0.5); lh = (torch.rand(R, B, cfg.hidden) - 0.5)
+    mask = torch.ones(B)
+    rec, hh2, lh2 = eng.act(obs, hh.cuda(), lh.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    orec, ohh, olh = ora.act({k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}, hh, lh, mask)
+    err = (rec.cpu() - orec).abs().max().item()
+    print(f"{name} [{precision}]: record max-abs {err:.3e}")
+    assert err <= (1e-3 if precision == "fp32" else 1.5e-2)
+    for got, ref in ((hh2, ohh), (lh2, olh)):
+        assert ((got.cpu() - ref).norm() / ref.norm()).item() <= 1e-2
+    eng.close()
