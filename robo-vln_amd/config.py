@@ -135,6 +135,11 @@ class CMAConfig:
             raise ValueError("STATE_ENCODER.rnn_type must be LSTM or GRU")
         if self.ablate_instruction or self.ablate_depth or self.ablate_rgb or self.progress_monitor:
             raise ValueError("ablation / progress-monitor branches are not built")
+        hh = self.hidden // 2
+        if self.rgb_out > hh or self.depth_out > hh:
+            # cma.py:281-286: `k, v = torch.split(kv(x), hidden_size // 2, dim=1)` over hidden/2 + output_size channels unpacks into exactly
+            # two pieces only while output_size <= hidden/2 (the reference raises "too many values to unpack" otherwise)
+            raise ValueError("CMANet needs RGB_ENCODER.output_size and DEPTH_ENCODER.output_size <= STATE_ENCODER.hidden_size / 2")
         return self
 
     @property

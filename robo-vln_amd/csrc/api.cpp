@@ -168,6 +168,8 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     REQUIRE(!cfg->progress_monitor, HCM_ERR_UNSUPPORTED, "the progress monitor is a training-only auxiliary loss (cma.py:320-329)");
     REQUIRE(cfg->rnn_type == HCM_LSTM || cfg->rnn_type == HCM_GRU, HCM_ERR_ARG, "STATE_ENCODER.rnn_type must be LSTM or GRU");
     REQUIRE(cfg->hidden >= 64 && cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
+    REQUIRE(cfg->rgb_out <= cfg->hidden / 2 && cfg->depth_out <= cfg->hidden / 2, HCM_ERR_UNSUPPORTED,
+            "CMANet: encoder output sizes must not exceed hidden / 2 (models/cma.py:281-286 unpacks torch.split(kv, hidden // 2) into two pieces)");
     REQUIRE(cfg->instr_hidden >= 4 && cfg->instr_hidden % 4 == 0 && cfg->embedding_size >= 1 && cfg->vocab_size >= 2, HCM_ERR_ARG,
             "bad INSTRUCTION_ENCODER sizes");
     REQUIRE(cfg->instr_len >= 1 && cfg->instr_len <= 256, HCM_ERR_UNSUPPORTED, "1 <= instr_len <= 256");

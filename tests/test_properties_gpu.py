@@ -482,3 +482,72 @@ def test_unusual_but_valid_configurations_match_the_oracle(name, precision):
     for got, ref in ((hh2, ohh), (lh2, olh)):
         assert ((got.cpu() - ref).norm() / ref.norm()).item() <= 1e-2
     eng.close()
+
+
+_CMA_UNUSUAL = {
+    "rgb250_d192": (dict(rgb_hw=250, depth_hw=192, instr_len=20), 2),
+    "gru_uni_outs": (dict(rgb_hw=64, depth_hw=64, instr_len=12, rnn_type="GRU", bidirectional=False, rgb_out=192, depth_out=64), 5),
+    "L200": (dict(rgb_hw=64, depth_hw=64, instr_len=200), 2),
+    "B1": (dict(rgb_hw=96, depth_hw=128, instr_len=20), 1),
+}
+
+
+@pytest.mark.parametrize("name", list(_CMA_UNUSUAL))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cma_unusual_configurations_match_the_oracle(name, precision):
+    """CMANet off the golden configurations (odd RGB maps with a 192-pixel depth frame, a narrower GRU state with a one-directional
+    instruction encoder, the reference's 200-token instructions, a single environment) against the CPU oracle."""
+    from oracle import hcm_oracle
+    from robo_vln_amd.cma import CMAEngine
+    from robo_vln_amd.config import CMAConfig
+    kw, B = _CMA_UNUSUAL[name]
+    with pytest.raises(ValueError):            # as in the reference: kv = hidden / 2 + output_size channels must split into exactly two pieces
+        CMAConfig(hidden=256).validate()
+    cfg = CMAConfig(**kw).validate()
+    sd = synth.make_cma_weights(cfg, 7)
+    eng = CMAEngine(cfg, sd, max_batch=B, precision=precision)
+    obs_np = synth.make_cma_observations(cfg, B, seed=7)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    R = cfg.num_recurrent_layers
+    hid = (torch.rand(R, B, cfg.hidden, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.5
+    mask = torch.ones(B)
+    out, stop, h2 = eng.forward(obs, hid.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    ora = hcm_oracle.CMAOracle(cfg, sd)
+    o_out, o_stop, o_h = ora.forward({k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}, hid, mask)
+    tol = 1e-3 if precision == "fp32" else 1.5e-2
+    e1, e2 = (out.cpu() - o_out).abs().max().item(), (stop.cpu() - o_stop).abs().max().item()
+    print(f"cma {name} [{precision}]: max-abs {e1:.3e} / {e2:.3e}")
+    assert e1 <= tol and e2 <= tol
+    assert ((h2.cpu() - o_h).norm() / o_h.norm()).item() <= 1e-2
+    eng.close()
+
+
+@pytest.mark.parametrize("sizes", [(128, 128), (100, 100), (90, 74), (64, 256), (36, 40)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_simplecnn_low_level_model_frame_sizes(sizes, precision):
+    """Low-level model with SimpleCNN encoders (the only model the reference can build with them) at frame sizes off the 256-pixel default:
+    multiples of 4 (packed-frame first conv, the one-pass depth conv), sizes that are not (element-wise gather), the smallest frames."""
+    from oracle import hcm_oracle
+    from robo_vln_amd.policy import HCMEngine
+    rgb_hw, depth_hw = sizes
+    cfg = HCMConfig(rgb_hw=rgb_hw, depth_hw=depth_hw, depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN").validate()
+    B = 3
+    lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", 5)
+    eng = HCMEngine(cfg, None, lo_sd, max_batch=B + 2, precision=precision, graph=False)            # batch below the engine's maximum
+    obs_np = synth.make_observations(cfg, B, step=0, seed=5)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    R = cfg.num_recurrent_layers
+    h = torch.rand(R, B, cfg.hidden) - 0.5
+    mask = torch.ones(B)
+    st = torch.tensor([0, 3, 1])
+    vel, stop, h2 = eng.low_forward(obs, h.cuda(), mask.cuda(), st.cuda())
+    torch.cuda.synchronize()
+    ora = hcm_oracle.LowLevelOracle(cfg, lo_sd)
+    o_vel, o_stop, o_h = ora.forward({k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}, h, mask, st)
+    tol = 1e-3 if precision == "fp32" else 1.5e-2
+    e1, e2 = (vel.cpu() - o_vel).abs().max().item(), (stop.cpu() - o_stop).abs().max().item()
+    print(f"simplecnn {sizes} [{precision}]: {e1:.3e} / {e2:.3e}")
+    assert e1 <= tol and e2 <= tol
+    assert ((h2.cpu() - o_h).norm() / o_h.norm()).item() <= 1e-2
+    eng.close()
