@@ -1,0 +1,44 @@
+"""Engine lifecycle: create -> a few steps -> close, repeated; device memory must come back (weights, workspace, graphs, events, streams).
+usage: python tools/lifecycle.py [cycles=40]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import hcm_pkg; hcm_pkg.load()
+from robo_vln_amd import synth
+from robo_vln_amd.config import HCMConfig, CMAConfig
+from robo_vln_amd.policy import HCMEngine
+from robo_vln_amd.cma import CMAEngine
+cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
+hi, lo = synth.make_weights(cfg, seed=0)
+ccfg = CMAConfig(rgb_hw=128, depth_hw=128, instr_len=20).validate()
+csd = synth.make_cma_weights(ccfg, 0)
+B = 4
+obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=0).items()}
+cobs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_observations(ccfg, B, seed=0).items()}
+base = None
+hist = []
+for c in range(cycles):
+    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16" if c % 2 else "fp32", graph=bool(c % 3))
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
+    for _ in range(4):
+        rec, hh, lh = eng.act(obs, hh, lh, m)
+    torch.cuda.synchronize()
+    eng.close()
+    ce = CMAEngine(ccfg, csd, max_batch=B, precision="bf16", graph=bool(c % 2))
+    h = torch.zeros(ccfg.num_recurrent_layers, B, ccfg.hidden, device="cuda")
+    for _ in range(3):
+        out, stop, h = ce.forward(cobs, h, m)
+    torch.cuda.synchronize()
+    ce.close()
+    del eng, ce, rec, out, stop
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if base is None: base = free
+    hist.append(free)
+    print(f"cycle {c}: free {free / 2**20:.0f} MiB, drift {(base - free) / 2**20:+.1f} MiB", flush=True)
+# the runtime's own pools (queues, code objects of newly used kernels, graph memory) grow for the first ~25 cycles (+82 MiB measured) and
+# then stay put: a leak would keep going
+assert hist[3 * cycles // 4] - hist[-1] <= 8 * 2**20, "device memory keeps shrinking: leak"
+print("lifecycle ok")
