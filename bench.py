@@ -132,7 +132,7 @@ def hbm_kernel_probe(batch):
     lib = _lib.lib()
     B, H, W, C1, CN = 2 * batch, 64, 64, 64, 64
     C3 = 4 * C1
-    bf = torch.bfloat16
+    bf = torch.float16                 # the storage type of the RGB trunks in 16-bit mode (round 2: fp16, range-calibrated)
     x = torch.randn(B, H, W, C1, device="cuda").to(bf)
     w2 = (torch.randn(C1, 3, 3, C1, device="cuda") * 0.05).to(bf)
     b2 = torch.randn(C1, device="cuda")
@@ -147,12 +147,12 @@ def hbm_kernel_probe(batch):
 
     def run():
         rc = lib.hcm_op_bottleneck_tail_next(x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), idt.data_ptr(),
-                                             y.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), _lib.HCM_BF16, B, H, W, C1, 1, CN, st)
+                                             y.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), _lib.HCM_F16, B, H, W, C1, 1, CN, st)
         assert rc == 0
     ms = _time_op(run, 100, 100)
     M = B * H * W
     gbytes = 2.0 * M * (C1 + 2 * C3 + CN) / 1e9
-    return {"kernel": "bneck231_kernel<bf16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair (M=2*B*4096)",
+    return {"kernel": "bneck231_kernel<f16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair (M=2*B*4096)",
             "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": PEAK_HBM_TBPS,
             "frac": round(gbytes / ms / PEAK_HBM_TBPS, 4)}
 
@@ -407,7 +407,7 @@ def main():
                       f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
             "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None,
-            "dtype": ("bf16+fp16 (16-bit MFMA, fp32 accumulate; DESIGN.md section 5)" if args.precision == "bf16" else "fp32") if args.config != 3
+            "dtype": ("fp16+bf16 (16-bit MFMA, fp32 accumulate: fp16 trunks and BERT, bf16 cross-modal block; DESIGN.md section 5)" if args.precision == "bf16" else "fp32") if args.config != 3
                      else (prec3 + " storage / MFMA, fp32 accumulate"),
             "data": "synthetic (random-init weights, random RGB-D frames and token ids, two observation sets resident in HBM used alternately)",
             "h2d_in_timed_region": bool(args.h2d),

@@ -184,6 +184,7 @@ struct Fwd {
         g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
         g.hpool = hpool;
         ck(launch_igemm(g, w.dt, s), "stem conv (packed)");
+        calib_check(out, w.dt, hpool ? B * Ho * (Wo / 2) : g.M, w.Cout, w.Cout);
     }
 
     Act trunk(const TrunkW& t, const Stem& st, int B, int Ho, int Wo, const std::string& tapname) {
@@ -299,6 +300,7 @@ struct Fwd {
                         if (b.c2.groups > 1) { q.g_w3 = (long long)b.c3ds.Cout * b.c3ds.Kp; q.g_xd = 64; }
                     }
                     ck(launch_bneck23(q, b.c2.dt, s), "bottleneck tail");
+                    calib_check(sc, b.c2.dt, B * Ho2 * Wo2, CO(b.c3), CO(b.c3));        // the block output (the mid tensor never leaves LDS)
                 }
                 if (next) pre = pre_slot;
                 x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
@@ -340,7 +342,10 @@ struct Fwd {
         const int H = ctx->cfg.rgb_h, W = ctx->cfg.rgb_w;
         const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
         // permute(0,3,1,2) + `/ 255.0` (resnet_encoders.py:211-213) are folded into the stem conv's gather
-        return trunk(t, Stem{rgb, rgb_dt, 1.0f / 255.0f, H, W, 3}, B, Ho, Wo, tapname);
+        calib_slot = 2;
+        Act o = trunk(t, Stem{rgb, rgb_dt, 1.0f / 255.0f, H, W, 3}, B, Ho, Wo, tapname);
+        calib_slot = -1;
+        return o;
     }
     Act depth_trunk(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
         calib_slot = 1;
@@ -893,7 +898,9 @@ struct Fwd {
         const hcm_config& c = ctx->cfg;
         use(ctx->dt_rgb);
         if (w.rgb_simple) {
+            calib_slot = 2;
             simple_cnn(w.rgb_s, rgb, rgb_dt, 1.0f / 255.0f, B, lb.xh + c.depth_out, lb.ldx);
+            calib_slot = -1;
         } else {
             Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "lo.rgb");
             void* pooled = alloc_t((size_t)B * o.C);

@@ -10,6 +10,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"].replace("void ", "").replace("hcm::", "")
     if "copyBuffer" in n or n.startswith("at::") or "elementwise_kernel" in n:
         n = "(torch / runtime helper kernels: weight upload copies, synthetic-input generation)"
+    if n.startswith("absmax_kernel"):
+        n = "absmax_kernel (fp16 range calibration at engine construction: not part of a step)"
     t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     e = d.setdefault(n, [0, 0, 1 << 60, 0])
     e[0] += 1; e[1] += t; e[2] = min(e[2], t); e[3] = max(e[3], t)
