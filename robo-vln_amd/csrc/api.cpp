@@ -130,8 +130,6 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     h->cfg = *cfg;
     h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
     // per-sub-network storage type; reserved[0..3] = (dtype + 1) overrides for depth / bert / vla / rgb, 0 = default.
-    // Default in bf16 mode: RGB trunks + cross-modal block on bf16 MFMA tiles; the GroupNorm depth trunk and BERT on
-    // fp16 tiles (same MFMA rate, 3 more mantissa bits) -- measured error budget in DESIGN.md section 5.
     h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
     // 16-bit mode: every sub-network whose fp16 range is checked by the calibration forward (BERT, both ResNet trunk pairs) stores fp16 --
     // same MFMA rate as bf16, three more mantissa bits; the cross-modal block and the small projections stay bf16.
