@@ -192,7 +192,8 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     c.hidden = cfg->hidden; c.rnn_type = cfg->rnn_type; c.num_actions = cfg->num_actions;
     h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
     h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
-    if (h->dt == DT_BF16) h->dt_depth = DT_F16;  // GroupNorm depth trunk on fp16 tiles
+    // both ResNet trunks on range-calibrated fp16 tiles, as in the HCM handle
+    if (h->dt == DT_BF16) { h->dt_depth = DT_F16; if (!getenv("HCM_RGB_BF16")) h->dt_rgb = DT_F16; }
     try {
         build_spec_cma(h);
     } catch (const std::exception& e) {
@@ -274,8 +275,8 @@ static void free_device_weights(hcm_ctx* h) {
 }
 static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, int L, hipStream_t stream) {
     const hcm_config& c = h->cfg;
-    if (h->kind != 0 || (h->dt_bert != DT_F16 && h->dt_depth != DT_F16 && h->dt_rgb != DT_F16)) return HCM_OK;          // nothing stored as fp16
-    const size_t R = c.rnn_type == HCM_LSTM ? 2 : 1;
+    if (h->dt_bert != DT_F16 && h->dt_depth != DT_F16 && h->dt_rgb != DT_F16) return HCM_OK;          // nothing stored as fp16
+    const size_t R = (c.rnn_type == HCM_LSTM ? 2 : 1) * (h->kind == 1 ? 2 : 1);        // CMANet: two state encoders in one tensor
     const size_t n_hid = R * (size_t)B * c.hidden * 4;
     char* tmp = nullptr;
     const size_t total = 4 * n_hid + (size_t)B * 64 * 4 + 4096;
@@ -293,7 +294,9 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     drop_instruction_cache(h);
     std::string err;
     try {
-        if (c.build_high && c.build_low)
+        if (h->kind == 1)
+            run_cma(h, rgb, rgb_dt, depth, ids, ids_dt, B, hh, mask, rec, rec + 8 * (size_t)B, hh2);
+        else if (c.build_high && c.build_low)
             run_step(h, true, true, rgb, rgb_dt, depth, ids, ids_dt, B, hh, lh, mask, nullptr, rec, 7, rec + 4, 7, rec + 6, 7, hh2, lh2);
         else if (c.build_high)
             run_step(h, true, false, rgb, rgb_dt, depth, ids, ids_dt, B, hh, nullptr, mask, nullptr, rec, c.num_actions, nullptr, 0, nullptr, 0, hh2, nullptr);
@@ -328,8 +331,11 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     h->seen_keys.clear();
     try {
         free_device_weights(h);
-        if (c.build_high) prepare_high(h);
-        if (c.build_low) prepare_low(h);
+        if (h->kind == 1) prepare_cma(h);
+        else {
+            if (c.build_high) prepare_high(h);
+            if (c.build_low) prepare_low(h);
+        }
     } catch (const std::exception& e) {
         return fail(h, HCM_ERR_HIP, std::string("re-building a sub-network on bf16 tiles failed: ") + e.what());
     }
@@ -347,8 +353,12 @@ static int calibrate_synthetic(hcm_ctx* h) {
     auto next = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
     for (auto& v : rgb) v = (unsigned char)(next() >> 24);
     for (auto& v : dep) v = (float)(next() >> 8) * (1.0f / 16777216.0f);
-    for (auto& v : ids) v = 1000 + (int64_t)(next() % (uint32_t)(c.bert_vocab > 1001 ? c.bert_vocab - 1000 : 1));
-    for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 101; ids[(size_t)b * L + L - 1] = 102; }
+    if (h->kind == 1) {
+        for (auto& v : ids) v = 1 + (int64_t)(next() % (uint32_t)(h->cma_cfg.vocab_size > 2 ? h->cma_cfg.vocab_size - 1 : 1));      // CMANet's own vocabulary, no padding
+    } else {
+        for (auto& v : ids) v = 1000 + (int64_t)(next() % (uint32_t)(c.bert_vocab > 1001 ? c.bert_vocab - 1000 : 1));
+        for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 101; ids[(size_t)b * L + L - 1] = 102; }
+    }
     char* d = nullptr;
     if (hipMalloc((void**)&d, n_rgb + n_dep * 4 + n_ids * 8 + 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc of the calibration batch failed");
     char* d_dep = d + ((n_rgb + 15) & ~(size_t)15);
@@ -391,7 +401,7 @@ int hcm_finalize(hcm_handle h) {
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
         if (hipMalloc((void**)&h->calib_buf, 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
         // fp16 range check on a synthetic batch; a real batch can follow through hcm_calibrate (reserved[4]: keep the host weights for it)
-        if (h->kind == 0 && !getenv("HCM_NO_CALIB")) {
+        if (!getenv("HCM_NO_CALIB")) {
             const int rc = calibrate_synthetic(h);
             if (rc != HCM_OK) return rc;
         }
@@ -455,11 +465,11 @@ int hcm_finalize(hcm_handle h) {
 int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L, void* stream) {
     int rc = check_fwd(h, B);
     if (rc) return rc;
-    REQUIRE(h->kind == 0, HCM_ERR_STATE, "hcm_calibrate: not an HCM handle");
-    REQUIRE(rgb && depth && (ids || !h->cfg.build_high), HCM_ERR_ARG, "null pointer");
+    const bool needs_ids = h->kind == 1 || h->cfg.build_high;
+    REQUIRE(rgb && depth && (ids || !needs_ids), HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
-    if (h->cfg.build_high && (rc = check_len(h, L))) return rc;
-    return calibrate_run(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, h->cfg.build_high ? L : 1, (hipStream_t)stream);
+    if (needs_ids && (rc = check_len(h, L))) return rc;
+    return calibrate_run(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, needs_ids ? L : 1, (hipStream_t)stream);
 }
 
 int hcm_release_host_weights(hcm_handle h) {

@@ -530,6 +530,10 @@ def test_cma_unusual_configurations_match_the_oracle(name, precision):
     R = cfg.num_recurrent_layers
     hid = (torch.rand(R, B, cfg.hidden, generator=torch.Generator().manual_seed(5)) - 0.5) * 0.5
     mask = torch.ones(B)
+    if precision == "bf16":
+        # both trunks run on fp16 tiles whose range was checked at construction (hcm_finalize: calibration forward), no fall-back needed here
+        assert eng.query(_lib_mod.HCM_FP16_FALLBACK) == 0 and eng.query(_lib_mod.HCM_CALIB_NONFINITE) == 0
+        assert 0 < eng.query(_lib_mod.HCM_CALIB_MAX_DEPTH) < 16384 and 0 < eng.query(_lib_mod.HCM_CALIB_MAX_RGB) < 16384
     out, stop, h2 = eng.forward(obs, hid.cuda(), mask.cuda())
     torch.cuda.synchronize()
     ora = hcm_oracle.CMAOracle(cfg, sd)
