@@ -51,11 +51,12 @@ enum hcm_query_what {
     HCM_MAX_BATCH = 6,
     HCM_GRAPH_LAUNCHES = 7,        /* hcm_act calls served by a captured hipGraph replay */
     HCM_EAGER_LAUNCHES = 8,
-    HCM_FP16_FALLBACK = 9,         /* bit 0: BERT, bit 1: the depth trunks, bit 2: the RGB trunks were re-built on bf16 tiles after a range calibration */
+    HCM_FP16_FALLBACK = 9,         /* bit 0: BERT, bit 1: the depth trunks, bit 2: the RGB trunks, bit 3: the cross-modal block were re-built on bf16 tiles after a range calibration */
     HCM_CALIB_MAX_BERT = 10,       /* max |x| (rounded down) over the GEMM outputs of BERT / the depth trunks in the last calibration forward */
     HCM_CALIB_MAX_DEPTH = 11,
     HCM_CALIB_NONFINITE = 12,      /* non-finite values seen in the last calibration forward */
-    HCM_CALIB_MAX_RGB = 13         /* as HCM_CALIB_MAX_BERT, over the conv outputs of the RGB trunks */
+    HCM_CALIB_MAX_RGB = 13,        /* as HCM_CALIB_MAX_BERT, over the conv outputs of the RGB trunks */
+    HCM_CALIB_MAX_VLA = 14         /* ... over the cross-modal block (its GEMM outputs and the fused layer's LDS-only intermediates) */
 };
 
 /* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,

@@ -134,7 +134,11 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     // 16-bit mode: every sub-network whose fp16 range is checked by the calibration forward (BERT, both ResNet trunk pairs) stores fp16 --
     // same MFMA rate as bf16, three more mantissa bits; the cross-modal block and the small projections stay bf16.
     // HCM_RGB_BF16=1: the RGB trunks on bf16 tiles as in round 1 (A/B knob).
-    if (h->dt == DT_BF16) { h->dt_depth = DT_F16; h->dt_bert = DT_F16; if (!getenv("HCM_RGB_BF16")) h->dt_rgb = DT_F16; }
+    if (h->dt == DT_BF16) {
+        h->dt_depth = DT_F16; h->dt_bert = DT_F16;
+        if (!getenv("HCM_RGB_BF16")) h->dt_rgb = DT_F16;
+        if (!getenv("HCM_VLA_BF16")) h->dt_vla = DT_F16;      // the cross-modal block too (fourth calibration slot; the fused layer checks its LDS-only intermediates itself)
+    }
     {
         int* slots[4] = {&h->dt_depth, &h->dt_bert, &h->dt_vla, &h->dt_rgb};
         for (int i = 0; i < 4; ++i) {
@@ -275,7 +279,7 @@ static void free_device_weights(hcm_ctx* h) {
 }
 static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, int L, hipStream_t stream) {
     const hcm_config& c = h->cfg;
-    if (h->dt_bert != DT_F16 && h->dt_depth != DT_F16 && h->dt_rgb != DT_F16) return HCM_OK;          // nothing stored as fp16
+    if (h->dt_bert != DT_F16 && h->dt_depth != DT_F16 && h->dt_rgb != DT_F16 && h->dt_vla != DT_F16) return HCM_OK;          // nothing stored as fp16
     const size_t R = (c.rnn_type == HCM_LSTM ? 2 : 1) * (h->kind == 1 ? 2 : 1);        // CMANet: two state encoders in one tensor
     const size_t n_hid = R * (size_t)B * c.hidden * 4;
     char* tmp = nullptr;
@@ -284,7 +288,7 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     (void)hipMemsetAsync(tmp, 0, total, stream);
     float* hh = (float*)tmp; float* lh = (float*)(tmp + n_hid); float* hh2 = (float*)(tmp + 2 * n_hid); float* lh2 = (float*)(tmp + 3 * n_hid);
     float* mask = (float*)(tmp + 4 * n_hid); float* rec = mask + B; int64_t* st = (int64_t*)(rec + 16 * (size_t)B);
-    (void)hipMemsetAsync(h->calib_buf, 0, 24, stream);
+    (void)hipMemsetAsync(h->calib_buf, 0, 32, stream);
     const bool conc = h->concurrent;
     h->concurrent = false;                       // one stream: the hooks are plain launches in program order
     h->stream = stream;
@@ -305,26 +309,27 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     } catch (const std::exception& e) { err = e.what(); }
     h->calib = false;
     h->concurrent = conc;
-    unsigned out[6] = {0, 0, 0, 0, 0, 0};
+    unsigned out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const hipError_t se = hipStreamSynchronize(stream);
-    if (se == hipSuccess) (void)hipMemcpy(out, h->calib_buf, 24, hipMemcpyDeviceToHost);
+    if (se == hipSuccess) (void)hipMemcpy(out, h->calib_buf, 32, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (!err.empty()) return fail(h, HCM_ERR_HIP, "calibration forward failed: " + err);
     if (se != hipSuccess) return fail(h, HCM_ERR_HIP, "calibration forward failed to complete");
     int rebuild = 0;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         std::memcpy(&h->calib_max[i], &out[2 * i], 4);
         h->calib_bad[i] = out[2 * i + 1];
-        const bool is_f16 = (i == 0 ? h->dt_bert : i == 1 ? h->dt_depth : h->dt_rgb) == DT_F16;
+        const bool is_f16 = (i == 0 ? h->dt_bert : i == 1 ? h->dt_depth : i == 2 ? h->dt_rgb : h->dt_vla) == DT_F16;
         if (is_f16 && (h->calib_bad[i] || h->calib_max[i] > 16384.0f)) rebuild |= 1 << i;
     }
     if (!rebuild) return HCM_OK;
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
-                    " depth / " + std::to_string(h->calib_max[2]) + " RGB) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
+                    " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
     if (rebuild & 1) h->dt_bert = DT_BF16;
     if (rebuild & 2) h->dt_depth = DT_BF16;
     if (rebuild & 4) h->dt_rgb = DT_BF16;
+    if (rebuild & 8) h->dt_vla = DT_BF16;
     h->fp16_fallback |= rebuild;
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);      // captured with the old weight pointers
     h->graphs.clear();
@@ -336,7 +341,20 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
             if (c.build_high) prepare_high(h);
             if (c.build_low) prepare_low(h);
         }
+        // sub-networks of different storage types hand their tensors over through conversion buffers that a uniform-type plan does not have:
+        // size the workspace again for the new plan
+        dry_run(h, c.max_batch);
+        h->arena.dry = false;
+        if (h->arena.peak + 4096 > h->arena.cap) {
+            if (stream) (void)hipStreamSynchronize(stream); else (void)hipDeviceSynchronize();
+            (void)hipFree(h->arena.base);
+            h->arena.base = nullptr;
+            h->arena.cap = h->arena.peak + 4096;
+            if (hipMalloc((void**)&h->arena.base, h->arena.cap) != hipSuccess)
+                return fail(h, HCM_ERR_NOMEM, "hipMalloc of the workspace failed (" + std::to_string(h->arena.cap) + " bytes)");
+        }
     } catch (const std::exception& e) {
+        h->arena.dry = false;
         return fail(h, HCM_ERR_HIP, std::string("re-building a sub-network on bf16 tiles failed: ") + e.what());
     }
     return HCM_OK;
@@ -664,7 +682,8 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_FP16_FALLBACK: *out = h->fp16_fallback; break;
         case HCM_CALIB_MAX_BERT: *out = (int64_t)h->calib_max[0]; break;
         case HCM_CALIB_MAX_DEPTH: *out = (int64_t)h->calib_max[1]; break;
-        case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1] + (int64_t)h->calib_bad[2]; break;
+        case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1] + (int64_t)h->calib_bad[2] + (int64_t)h->calib_bad[3]; break;
+        case HCM_CALIB_MAX_VLA: *out = (int64_t)h->calib_max[3]; break;
         case HCM_CALIB_MAX_RGB: *out = (int64_t)h->calib_max[2]; break;
         default: return fail(h, HCM_ERR_ARG, "hcm_query: unknown selector");
     }

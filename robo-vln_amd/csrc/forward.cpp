@@ -565,6 +565,7 @@ struct Fwd {
         const VlaW& v = w.vla;
         const int d = c.d_model, rC = 2048 + 64, dS = w.depth_S, dC = w.depth_C;
         use(ctx->dt_vla);
+        calib_slot = 3;                       // range hooks of the cross-modal block's GEMM outputs (calibration forward)
         const size_t m = ar.mark();
         const int S = stream == 0 ? 16 : dS;
         const void* tok = stream == 0 ? hb.rgb_tok : hb.dep_tok;
@@ -588,6 +589,7 @@ struct Fwd {
         }
         // NOTE: no ar.release(m): chains run concurrently and allocate from one bump arena
         (void)m;
+        calib_slot = -1;
     }
     // The instruction stream of Visual_Ling_Attn (transformer.py:263-269): identical for both calls, depends on BERT only.
     void hi_ins_pre(int B, HiBufs& hb) {
@@ -596,6 +598,7 @@ struct Fwd {
         const int L = ctx->cur_L, d = c.d_model, rows = B * L;
         const size_t rmax = (size_t)B * c.instr_len;
         use(ctx->dt_vla);
+        calib_slot = 3;
         void* emb = hb.emb;
         if (ctx->dt_bert != ctx->dt_vla) {
             void* e2 = alloc_t(rmax * c.bert_hidden);
@@ -606,6 +609,7 @@ struct Fwd {
         linear(v.ins_fc, emb, rows, c.bert_hidden, tmp, d, ACT_RELU, false);
         ln(tmp, nullptr, v.ln, v.pe, L, hb.I, rows, d, 1e-5f);     // LN then + PE; identical for both calls -> computed once
         for (size_t l = 0; l < v.layers.size(); ++l) linear(v.layers[l].q, hb.I, rows, d, hb.Q[l], d, ACT_NONE, false);
+        calib_slot = -1;
     }
     LoBufs lo_alloc(int B) {
         LoBufs b;
@@ -764,6 +768,7 @@ struct Fwd {
         const int ldx = hb.ldx;
         float* xh = hb.xh;
         use(ctx->dt_vla);
+        calib_slot = 3;                       // (the recurrent GEMMs behind the block are fp32: their hooks are no-ops)
         const VlaW& v = w.vla;
         const int rows = B * L;
         void* I = hb.I;
@@ -809,6 +814,7 @@ struct Fwd {
                     q.out[st] = outb[st][l & 1];
                     if (last && pool_in_kernel) { q.pooled[st] = xh + w.rnn.xcol(c.rgb_out + c.depth_out + st * d); q.ld_pool = ldx; }
                 }
+                if (ctx->calib && dt == DT_F16) q.calib = ctx->calib_buf + 2 * 3;      // the kernel's LDS-only intermediates are range-checked inside it
                 if (!dry) ck(launch_vla_post(q, dt, s), "fused cross-modal layer");
             }
             const size_t lastl = (v.layers.size() - 1) & 1;
@@ -878,6 +884,7 @@ struct Fwd {
         if (split) rnn_finish(w.rnn, xh, ldx, B, hi_pre, h_in, mask, h_out, hd);
         else rnn_scan(w.rnn, xh, ldx, T, B / T, h_in, mask, h_out, hd);
         tap_rnn_in("hi.rnn_in", w.rnn, xh, ldx, B);
+        calib_slot = -1;
     }
 
     // ---------------------------------------------------------------- stages of Seq2Seq_LowLevel.forward

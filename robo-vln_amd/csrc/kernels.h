@@ -147,6 +147,7 @@ struct VlaPost {
     const int* lens = nullptr;               // per-environment token counts (ragged batches) or null
     int B = 0, L = 0, Lk[2] = {0, 0}, d_ff = 1024, fuse_att = 0, ld_pool = 0, streams = 2;
     int dbg = 0;
+    unsigned* calib = nullptr;   // calibration forward: {max |x| bits, non-finite count} over everything the kernel rounds to the storage type
 };
 bool vla_post_ok(int dt, int d_model, int heads, int d_ff);
 hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s);

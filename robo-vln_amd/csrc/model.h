@@ -200,8 +200,8 @@ struct hcm_ctx {
     bool calib = false;
     unsigned* calib_buf = nullptr;       // device, 4 words
     int fp16_fallback = 0;               // bit 0: BERT was re-built on bf16 tiles, bit 1: the depth trunks
-    float calib_max[3] = {0.f, 0.f, 0.f};     // last calibration's max |x| per sub-network: BERT, depth trunks, RGB trunks
-    unsigned calib_bad[3] = {0u, 0u, 0u};
+    float calib_max[4] = {0.f, 0.f, 0.f, 0.f};     // last calibration's max |x| per sub-network: BERT, depth trunks, RGB trunks, cross-modal block
+    unsigned calib_bad[4] = {0u, 0u, 0u, 0u};
     bool host_weights = true;            // the f32 host copies of the state_dicts are still held (needed to re-build a sub-network)
     const int* cur_lens = nullptr;  // optional per-environment instruction lengths of the current call (device, [B]); null = all L
 };

@@ -66,10 +66,16 @@ __device__ __forceinline__ v_v4i v_make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
-template <typename T> __device__ __forceinline__ void v_st4(char* p, const float (&v)[4]) {
+// (mx: running max |v| of everything this thread rounds to the storage type -- the fp16 range check of the calibration forward; a NaN counts
+//  as +inf.  The x1 rows and the feed-forward intermediate never leave LDS, so no hook outside the kernel can see them.)
+template <typename T> __device__ __forceinline__ void v_st4(char* p, const float (&v)[4], float& mx) {
     T o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Tr<T>::st(&o[e], v[e]);
+    for (int e = 0; e < 4; ++e) {
+        Tr<T>::st(&o[e], v[e]);
+        const float a = fabsf(v[e]);
+        mx = (a != a) ? __builtin_inff() : fmaxf(mx, a);
+    }
     *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(o);
 }
 template <typename T> __device__ __forceinline__ void v_ld4(const char* p, float (&v)[4]) {
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     const int b = blockIdx.x / nblk, r0 = (blockIdx.x - b * nblk) * V_RB;
     const int nrow = p.L - r0 < V_RB ? p.L - r0 : V_RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float cmax = 0.f;                                  // max |x| of what this thread rounds to T (calibration forward: p.calib)
     const T* q = reinterpret_cast<const T*>(p.q) + ((size_t)b * p.L + r0) * V_D;
     const T* I = reinterpret_cast<const T*>(p.I) + ((size_t)b * p.L + r0) * V_D;
     T* out = reinterpret_cast<T*>(p.out[st]) + ((size_t)b * p.L + r0) * V_D;
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < V_MF; ++j) v_st4<T>(sX + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, v[i][j]);
+        for (int j = 0; j < V_MF; ++j) v_st4<T>(sX + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, v[i][j], cmax);
     __syncthreads();
     if (V_DBG(p) & 32) return;
 
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             for (int j = 0; j < V_MF; ++j) {
                 const float h[4] = {fmaxf(acc1[i][j][0] + bb.x, 0.f), fmaxf(acc1[i][j][1] + bb.y, 0.f), fmaxf(acc1[i][j][2] + bb.z, 0.f),
                                     fmaxf(acc1[i][j][3] + bb.w, 0.f)};
-                v_st4<T>(sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, h);
+                v_st4<T>(sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, h, cmax);
             }
         }
         __syncthreads();
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
 #pragma unroll
         for (int j = 0; j < V_MF; ++j) {
             char* dst = sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2;
-            v_st4<T>(dst, v[i][j]);
+            v_st4<T>(dst, v[i][j], cmax);
             if (p.pooled[st] && r0 + j * 16 + fr < len) {
                 float r4[4];
                 v_ld4<T>(dst, r4);
@@ -433,6 +440,13 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     for (int e = tid; e < nrow * 32; e += 512) {
         const int row = e >> 5, c = e & 31;
         *reinterpret_cast<uint4*>(out + (size_t)row * V_D + c * 8) = *reinterpret_cast<const uint4*>(sA + row * V_LDA + c * 16);
+    }
+    if (p.calib) {                                     // fp16 range check (absmax_kernel's slot format: max |x| bits, non-finite count)
+        const float m = wave_max(cmax);
+        if (lane == 0) {
+            if (m <= 3.0e38f) atomicMax(p.calib, __float_as_uint(m));
+            else atomicAdd(p.calib + 1, 1u);
+        }
     }
 }
 

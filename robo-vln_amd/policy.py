@@ -126,13 +126,13 @@ class HCMEngine:
 
     @property
     def fp16_fallback(self):
-        """Sub-networks the range calibration moved from fp16 to bf16 storage: subset of {"bert", "depth", "rgb"}."""
+        """Sub-networks the range calibration moved from fp16 to bf16 storage: subset of {"bert", "depth", "rgb", "vla"}."""
         bits = self.query(_lib.HCM_FP16_FALLBACK)
-        return {n for b, n in ((1, "bert"), (2, "depth"), (4, "rgb")) if bits & b}
+        return {n for b, n in ((1, "bert"), (2, "depth"), (4, "rgb"), (8, "vla")) if bits & b}
 
     def calibration_report(self):
         return {"bert_max_abs": self.query(_lib.HCM_CALIB_MAX_BERT), "depth_max_abs": self.query(_lib.HCM_CALIB_MAX_DEPTH),
-                "rgb_max_abs": self.query(_lib.HCM_CALIB_MAX_RGB),
+                "rgb_max_abs": self.query(_lib.HCM_CALIB_MAX_RGB), "vla_max_abs": self.query(_lib.HCM_CALIB_MAX_VLA),
                 "non_finite": self.query(_lib.HCM_CALIB_NONFINITE), "fp16_fallback": sorted(self.fp16_fallback)}
 
     def calibrate(self, observations, release_host_weights=True):

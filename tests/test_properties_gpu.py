@@ -340,7 +340,7 @@ def test_fp16_calibration_reports_ranges_and_keeps_fp16_on_ordinary_weights():
     eng, rec, err, obs = _run_vs_oracle(cfg, hi_sd, lo_sd, keep_host_weights=True)
     rep = eng.calibration_report()
     assert rep["fp16_fallback"] == [] and rep["non_finite"] == 0
-    assert 0 < rep["bert_max_abs"] < 16384 and 0 < rep["depth_max_abs"] < 16384 and 0 < rep["rgb_max_abs"] < 16384
+    assert 0 < rep["bert_max_abs"] < 16384 and 0 < rep["depth_max_abs"] < 16384 and 0 < rep["rgb_max_abs"] < 16384 and 0 < rep["vla_max_abs"] < 16384
     assert err <= 1e-2
     rep2 = eng.calibrate(obs)                        # the caller's own observations: same verdict, host copies released afterwards
     assert rep2["fp16_fallback"] == [] and 0 < rep2["bert_max_abs"] < 16384
@@ -364,7 +364,7 @@ def test_bert_outlier_channels_stay_in_fp16_range():
     eng.close()
 
 
-@pytest.mark.parametrize("which", ["bert", "depth", "rgb"])
+@pytest.mark.parametrize("which", ["bert", "depth", "rgb", "vla"])
 def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
     """Weights that push a GEMM output of an fp16 sub-network past 65504 (BERT: FFN1 of layer 0 scaled by 2^16; depth: a large-map 3x3
     conv scaled by 2^16 -- the GroupNorm / LayerNorm that follows makes the reference indifferent to the scale): with fp16 storage the
@@ -381,6 +381,11 @@ def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
         for sd in (hi_sd, lo_sd):
             k = "depth_encoder.visual_encoder.backbone.layer1.0.convs.3.weight"
             sd[k] = sd[k] * 65536.0
+    elif which == "vla":
+        # the feed-forward intermediate of the cross-modal layer: it exists only in the LDS of the fused kernel, so this also checks the
+        # kernel's own range check (no hook outside can see it); the LayerNorm behind fc2 keeps the result well-scaled
+        for k in ("image_cm_encoder.layers.0.pwff.fc1.weight", "image_cm_encoder.layers.0.pwff.fc1.bias"):
+            hi_sd[k] = hi_sd[k] * 65536.0
     else:
         # RGB: BatchNorm is folded into the conv weights, so a weight scale cancels; a large BatchNorm gain on the last block does not: features
         # of a few 10^4 (past the 2^14 guard band) that the LayerNorm of the cross-modal block and the saturating cells downstream absorb
@@ -392,18 +397,21 @@ def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
     eng, rec, err, obs = _run_vs_oracle(cfg, hi_sd, lo_sd)
     rep = eng.calibration_report()
     print(f"forced {which} overflow: fallback {rep}, record error vs oracle {err:.3e}")
-    assert eng.fp16_fallback == {which}
+    # (features of 3.6e4 out of the RGB trunks also push the cross-modal block's rgb_kv projection past the guard band)
+    assert eng.fp16_fallback == ({"rgb", "vla"} if which == "rgb" else {which})
     assert torch.isfinite(rec).all()
     if which != "rgb":
         assert err <= 3e-2               # the bf16 budget of that sub-network (depth alone 1.9e-2)
     else:
-        # features of 3 x 10^4 are not a regime the 1e-2 budget was set for; what must hold is that the re-built engine IS the bf16-RGB engine
+        # features of 3 x 10^4 are not a regime the 1e-2 budget was set for; what must hold is that the re-built engine IS the engine with
+        # bf16 RGB trunks and a bf16 cross-modal block
         import os
         os.environ["HCM_RGB_BF16"] = "1"
+        os.environ["HCM_VLA_BF16"] = "1"
         try:
             ref_eng, ref_rec, _, _ = _run_vs_oracle(cfg, hi_sd, lo_sd)
         finally:
-            del os.environ["HCM_RGB_BF16"]
+            del os.environ["HCM_RGB_BF16"], os.environ["HCM_VLA_BF16"]
         assert ref_eng.fp16_fallback == set() and torch.equal(rec, ref_rec)
         ref_eng.close()
     eng.close()
