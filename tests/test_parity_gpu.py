@@ -15,9 +15,10 @@ TOL = {"fp32": 1e-3, "bf16": 1e-2}
 
 
 # Intermediate tensors (step 0, whole tensors vs the oracle): relative l2 bounds.  The fp32 path only re-orders sums; the 16-bit
-# path rounds storage to 8 (bf16) / 11 (fp16) significant bits per layer.  Measured over all cases at the round-2 state: fp32
-# <= 6e-6; 16-bit <= 1.2e-2 (worst: hi.vla_depth, the cross-modal block's bf16 output fed by the depth trunk).
-TAP_REL = {"fp32": 1e-4, "bf16": 2e-2}
+# path rounds storage to 11 significant bits per layer (fp16 everywhere since the end of round 2).  Measured over all cases: fp32
+# <= 1.3e-5; 16-bit <= 9.7e-3 (worst: hi.vla_depth, fed by the depth trunk's few-channel GroupNorm groups; 1.2e-2 while the cross-modal block
+# was on bf16).
+TAP_REL = {"fp32": 1e-4, "bf16": 1.5e-2}
 
 
 def _check(name, precision, **kw):
