@@ -167,6 +167,16 @@ def pmc_traffic(config=1):
         return None
 
 
+def dtype_string(args, eng):
+    """What the 16-bit engine actually stores: fp16 everywhere unless the range calibration moved a sub-network to bf16."""
+    if args.precision != "bf16":
+        return "fp32"
+    fb = sorted(eng.fp16_fallback)
+    if not fb:
+        return "fp16 (range-calibrated fp16 storage and MFMA in BERT, both trunks and the cross-modal block; fp32 accumulate, fp32 recurrent state; DESIGN.md section 5)"
+    return "fp16+bf16 (fp16 storage / MFMA, fp32 accumulate; moved to bf16 by the range calibration: " + ", ".join(fb) + ")"
+
+
 # ------------------------------------------------------------------------------------------------------------ workloads
 def build_act_workload(args, cfg_idx, rank, world, local_rank):
     import torch
@@ -407,8 +417,7 @@ def main():
                       f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
             "value": round(value, 2), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None,
-            "dtype": ("fp16+bf16 (16-bit MFMA, fp32 accumulate: fp16 trunks and BERT, bf16 cross-modal block; DESIGN.md section 5)" if args.precision == "bf16" else "fp32") if args.config != 3
-                     else (prec3 + " storage / MFMA, fp32 accumulate"),
+            "dtype": dtype_string(args, eng) if args.config != 3 else (prec3 + " storage / MFMA, fp32 accumulate"),
             "data": "synthetic (random-init weights, random RGB-D frames and token ids, two observation sets resident in HBM used alternately)",
             "h2d_in_timed_region": bool(args.h2d),
             "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": global_B,
