@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HCM_DEV_LIB=1 loads the development build (`make DEV=1` -> libhcm_dev.so: profiling knobs compiled in); never the default
-LIB_PATH = os.path.join(_HERE, "libhcm_dev.so" if os.environ.get("HCM_DEV_LIB") else "libhcm.so")
+LIB_PATH = os.path.join(_HERE, "libhcm_dev.so" if os.environ.get("HCM_DEV_LIB", "0") not in ("", "0") else "libhcm.so")
 
 HCM_F32, HCM_BF16, HCM_I32, HCM_I64, HCM_U8, HCM_F16 = 0, 1, 2, 3, 4, 5
 HCM_HIGH, HCM_LOW, HCM_CMA = 0, 1, 2

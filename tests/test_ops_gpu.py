@@ -91,6 +91,41 @@ def test_linear(prec, mnk, act):
         assert err <= (tol if not out_f32 or prec == "fp32" else 2e-3) * max(1.0, ref.abs().max().item()), (err, out_f32)
 
 
+@pytest.mark.parametrize("impl", [1, 2])
+def test_gelu_epilogue_accuracy(impl):
+    """The 16-bit paths' erf-GELU (csrc/dev.h gelu_fast: Abramowitz-Stegun 7.1.26, one v_rcp + one v_exp + FMAs) seen by itself:
+    identity weights, zero bias, f32 output, inputs sweeping every fp16 value in [-12, 12] including the subnormals -- against torch's
+    erf-GELU in float64.  Bound: 1e-6 relative to max(|x|, 1) (the form's 1.5e-7 absolute erf error), i.e. far below the fp16 / bf16
+    rounding of the stored value; both GEMM kernels (128-wide implicit GEMM, 256-wide 8-phase) share the function."""
+    lib, L = _lib()
+    code = DT["fp16"][0]
+    N = K = 512
+    allh = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.float16)
+    vals = allh[torch.isfinite(allh) & (allh.abs() <= 12)]
+    M = 12288                                          # 48 x 2 tiles of 256 x 256: a shape the 256-wide launcher accepts
+    assert vals.numel() <= M * K
+    x = torch.zeros(M * K, dtype=torch.float16)
+    x[:vals.numel()] = vals
+    x = x.view(M, K)
+    # each output column n reads input column n only: W = I (exact in fp16, the f32 accumulation adds zeros)
+    w = torch.eye(N, K, dtype=torch.float16)
+    xd, wd, bd = x.cuda(), w.cuda(), torch.zeros(N, device="cuda")
+    ref = F.gelu(x.double())
+    if impl == 1:                                      # (the 256-wide kernel writes 16-bit outputs only)
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+        assert lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), None, _p(y), code, M, N, K, 2, 1, impl, None) == 0
+        torch.cuda.synchronize()
+        err = (y.cpu().double() - ref).abs() / x.double().abs().clamp(min=1.0)
+        assert err.max().item() <= 1e-6, err.max().item()
+    # and the stored 16-bit value is the correctly rounded one except within that error of a rounding boundary
+    y16 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    assert lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), None, _p(y16), code, M, N, K, 2, 0, impl, None) == 0
+    torch.cuda.synchronize()
+    mism = (y16.cpu() != ref.to(torch.float16)) & (x.abs() <= 4)
+    assert mism.float().mean().item() < 2e-3, mism.float().mean().item()
+    assert ((y16.cpu().double() - ref).abs() <= 1e-3 * ref.abs() + 1e-5).all()
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(2, 12, 80, 80), (3, 4, 80, 16), (1, 4, 20, 4), (2, 12, 160, 160), (2, 4, 160, 160), (1, 12, 7, 7)])
 def test_attention(prec, cfg):
