@@ -56,7 +56,10 @@ enum hcm_query_what {
     HCM_CALIB_MAX_DEPTH = 11,
     HCM_CALIB_NONFINITE = 12,      /* non-finite values seen in the last calibration forward */
     HCM_CALIB_MAX_RGB = 13,        /* as HCM_CALIB_MAX_BERT, over the conv outputs of the RGB trunks */
-    HCM_CALIB_MAX_VLA = 14         /* ... over the cross-modal block (its GEMM outputs and the fused layer's LDS-only intermediates) */
+    HCM_CALIB_MAX_VLA = 14,        /* ... over the cross-modal block (its GEMM outputs and the fused layer's LDS-only intermediates) */
+    HCM_STEP_NONFINITE = 15        /* overflow guard: (sample, recurrent step) pairs since hcm_finalize whose gate pre-activations were not all
+                                      finite -- an fp16 overflow or a NaN anywhere upstream of the state encoder lands there, and the squashing
+                                      cell would otherwise turn it into finite garbage.  0 on a healthy engine.  Synchronises the device. */
 };
 
 /* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,
@@ -178,7 +181,10 @@ int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const 
  * activations as fp16, whose range ends at 65504.  hcm_finalize runs one forward on a synthetic batch with range hooks on every GEMM output
  * of those sub-networks; hcm_calibrate does the same on the caller's own observations (device pointers as for hcm_act; zero recurrent
  * state; synchronises the stream).  A sub-network whose max |x| exceeds 2^14 or that produced a non-finite value is re-built on bf16 tiles
- * (needs the host copies of the weights: hcm_config.reserved[4], else HCM_ERR_STATE) and hcm_query(HCM_FP16_FALLBACK) reports it. */
+ * (needs the host copies of the weights: hcm_config.reserved[4], else HCM_ERR_STATE) and hcm_query(HCM_FP16_FALLBACK) reports it; the forward is
+ * then repeated on the re-built engine, so that what sat downstream of the overflow is judged on clean inputs and the reported ranges are
+ * those of the engine as it runs.  At run time NaN / inf are never washed out (ReLU, max-pool and the variance clamps propagate them as
+ * torch's do) and the recurrent cells count what reaches them: hcm_query(HCM_STEP_NONFINITE). */
 int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L, void* stream);
 int hcm_release_host_weights(hcm_handle h);
 

@@ -13,7 +13,7 @@ HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
  HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES, HCM_FP16_FALLBACK, HCM_CALIB_MAX_BERT, HCM_CALIB_MAX_DEPTH,
- HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA) = range(15)
+ HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE) = range(16)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 HCM_ACT_REUSE_INSTRUCTION = 1
 

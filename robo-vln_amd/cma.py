@@ -68,6 +68,10 @@ class CMAEngine:
         _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
         return out.value
 
+    def nonfinite_steps(self):
+        """Overflow guard, as HCMEngine.nonfinite_steps (hcm_query(HCM_STEP_NONFINITE)); synchronises the device."""
+        return self.query(_lib.HCM_STEP_NONFINITE)
+
     @property
     def num_recurrent_layers(self):
         return self.query(_lib.HCM_NUM_RECURRENT_LAYERS)

@@ -277,7 +277,8 @@ static void free_device_weights(hcm_ctx* h) {
     h->hi = hcm::HighW();
     h->lo = hcm::LowW();
 }
-static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, int L, hipStream_t stream) {
+static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, int L, hipStream_t stream,
+                         int pass = 0) {
     const hcm_config& c = h->cfg;
     if (h->dt_bert != DT_F16 && h->dt_depth != DT_F16 && h->dt_rgb != DT_F16 && h->dt_vla != DT_F16) return HCM_OK;          // nothing stored as fp16
     const size_t R = (c.rnn_type == HCM_LSTM ? 2 : 1) * (h->kind == 1 ? 2 : 1);        // CMANet: two state encoders in one tensor
@@ -322,7 +323,12 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
         const bool is_f16 = (i == 0 ? h->dt_bert : i == 1 ? h->dt_depth : i == 2 ? h->dt_rgb : h->dt_vla) == DT_F16;
         if (is_f16 && (h->calib_bad[i] || h->calib_max[i] > 16384.0f)) rebuild |= 1 << i;
     }
+    // NaN / inf travel downstream (ReLU, pools and the variance clamps propagate them, dev.h max_nan): non-finite values in the
+    // cross-modal block while one of its three inputs was already non-finite say nothing about the block itself -- re-build the source
+    // first; the forward below this re-build judges the block on clean inputs
+    if ((rebuild & 8) && (rebuild & 7) && (h->calib_bad[0] || h->calib_bad[1] || h->calib_bad[2])) rebuild &= ~8;
     if (!rebuild) return HCM_OK;
+    (void)hipMemset(h->calib_buf + 12, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
                     " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
@@ -357,7 +363,9 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
         h->arena.dry = false;
         return fail(h, HCM_ERR_HIP, std::string("re-building a sub-network on bf16 tiles failed: ") + e.what());
     }
-    return HCM_OK;
+    // once more on the re-built engine: what was downstream of the overflow is measured on clean inputs now (the reported ranges are
+    // those of the engine as it runs); a sub-network is re-built at most once, so this ends after at most four passes
+    return pass < 4 ? calibrate_run(h, rgb, rgb_dt, depth, ids, ids_dt, B, L, stream, pass + 1) : HCM_OK;
 }
 // deterministic synthetic calibration batch for hcm_finalize: frames of mid-range noise, ids spread over the vocabulary
 static int calibrate_synthetic(hcm_ctx* h) {
@@ -418,6 +426,7 @@ int hcm_finalize(hcm_handle h) {
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
         if (hipMalloc((void**)&h->calib_buf, 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+        if (hipMemset(h->calib_buf, 0, 64) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipMemset failed");       // words 0-7: calibration, 12: step guard
         // fp16 range check on a synthetic batch; a real batch can follow through hcm_calibrate (reserved[4]: keep the host weights for it)
         if (!getenv("HCM_NO_CALIB")) {
             const int rc = calibrate_synthetic(h);
@@ -685,6 +694,14 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1] + (int64_t)h->calib_bad[2] + (int64_t)h->calib_bad[3]; break;
         case HCM_CALIB_MAX_VLA: *out = (int64_t)h->calib_max[3]; break;
         case HCM_CALIB_MAX_RGB: *out = (int64_t)h->calib_max[2]; break;
+        case HCM_STEP_NONFINITE: {           // (synchronises the device: a diagnostic, not a per-step call)
+            unsigned v = 0;
+            if (!h->calib_buf) { *out = 0; break; }
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->calib_buf + 12, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(h, HCM_ERR_HIP, "hcm_query: reading the overflow guard failed");
+            *out = (int64_t)v;
+            break;
+        }
         default: return fail(h, HCM_ERR_ARG, "hcm_query: unknown selector");
     }
     return HCM_OK;

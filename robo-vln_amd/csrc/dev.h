@@ -100,6 +100,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// IEEE-754-2019 maximum (v_maximum3_f32 on gfx950): NaN-propagating, so that relu(NaN) = NaN and max-pool / variance clamps keep a NaN
+// like torch's do -- with fmaxf (maxNum: "the other operand") a NaN or an inf - inf born upstream would be washed into zeros by the next
+// ReLU and come out of the policy as a finite, wrong action; this way it reaches the recurrent cells' overflow guard (HCM_STEP_NONFINITE).
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float relu_f(float v) { return __builtin_elementwise_maximum(v, 0.f); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf-GELU for the 16-bit paths: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. 4 orders of magnitude below the
 // rounding of the fp16 / bf16 value it is stored as) in 12 instructions -- one v_rcp, one v_exp, FMAs -- instead of the ~50-instruction

@@ -138,7 +138,7 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
         for (int j = 0; j < CH; ++j) {
             m[j] = v[0][j];
 #pragma unroll
-            for (int t = 1; t < 9; ++t) m[j] = fmaxf(m[j], v[t][j]);
+            for (int t = 1; t < 9; ++t) m[j] = max_nan(m[j], v[t][j]);
         }
         st_chunk(y + pix * C + c, m);
     }
@@ -171,7 +171,7 @@ __global__ void vpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int 
         }
         float m[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), v[2][j]);
+        for (int j = 0; j < CH; ++j) m[j] = max_nan(max_nan(v[0][j], v[1][j]), v[2][j]);
         st_chunk(y + e * CH, m);
     }
 }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
         for (int j = 0; j < Cg; ++j) { a += s_sum[g0 + j]; q += s_sq[g0 + j]; }
         const float inv_n = 1.0f / ((float)HW * (float)(cg_true > 0 ? cg_true : Cg));     // cg_true: the group's other channels are zero padding
         const float mean = a * inv_n;
-        const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+        const float var = relu_f(q * inv_n - mean * mean);
         const float rstd = rsqrtf(var + eps);
         const float ga = gamma[c_base + ch];
         s_mean[ch] = mean * rstd * ga - beta[c_base + ch];     // y = x*scale - shift'
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
         for (int j = 0; j < CH; ++j) {
             float o = v[j] * sc[j] - sh[j];
             if (rb) o += r[j];
-            if (relu) o = fmaxf(o, 0.f);
+            if (relu) o = relu_f(o);
             v[j] = o;
         }
         st_chunk(xb + (size_t)p * C, v);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
         }
         const float inv_n = 1.0f / ((float)HW * (float)Cg);
         const float mean = a * inv_n;
-        const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+        const float var = relu_f(q * inv_n - mean * mean);
         s_mean[g] = mean;
         s_rstd[g] = rsqrtf(var + eps);
     }
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
         for (int j = 0; j < CH; ++j) {
             float o = v[j] * sc[j] - sh[j];
             if (res) o += r[j];
-            if (relu) o = fmaxf(o, 0.f);
+            if (relu) o = relu_f(o);
             v[j] = o;
         }
         st_chunk(x + base + (size_t)p * C, v);
@@ -492,13 +492,13 @@ __global__ __launch_bounds__(256) void gn_generic_kernel(T* __restrict__ x, cons
     }
     const float inv_n = 1.0f / ((float)HW * (float)(cg_true > 0 ? cg_true : Cg));
     const float mean = s_a[0] * inv_n;
-    const float rstd = rsqrtf(fmaxf(s_q[0] * inv_n - mean * mean, 0.f) + eps);
+    const float rstd = rsqrtf(relu_f(s_q[0] * inv_n - mean * mean) + eps);
     for (int e = tid; e < n; e += 256) {
         const int p = e / Cg, c = e - p * Cg;
         const size_t off = (size_t)p * C + c;
         float o = (Tr<T>::ld(xb + off) - mean) * rstd * gamma[g * Cg + c] + beta[g * Cg + c];
         if (rb) o += Tr<T>::ld(rb + off);
-        if (relu) o = fmaxf(o, 0.f);
+        if (relu) o = relu_f(o);
         Tr<T>::st(xb + off, o);
     }
 }
@@ -782,8 +782,10 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const float* _
     const int b = blockIdx.x;
     const float mk = mask[b];
     const float* g = gates + (size_t)b * 4 * Hd;
+    bool bad = false;
     for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
         const float c = h_in[(size_t)(B + b) * Hd + j] * mk;          // hidden[1] = c
+        bad |= !isfinite(g[j] + g[Hd + j] + g[2 * Hd + j] + g[3 * Hd + j]);       // (a finite sum has finite terms)
         const float gi = sigmoidf_(g[j]), gf = sigmoidf_(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), go = sigmoidf_(g[3 * Hd + j]);
         const float c2 = gf * c + gi * gg;
         const float h2 = go * tanhf(c2);
@@ -791,6 +793,7 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const float* _
         h_out[(size_t)b * Hd + j] = h2;
         h_out[(size_t)(B + b) * Hd + j] = c2;
     }
+    if (hd.bad && __syncthreads_or(bad) && threadIdx.x == 0) atomicAdd(hd.bad, 1u);
     __syncthreads();
     heads_eval(hs, Hd, hd, b);
 }
@@ -807,8 +810,10 @@ __global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __res
     const float mk = mask[b];
     const float* a = gi + (size_t)b * 3 * Hd;
     const float* c = gh + (size_t)b * 3 * Hd;
+    bool bad = false;
     for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
         const float h = h_in[(size_t)b * Hd + j] * mk;
+        bad |= !isfinite(a[j] + a[Hd + j] + a[2 * Hd + j]) || !isfinite(c[j] + c[Hd + j] + c[2 * Hd + j]);
         const float r = sigmoidf_(a[j] + c[j]);
         const float z = sigmoidf_(a[Hd + j] + c[Hd + j]);
         const float n = tanhf(a[2 * Hd + j] + r * c[2 * Hd + j]);
@@ -816,6 +821,7 @@ __global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __res
         hs[j] = h2;
         h_out[(size_t)b * Hd + j] = h2;
     }
+    if (hd.bad && __syncthreads_or(bad) && threadIdx.x == 0) atomicAdd(hd.bad, 1u);
     __syncthreads();
     heads_eval(hs, Hd, hd, b);
 }
@@ -861,7 +867,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
         const size_t m = e / N;
         float a = bias ? bias[n] : 0.f;
         for (int s_ = 0; s_ < S; ++s_) a += part[(size_t)s_ * total + e];
-        if (act == ACT_RELU) a = fmaxf(a, 0.f);
+        if (act == ACT_RELU) a = relu_f(a);
         else if (act == ACT_GELU) a = gelu_erf(a);
         if (out_f32) reinterpret_cast<float*>(y)[m * ldy + n] = a;
         else Tr<T>::st(reinterpret_cast<T*>(y) + m * ldy + n, a);

@@ -449,8 +449,10 @@ struct Fwd {
         return gates;
     }
     void rnn_finish(const RnnW& w, float* xh, int ld, int B, float* gates, const float* h_in, const float* mask, float* h_out,
-                    const Heads& heads) {
+                    const Heads& heads_in) {
         const int H = ctx->cfg.hidden;
+        Heads heads = heads_in;
+        heads.bad = ctx->calib_buf ? ctx->calib_buf + 12 : nullptr;      // overflow guard of every recurrent step (hcm_query(HCM_STEP_NONFINITE))
         if (ctx->cfg.rnn_type == HCM_LSTM) {
             if (w.early < w.in) {
                 LinW late = w.cat;

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
                     for (int e = 0; e < 8; ++e) v[e] += r8[e];
                     if (p.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
                     float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
                     if (p.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
                     for (int e = 0; e < 8; ++e) v[e] += r8[e];
                     if (p.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
                     float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
                     if (p.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);

@@ -148,7 +148,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
                 const float inv = 1.0f / (float)ne;
                 const float mean = a * inv;
                 gst[pr * 2] = mean;
-                gst[pr * 2 + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
+                gst[pr * 2 + 1] = rsqrtf(relu_f(q * inv - mean * mean) + p.gn_eps);
             }
         }
         __syncthreads();
@@ -289,7 +289,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
         }
         if (p.act == ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
@@ -364,13 +364,13 @@ __device__ __forceinline__ void igemm_epilogue_hpool(const IGemmDev& p, f32x4 (&
             const float4 a = *reinterpret_cast<const float4*>(sc + r0 * LDC + c8 + 4 * h);
             const float4 b = *reinterpret_cast<const float4*>(sc + r1 * LDC + c8 + 4 * h);
             const float4 c = *reinterpret_cast<const float4*>(sc + r2 * LDC + c8 + 4 * h);
-            v[4 * h + 0] = fmaxf(fmaxf(a.x, b.x), c.x); v[4 * h + 1] = fmaxf(fmaxf(a.y, b.y), c.y);
-            v[4 * h + 2] = fmaxf(fmaxf(a.z, b.z), c.z); v[4 * h + 3] = fmaxf(fmaxf(a.w, b.w), c.w);
+            v[4 * h + 0] = max_nan(max_nan(a.x, b.x), c.x); v[4 * h + 1] = max_nan(max_nan(a.y, b.y), c.y);
+            v[4 * h + 2] = max_nan(max_nan(a.z, b.z), c.z); v[4 * h + 3] = max_nan(max_nan(a.w, b.w), c.w);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             v[e] += bias8[e];
-            if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            if (p.act == ACT_RELU) v[e] = relu_f(v[e]);
         }
         const size_t pix = (size_t)((m0 / p.Wo) + row) * Wq + pc;
         if constexpr (sizeof(T) == 2) st_chunk(reinterpret_cast<T*>(p.y) + pix * p.ldy + n, v);
@@ -461,7 +461,7 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
                 const float inv = 1.0f / (float)ne;
                 const float mean = a * inv;
                 gst[pr * 2] = mean;
-                gst[pr * 2 + 1] = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + p.gn_eps);
+                gst[pr * 2 + 1] = rsqrtf(relu_f(q * inv - mean * mean) + p.gn_eps);
             }
         }
         __syncthreads();
@@ -522,7 +522,7 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
         }
         if (p.act == ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
@@ -1399,10 +1399,10 @@ __global__ __launch_bounds__(512) void bneck23_kernel(BneckDev q) {
         for (int j = 0; j < TM; ++j) {
             const int r = wm * (BM / WMc) + j * 16 + fr;
             T o4[4];
-            Tr<T>::st(&o4[0], fmaxf(acc1[i][j][0] + b4.x, 0.f));
-            Tr<T>::st(&o4[1], fmaxf(acc1[i][j][1] + b4.y, 0.f));
-            Tr<T>::st(&o4[2], fmaxf(acc1[i][j][2] + b4.z, 0.f));
-            Tr<T>::st(&o4[3], fmaxf(acc1[i][j][3] + b4.w, 0.f));
+            Tr<T>::st(&o4[0], relu_f(acc1[i][j][0] + b4.x));
+            Tr<T>::st(&o4[1], relu_f(acc1[i][j][1] + b4.y));
+            Tr<T>::st(&o4[2], relu_f(acc1[i][j][2] + b4.z));
+            Tr<T>::st(&o4[3], relu_f(acc1[i][j][3] + b4.w));
             char* dst = smem + (cc >> 6) * (BM * 128) + r * 128 + ((((cc & 63) >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2;
             *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o4);
         }
@@ -1657,10 +1657,10 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
         for (int j = 0; j < TM; ++j) {
             const int r = wm * (BM / WMc) + j * 16 + fr;
             T o4[4];
-            Tr<T>::st(&o4[0], fmaxf(acc1[i][j][0] + b4.x, 0.f));
-            Tr<T>::st(&o4[1], fmaxf(acc1[i][j][1] + b4.y, 0.f));
-            Tr<T>::st(&o4[2], fmaxf(acc1[i][j][2] + b4.z, 0.f));
-            Tr<T>::st(&o4[3], fmaxf(acc1[i][j][3] + b4.w, 0.f));
+            Tr<T>::st(&o4[0], relu_f(acc1[i][j][0] + b4.x));
+            Tr<T>::st(&o4[1], relu_f(acc1[i][j][1] + b4.y));
+            Tr<T>::st(&o4[2], relu_f(acc1[i][j][2] + b4.z));
+            Tr<T>::st(&o4[3], relu_f(acc1[i][j][3] + b4.w));
             char* dst = smem + (cc >> 6) * (BM * 128) + r * 128 + ((((cc & 63) >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2;
             *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o4);
         }

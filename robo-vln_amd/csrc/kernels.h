@@ -159,7 +159,9 @@ struct Heads {            // up to two small linear heads on the new hidden stat
     const float* w1 = nullptr; const float* b1 = nullptr; float* out1 = nullptr; int r1 = 0; int ld1 = 0;
     // optional, fused act() step: pred[b] = argmax(out0 row) (first maximal index, hierarchical_trainer.py:1098) and the low-level model's
     // sub-task embedding row emb[pred] written to emb_out[b*emb_ld ..] -- saves two launches on the step's serial tail
-    int64_t* pred = nullptr; const float* emb = nullptr; float* emb_out = nullptr; int emb_dim = 0, emb_ld = 0, emb_rows = 0;
+    int64_t* pred = nullptr; const float* emb = nullptr; float* emb_out = nullptr; int emb_dim = 0, emb_ld = 0, emb_rows = 0;    // optional overflow guard: incremented once per sample whose gate pre-activations are not all finite (an fp16 overflow or a NaN
+    // anywhere upstream ends up there: the squashing cell would turn it into finite garbage) -- hcm_query(HCM_STEP_NONFINITE)
+    unsigned* bad = nullptr;
 };
 // LSTM cell from pre-activations gates [B][4H] (i,f,g,o), c_in = h_in[1]*mask; writes h_out (2,B,H)
 hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* mask, float* h_out, int B, int Hd,

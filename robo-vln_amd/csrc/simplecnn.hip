@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void depth_conv8x8s4_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float v0 = acc[i][0] + b4[i].x, v1 = acc[i][1] + b4[i].y, v2 = acc[i][2] + b4[i].z, v3 = acc[i][3] + b4[i].w;
-                if (act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (act == ACT_RELU) { v0 = relu_f(v0); v1 = relu_f(v1); v2 = relu_f(v2); v3 = relu_f(v3); }
                 T o[4];
                 Tr<T>::st(&o[0], v0); Tr<T>::st(&o[1], v1); Tr<T>::st(&o[2], v2); Tr<T>::st(&o[3], v3);
                 *reinterpret_cast<uint2*>(yb + (size_t)p * 32 + i * 16 + fg * 4) = *reinterpret_cast<const uint2*>(o);

@@ -134,7 +134,7 @@ __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float4
 #pragma unroll
         for (int w = 0; w < 8; ++w) { a += sRed[(w * V_RB + j * 16 + fr) * 2]; q += sRed[(w * V_RB + j * 16 + fr) * 2 + 1]; }
         const float mean = a * (1.0f / V_D);
-        const float rstd = rsqrtf(fmaxf(q * (1.0f / V_D) - mean * mean, 0.f) + 1e-5f);
+        const float rstd = rsqrtf(relu_f(q * (1.0f / V_D) - mean * mean) + 1e-5f);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
             const float4 bb = b1c[i];
 #pragma unroll
             for (int j = 0; j < V_MF; ++j) {
-                const float h[4] = {fmaxf(acc1[i][j][0] + bb.x, 0.f), fmaxf(acc1[i][j][1] + bb.y, 0.f), fmaxf(acc1[i][j][2] + bb.z, 0.f),
-                                    fmaxf(acc1[i][j][3] + bb.w, 0.f)};
+                const float h[4] = {relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y), relu_f(acc1[i][j][2] + bb.z),
+                                    relu_f(acc1[i][j][3] + bb.w)};
                 v_st4<T>(sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, h, cmax);
             }
         }

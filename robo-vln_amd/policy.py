@@ -135,6 +135,13 @@ class HCMEngine:
                 "rgb_max_abs": self.query(_lib.HCM_CALIB_MAX_RGB), "vla_max_abs": self.query(_lib.HCM_CALIB_MAX_VLA),
                 "non_finite": self.query(_lib.HCM_CALIB_NONFINITE), "fp16_fallback": sorted(self.fp16_fallback)}
 
+    def nonfinite_steps(self):
+        """Overflow guard (hcm_query(HCM_STEP_NONFINITE)): number of (sample, recurrent step) pairs since construction whose gate
+        pre-activations were not all finite -- an fp16 overflow or a NaN anywhere upstream of the state encoders ends up there, and the
+        squashing cell would otherwise turn it into finite garbage.  0 on a healthy engine.  Synchronises the device: call it per episode
+        or per evaluation, not per step."""
+        return self.query(_lib.HCM_STEP_NONFINITE)
+
     def calibrate(self, observations, release_host_weights=True):
         """Range-check the fp16 sub-networks on these observations (hcm_calibrate); returns calibration_report().  Needs
         keep_host_weights=True at construction to be able to re-build a sub-network on bf16 tiles."""

@@ -344,6 +344,7 @@ def test_fp16_calibration_reports_ranges_and_keeps_fp16_on_ordinary_weights():
     assert err <= 1e-2
     rep2 = eng.calibrate(obs)                        # the caller's own observations: same verdict, host copies released afterwards
     assert rep2["fp16_fallback"] == [] and 0 < rep2["bert_max_abs"] < 16384
+    assert eng.nonfinite_steps() == 0                # the run-time overflow guard saw nothing in any of these forwards
     eng.close()
 
 
@@ -400,6 +401,7 @@ def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
     # (features of 3.6e4 out of the RGB trunks also push the cross-modal block's rgb_kv projection past the guard band)
     assert eng.fp16_fallback == ({"rgb", "vla"} if which == "rgb" else {which})
     assert torch.isfinite(rec).all()
+    assert eng.nonfinite_steps() == 0                # re-built engine: the guard starts again and stays silent
     if which != "rgb":
         assert err <= 3e-2               # the bf16 budget of that sub-network (depth alone 1.9e-2)
     else:
@@ -427,10 +429,45 @@ def test_fp16_overflow_falls_back_to_bf16_and_says_so(which):
     z = torch.zeros(R, 2, cfg.hidden, device="cuda")
     r2, _, _ = raw.act(obs, z, z, torch.zeros(2, device="cuda"))
     raw_err = (r2.cpu() - rec).abs().max().item()
-    print(f"   un-calibrated fp16 engine: finite {bool(torch.isfinite(r2).all())}, differs from the calibrated one by {raw_err:.3e}")
+    print(f"   un-calibrated fp16 engine: finite {bool(torch.isfinite(r2).all())}, differs from the calibrated one by {raw_err:.3e}, "
+          f"overflow guard {raw.nonfinite_steps()}")
     assert raw.fp16_fallback == set()
     assert not torch.isfinite(r2).all() or raw_err > 2e-2          # silently wrong (or NaN) without the safety net
     raw.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_runtime_overflow_guard_counts_poisoned_samples(precision, graph):
+    """hcm_query(HCM_STEP_NONFINITE): the recurrent cells squash whatever reaches them, so an inf / NaN upstream (an fp16 overflow, a broken
+    sensor frame) would come out as a finite, wrong action.  The cell kernels count the samples whose gate pre-activations are not all
+    finite: one inf pixel in ONE environment's depth frame is counted once per state encoder and step (high-level + low-level = 2), the other
+    environment's record is untouched (row independence), and clean steps before and after leave the counter alone."""
+    from robo_vln_amd.policy import HCMEngine
+    cfg = _small_cfg()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=3)
+    n = 2
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision, graph=graph)
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, n, seed=3).items()}
+    R = cfg.num_recurrent_layers
+    z = torch.zeros(R, n, cfg.hidden, device="cuda")
+    m = torch.zeros(n, device="cuda")
+    for _ in range(3):
+        clean, _, _ = eng.act(obs, z, z, m)
+    clean = clean.clone()
+    assert eng.nonfinite_steps() == 0
+    bad = dict(obs)
+    bad["depth"] = obs["depth"].clone()
+    bad["depth"][1, 17, 23, 0] = float("inf")
+    steps = 3
+    for _ in range(steps):
+        r, _, _ = eng.act(bad, z, z, m)
+    r = r.clone()
+    assert eng.nonfinite_steps() == 2 * steps, eng.nonfinite_steps()
+    assert torch.equal(r[0], clean[0])
+    r2, _, _ = eng.act(obs, z, z, m)
+    assert torch.equal(r2, clean) and eng.nonfinite_steps() == 2 * steps
+    eng.close()
 
 
 @pytest.mark.parametrize("depth_hw", [64, 448, 512, 640, 1024])
