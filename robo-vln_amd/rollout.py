@@ -81,4 +81,12 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         out.append(full.clone())
         prev_done = done_fn(t, lo, hi)
         st.after_step(hh, lh, prev_done)
+    # overflow guard of the HIP engine (hcm_query(HCM_STEP_NONFINITE)): a NaN / inf anywhere upstream of the state encoders would
+    # otherwise leave the squashing cells as a finite, wrong action -- checked once per rollout (it synchronises), loudly
+    eng = getattr(policy, "engine", None)
+    if eng is not None and hasattr(eng, "nonfinite_steps"):
+        bad = eng.nonfinite_steps()
+        if bad:
+            raise FloatingPointError(f"{bad} (environment, step) pairs of this rollout had non-finite activations in front of a recurrent "
+                                     "cell: broken sensor frames, or a sub-network outside its fp16 range (engine.calibrate(observations))")
     return torch.stack(out)
