@@ -465,6 +465,7 @@ def test_runtime_overflow_guard_counts_poisoned_samples(precision, graph):
     r = r.clone()
     assert eng.nonfinite_steps() == 2 * steps, eng.nonfinite_steps()
     assert torch.equal(r[0], clean[0])
+    assert torch.isnan(r[1]).all()                   # ... and the poisoned environment's record is NaN, as the reference's would be
     r2, _, _ = eng.act(obs, z, z, m)
     assert torch.equal(r2, clean) and eng.nonfinite_steps() == 2 * steps
     eng.close()
