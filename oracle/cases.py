@@ -31,6 +31,10 @@ CASES = {
     "depth192_128": (dict(rgb_hw=128, depth_hw=192, instr_len=20, bert_layers=2), 2, 2, "both"),
     "depth320_128": (dict(rgb_hw=128, depth_hw=320, instr_len=20, bert_layers=1), 1, 1, "both"),
     "depth384_128": (dict(rgb_hw=128, depth_hw=384, instr_len=20, bert_layers=1), 1, 1, "both"),        # 6x6 x 57 (an odd count)
+    # non-square RGB frames (TorchVisionResNet50 ends in adaptive pools, resnet_encoders.py:211-236): landscape 4:3 and a portrait frame
+    # whose stem / pool maps have odd sizes (H 200 -> 100 -> 50, W 152 -> 76 -> 38 ... 7 x 5 final map)
+    "rgb_160x224": (dict(rgb_hw=160, rgb_w=224, depth_hw=128, instr_len=20, bert_layers=2), 2, 2, "both"),
+    "rgb_200x152": (dict(rgb_hw=200, rgb_w=152, depth_hw=128, instr_len=20, bert_layers=1), 1, 1, "both"),
 }
 
 # The reference's eval loop feeds the model the UNPADDED token ids of the episode's instruction as a (1, L) tensor
@@ -125,6 +129,8 @@ CMA_CASES = {
     "cma_256_L80": (dict(), 1, 2),
     # 192-pixel depth frames: 3x3 map x 228 compression channels
     "cma_depth192_L12": (dict(rgb_hw=128, depth_hw=192, instr_len=12), 2, 2),
+    # non-square RGB frames (portrait, odd pooled map sizes)
+    "cma_rgb_200x152_L12": (dict(rgb_hw=200, rgb_w=152, depth_hw=128, instr_len=12), 2, 2),
 }
 
 

@@ -333,7 +333,7 @@ def build_models(cfg, hi_sd=None, lo_sd=None, want_hi=True, want_lo=True):
     mc = model_config(cfg)
     space = obs_space(cfg)
     if cfg.rgb_encoder != "TorchVisionResNet50":
-        space.spaces["rgb"] = _Box(0, 255, (cfg.rgb_hw, cfg.rgb_hw, 3), np.uint8)
+        space.spaces["rgb"] = _Box(0, 255, (*cfg.rgb_shape, 3), np.uint8)
     hi = lo = None
     if want_hi:
         from robo_vln_baselines.models.seq2seq_highlevel_cma import Seq2Seq_HighLevel_CMA

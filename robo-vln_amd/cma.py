@@ -20,7 +20,7 @@ def _to_struct(cfg: CMAConfig, max_batch, precision):
     s.struct_size = C.sizeof(_lib.HcmCmaConfigStruct)
     s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
     s.max_batch = max_batch
-    s.rgb_h = s.rgb_w = cfg.rgb_hw
+    s.rgb_h, s.rgb_w = cfg.rgb_shape
     s.depth_h = s.depth_w = cfg.depth_hw
     s.instr_len = cfg.instr_len
     s.vocab_size, s.embedding_size, s.instr_hidden = cfg.vocab_size, cfg.embedding_size, cfg.instr_hidden
@@ -100,8 +100,8 @@ class CMAEngine:
             rgb = self._dev(observations["rgb"], (torch.float32, torch.uint8))
             depth = self._dev(observations["depth"], (torch.float32,))
             B = rgb.shape[0]
-            if tuple(rgb.shape[1:]) != (c.rgb_hw, c.rgb_hw, 3):
-                raise ValueError(f"rgb must be (B,{c.rgb_hw},{c.rgb_hw},3), got {tuple(rgb.shape)}")
+            if tuple(rgb.shape[1:]) != (*c.rgb_shape, 3):
+                raise ValueError(f"rgb must be (B,{c.rgb_shape[0]},{c.rgb_shape[1]},3), got {tuple(rgb.shape)}")
             if tuple(depth.shape) != (B, c.depth_hw, c.depth_hw, 1):
                 raise ValueError(f"depth must be (B,{c.depth_hw},{c.depth_hw},1), got {tuple(depth.shape)}")
             ids = self._dev(observations["instruction"], (torch.int64, torch.int32, torch.float32))

@@ -10,7 +10,8 @@ from dataclasses import dataclass, asdict
 @dataclass
 class HCMConfig:
     # observation sizes (frames are NHWC)
-    rgb_hw: int = 256
+    rgb_hw: int = 256              # RGB frame height (and width when rgb_w == 0)
+    rgb_w: int = 0                 # RGB frame width; 0 = square.  Non-square frames: TorchVisionResNet50 only (adaptive pools)
     depth_hw: int = 256
     instr_len: int = 80            # L: tokens per instruction of the synthetic workloads; an engine accepts any L <= its max_instr_len per call
     # encoders: cnn_type strings are the reference's
@@ -68,7 +69,14 @@ class HCMConfig:
             # give the map that formula predicts (192 -> 3x3 x 228 channels, 256 -> 4x4 x 128, 320 -> 5x5 x 82)
             if self.depth_hw % 64 or not 64 <= self.depth_hw <= 1024:
                 raise ValueError("depth frame size must be a multiple of 64 for the ResNet depth encoder")
+        if self.rgb_w and self.rgb_w != self.rgb_hw and self.rgb_encoder != "TorchVisionResNet50":
+            raise ValueError("non-square RGB frames: TorchVisionResNet50 only (SimpleRGBCNN is built for square frames)")
         return self
+
+    @property
+    def rgb_shape(self):
+        """(H, W) of the RGB frames."""
+        return self.rgb_hw, (self.rgb_w or self.rgb_hw)
 
     @property
     def num_recurrent_layers(self):
@@ -105,7 +113,8 @@ class CMAConfig:
     """`CMANet` flat baseline (models/cma.py:28-186) with the values of paper_configs/cma_robo.yaml over
     config/default.py:97-115,:180-216: bidirectional LSTM instruction encoder over a 2504-word vocabulary, both
     ResNet-50 encoders in spatial mode, two recurrent state encoders."""
-    rgb_hw: int = 256
+    rgb_hw: int = 256              # RGB frame height (and width when rgb_w == 0)
+    rgb_w: int = 0                 # RGB frame width; 0 = square.  Non-square frames: TorchVisionResNet50 only (adaptive pools)
     depth_hw: int = 256
     instr_len: int = 80            # padded instruction length handed to the model (INSTRUCTION_ENCODER.max_length = 200)
     vocab_size: int = 2504         # INSTRUCTION_ENCODER.vocab_size
@@ -141,6 +150,11 @@ class CMAConfig:
             # two pieces only while output_size <= hidden/2 (the reference raises "too many values to unpack" otherwise)
             raise ValueError("CMANet needs RGB_ENCODER.output_size and DEPTH_ENCODER.output_size <= STATE_ENCODER.hidden_size / 2")
         return self
+
+    @property
+    def rgb_shape(self):
+        """(H, W) of the RGB frames."""
+        return self.rgb_hw, (self.rgb_w or self.rgb_hw)
 
     @property
     def instr_out(self):           # InstructionEncoder.output_size (instruction_encoder.py:49-51)

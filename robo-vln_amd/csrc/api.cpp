@@ -118,12 +118,15 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
         REQUIRE(cfg->vla_layers >= 1 && cfg->bert_layers >= 1, HCM_ERR_ARG, "layer counts must be >= 1");
     }
     REQUIRE(cfg->hidden == 512 || cfg->hidden % 64 == 0, HCM_ERR_UNSUPPORTED, "hidden size must be a multiple of 64");
-    REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
+    // depth: habitat's encoders size themselves from the frame HEIGHT and assume a square final map (resnet_encoders.py:37-62); RGB: the
+    // torchvision trunk ends in adaptive pools and takes any H x W (resnet_encoders.py:211-236), SimpleRGBCNN is kept to square frames
+    REQUIRE(cfg->depth_h == cfg->depth_w, HCM_ERR_UNSUPPORTED, "depth frames must be square");
+    REQUIRE(cfg->rgb_h == cfg->rgb_w || cfg->rgb_encoder == HCM_ENC_RESNET, HCM_ERR_UNSUPPORTED, "SimpleRGBCNN: rgb frames must be square");
     if (cfg->depth_encoder == HCM_ENC_RESNET)
         REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && cfg->depth_h <= 1024, HCM_ERR_UNSUPPORTED,
                 "depth frame size must be a multiple of 64 (habitat's ResNetEncoder: final map (H/2)/32, resnet_encoders.py:37-62)");
     if (cfg->rgb_encoder == HCM_ENC_RESNET)
-        REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
+        REQUIRE(cfg->rgb_h >= 32 && cfg->rgb_w >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
     REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0, HCM_ERR_UNSUPPORTED, "encoder output sizes must be multiples of 4");
     h = new hcm_ctx();
@@ -178,9 +181,9 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     REQUIRE(cfg->instr_hidden >= 4 && cfg->instr_hidden % 4 == 0 && cfg->embedding_size >= 1 && cfg->vocab_size >= 2, HCM_ERR_ARG,
             "bad INSTRUCTION_ENCODER sizes");
     REQUIRE(cfg->instr_len >= 1 && cfg->instr_len <= 256, HCM_ERR_UNSUPPORTED, "1 <= instr_len <= 256");
-    REQUIRE(cfg->depth_h == cfg->depth_w && cfg->rgb_h == cfg->rgb_w, HCM_ERR_UNSUPPORTED, "frames must be square");
+    REQUIRE(cfg->depth_h == cfg->depth_w, HCM_ERR_UNSUPPORTED, "depth frames must be square");
     REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && cfg->depth_h <= 1024, HCM_ERR_UNSUPPORTED, "depth frame size must be a multiple of 64");
-    REQUIRE(cfg->rgb_h >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
+    REQUIRE(cfg->rgb_h >= 32 && cfg->rgb_w >= 32, HCM_ERR_UNSUPPORTED, "rgb frame too small");
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
     REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0 && cfg->num_actions >= 1, HCM_ERR_UNSUPPORTED, "bad output sizes");
     h = new hcm_ctx();

@@ -13,14 +13,14 @@ import torch
 class ObsStager:
     """Reusable pinned staging buffers for a fixed number of environments."""
 
-    def __init__(self, num_envs: int, rgb_hw: int, depth_hw: int, instr_len: int, device: Optional[torch.device] = None,
+    def __init__(self, num_envs: int, rgb_hw, depth_hw: int, instr_len: int, device: Optional[torch.device] = None,
                  pin: Optional[bool] = None):
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         on_gpu = self.device.type == "cuda"
         pin = on_gpu if pin is None else pin
         self.n = num_envs
         self.host = {
-            "rgb": torch.empty(num_envs, rgb_hw, rgb_hw, 3, dtype=torch.uint8, pin_memory=pin),
+            "rgb": torch.empty(num_envs, *((rgb_hw, rgb_hw) if isinstance(rgb_hw, int) else tuple(rgb_hw)), 3, dtype=torch.uint8, pin_memory=pin),
             "depth": torch.empty(num_envs, depth_hw, depth_hw, 1, dtype=torch.float32, pin_memory=pin),
             "instruction": torch.empty(num_envs, instr_len, dtype=torch.int32, pin_memory=pin),
         }

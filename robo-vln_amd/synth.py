@@ -342,8 +342,9 @@ def make_observations(cfg: HCMConfig, batch: int, step: int = 0, seed: int = 0, 
     instruction (B,L) token ids ([CLS]=101 first, [SEP]=102 at len-1, 0-padded)."""
     B, L = batch, cfg.instr_len
     tag = f"obs/{step}"
-    rgb = np.floor(uniform01(tag + "/rgb", B * cfg.rgb_hw * cfg.rgb_hw * 3, seed) * 256.0)
-    rgb = rgb.reshape(B, cfg.rgb_hw, cfg.rgb_hw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
+    rh, rw = cfg.rgb_shape
+    rgb = np.floor(uniform01(tag + "/rgb", B * rh * rw * 3, seed) * 256.0)
+    rgb = rgb.reshape(B, rh, rw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
     depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
     # the instruction is per-episode, not per-step: keyed without `step`
     ids = randint("obs/instr", B * L, 1000, cfg.bert_vocab, seed).reshape(B, L)
@@ -367,8 +368,9 @@ def make_cma_observations(cfg, batch: int, step: int = 0, seed: int = 0, rgb_uin
     in [L/2, L] (InstructionEncoder derives the lengths from `!= 0`, instruction_encoder.py:79)."""
     B, L = batch, cfg.instr_len
     tag = f"obs/{step}"
-    rgb = np.floor(uniform01(tag + "/rgb", B * cfg.rgb_hw * cfg.rgb_hw * 3, seed) * 256.0)
-    rgb = rgb.reshape(B, cfg.rgb_hw, cfg.rgb_hw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
+    rh, rw = cfg.rgb_shape
+    rgb = np.floor(uniform01(tag + "/rgb", B * rh * rw * 3, seed) * 256.0)
+    rgb = rgb.reshape(B, rh, rw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
     depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
     ids = randint("obs/cma_instr", B * L, 1, cfg.vocab_size, seed).reshape(B, L)
     lens = randint("obs/cma_instr_len", B, max(2, L // 2), L + 1, seed)
