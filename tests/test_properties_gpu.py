@@ -517,6 +517,9 @@ _UNUSUAL = {
     "L1": (dict(rgb_hw=64, depth_hw=64), 3, 1),                           # one-token instruction
     "L512": (dict(rgb_hw=64, depth_hw=64), 2, 512),                       # BERT's whole position table
     "dff512_N3": (dict(rgb_hw=64, depth_hw=64, d_ff=512, vla_layers=3), 3, 40),
+    "rgb_480x640": (dict(rgb_hw=480, rgb_w=640, depth_hw=64), 2, 12),     # a VGA frame: 15 x 20 layer4 map
+    "rgb_32x330": (dict(rgb_hw=32, rgb_w=330, depth_hw=64), 3, 12),       # a strip: 1 x 11 layer4 map, 83-pixel pooled rows
+    "rgb_258x34": (dict(rgb_hw=258, rgb_w=34, depth_hw=64), 2, 12),       # ... and its transpose-ish: 9 x 2
 }
 
 
