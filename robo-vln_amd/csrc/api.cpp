@@ -331,7 +331,7 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     // first; the forward below this re-build judges the block on clean inputs
     if ((rebuild & 8) && (rebuild & 7) && (h->calib_bad[0] || h->calib_bad[1] || h->calib_bad[2])) rebuild &= ~8;
     if (!rebuild) return HCM_OK;
-    (void)hipMemset(h->calib_buf + 12, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
+    (void)hipMemset(h->calib_buf + hcm_ctx::kStepBadWord, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
                     " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
@@ -700,7 +700,7 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_STEP_NONFINITE: {           // (synchronises the device: a diagnostic, not a per-step call)
             unsigned v = 0;
             if (!h->calib_buf) { *out = 0; break; }
-            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->calib_buf + 12, 4, hipMemcpyDeviceToHost) != hipSuccess)
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->calib_buf + hcm_ctx::kStepBadWord, 4, hipMemcpyDeviceToHost) != hipSuccess)
                 return fail(h, HCM_ERR_HIP, "hcm_query: reading the overflow guard failed");
             *out = (int64_t)v;
             break;

@@ -452,7 +452,7 @@ struct Fwd {
                     const Heads& heads_in) {
         const int H = ctx->cfg.hidden;
         Heads heads = heads_in;
-        heads.bad = ctx->calib_buf ? ctx->calib_buf + 12 : nullptr;      // overflow guard of every recurrent step (hcm_query(HCM_STEP_NONFINITE))
+        heads.bad = ctx->calib_buf ? ctx->calib_buf + hcm_ctx::kStepBadWord : nullptr;      // overflow guard of every recurrent step (hcm_query(HCM_STEP_NONFINITE))
         if (ctx->cfg.rnn_type == HCM_LSTM) {
             if (w.early < w.in) {
                 LinW late = w.cat;

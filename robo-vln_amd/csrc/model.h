@@ -198,7 +198,9 @@ struct hcm_ctx {
     // fp16 range calibration (hcm_finalize's synthetic batch, hcm_calibrate's caller batch): while `calib` is set the forward code
     // reduces max |x| / non-finite counts of every GEMM output of the fp16 sub-networks into calib_buf[2 * slot] (0 BERT, 1 depth trunks)
     bool calib = false;
-    unsigned* calib_buf = nullptr;       // device, 4 words
+    unsigned* calib_buf = nullptr;       // device, 16 words: [2 * slot] = max |x| bits, [2 * slot + 1] = non-finite count (slots 0 BERT, 1 depth, 2 RGB,
+                                         // 3 cross-modal block); [kStepBadWord] = the run-time overflow guard of the recurrent cells
+    static constexpr int kStepBadWord = 12;
     int fp16_fallback = 0;               // bit 0: BERT was re-built on bf16 tiles, bit 1: the depth trunks
     float calib_max[4] = {0.f, 0.f, 0.f, 0.f};     // last calibration's max |x| per sub-network: BERT, depth trunks, RGB trunks, cross-modal block
     unsigned calib_bad[4] = {0u, 0u, 0u, 0u};
