@@ -2057,10 +2057,10 @@ static hipError_t tune_shape(const IGemmDev& d, int dt, hipStream_t s, int* best
 
 #ifdef HCM_DEV_KNOBS
 // make DEV=1 builds: HCM_IGEMM_TIME=1 brackets every launch with events (synchronising: stand-alone durations) and prints a per-shape
-// table at exit -- how profiles/r2_igemm_shapes.md was made
+// table at exit -- how profiles/r2e_igemm_shapes.md was made
 static hipError_t launch_igemm_impl(const IGemm& g, int dt, hipStream_t s);
 namespace {
-struct ShapeTime { double us = 0; long n = 0; double flop = 0; };
+struct ShapeTime { double us = 0; long n = 0; double flop = 0; double bytes = 0; };
 std::unordered_map<std::string, ShapeTime> g_shape_time;
 struct ShapeTimePrinter {
     ~ShapeTimePrinter() {
@@ -2069,10 +2069,14 @@ struct ShapeTimePrinter {
         std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.second.us > b.second.us; });
         double tot = 0;
         for (auto& kv : v) tot += kv.second.us;
-        fprintf(stderr, "| shape | launches | total us | avg us | TFLOP/s |\n|---|---|---|---|---|\n");
-        for (auto& kv : v)
-            fprintf(stderr, "| %s | %ld | %.0f | %.1f | %.0f |\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.us / kv.second.n,
-                    kv.second.flop / kv.second.us / 1e6);
+        // algorithmic bytes: input map + weights + output (+ identity) once each; fractions against 2.5 PFLOP/s dense 16-bit (f32: 1/16) and 8 TB/s
+        fprintf(stderr, "| shape | launches | total us | avg us | TFLOP/s | of MFMA peak | alg MB / launch | TB/s | of HBM peak |\n|---|---|---|---|---|---|---|---|---|\n");
+        for (auto& kv : v) {
+            const double tf = kv.second.flop / kv.second.us / 1e6, tb = kv.second.bytes / kv.second.us / 1e6;
+            const bool f32 = kv.first.rfind("dt0", 0) == 0;
+            fprintf(stderr, "| %s | %ld | %.0f | %.1f | %.0f | %.3f | %.1f | %.2f | %.3f |\n", kv.first.c_str(), kv.second.n, kv.second.us, kv.second.us / kv.second.n,
+                    tf, tf / (f32 ? 156.0 : 2500.0), kv.second.bytes / kv.second.n / 1e6, tb, tb / 8.0);
+        }
         fprintf(stderr, "total %.0f us\n", tot);
     }
 } g_shape_time_printer;
@@ -2094,7 +2098,10 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     snprintf(key, sizeof key, "dt%d M=%d N=%d K=%d g=%d %dx%d s%d%s%s%s", dt, g.M, g.N, g.K, g.groups, g.KH, g.KW, g.stride, g.res ? " res" : "",
              g.gn_gamma ? " gn" : "", g.cs_part ? " cs" : "");
     ShapeTime& t = g_shape_time[key];
-    t.us += ms * 1e3; t.n += 1; t.flop += 2.0 * g.M * g.N * g.K * (g.groups > 1 ? g.groups : 1);
+    const double gr = g.groups > 1 ? g.groups : 1, esz = dt == DT_F32 ? 4 : 2;
+    t.us += ms * 1e3; t.n += 1; t.flop += 2.0 * g.M * g.N * g.K * gr;
+    const double in_elems = (g.KH * g.KW > 1 || g.H > 1) ? (double)g.B * g.H * g.W * g.Cin : (double)g.M * g.K;
+    t.bytes += gr * ((in_elems + (double)g.N * g.K) * esz + (double)g.M * g.N * (g.out_f32 ? 4 : esz) + (g.res ? (double)g.M * g.N * esz : 0));
     return rc;
 }
 static hipError_t launch_igemm_impl(const IGemm& g, int dt, hipStream_t s) {
