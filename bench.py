@@ -208,20 +208,28 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank):
         stager.host["rgb"].copy_(sets[0]["rgb"].cpu())
         stager.host["depth"].copy_(sets[0]["depth"].cpu())
         stager.host["instruction"].copy_(sets[0]["instruction"].cpu().int())
+        stager.dev["instruction"].copy_(stager.host["instruction"])       # ids change per episode, not per step: resident
 
     def step(mask=None):
         obs = sets[state["tick"] & 1]
         state["tick"] += 1
-        if stager is not None:
+        host_frames = False
+        if stager is not None and args.h2d_prestage:
+            # the frames are copied in front of the step on the caller's stream (what round 1 measured)
             for k in ("rgb", "depth"):
                 stager.dev[k].copy_(stager.host[k], non_blocking=True)
             obs = stager.dev
+        elif stager is not None:
+            # HCM_ACT_HOST_FRAMES: the library reads the pinned host frames itself, one copy per encoder chain inside the (captured) step
+            obs = {"rgb": stager.host["rgb"], "depth": stager.host["depth"], "instruction": stager.dev["instruction"]}
+            host_frames = True
         m = mask1 if mask is None else mask
         if hi_only:
             logits, state["hh"] = eng.high_forward(obs, state["hh"], m)
             return logits
         r, state["hh"], state["lh"] = eng.act(obs, state["hh"], state["lh"], m,
-                                              reuse_instruction=args.reuse_instruction and mask is None and state["tick"] > 3)
+                                              reuse_instruction=args.reuse_instruction and mask is None and state["tick"] > 3,
+                                              host_frames=host_frames)
         return r
     return cfg, B, eng, step, (hi_sd, lo_sd)
 
@@ -275,6 +283,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="include the per-step host->device staging of uint8 RGB + f32 depth "
                     "(pinned buffers) in the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
+    ap.add_argument("--h2d-prestage", action="store_true", help="with --h2d: copy the frames in front of the step on the caller's stream instead of "
+                    "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 

@@ -16,6 +16,7 @@ HCM_LSTM, HCM_GRU = 0, 1
  HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE) = range(16)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 HCM_ACT_REUSE_INSTRUCTION = 1
+HCM_ACT_HOST_FRAMES = 2
 
 STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: KeyError, -4: ValueError, -5: RuntimeError, -6: ValueError,
               -7: MemoryError}

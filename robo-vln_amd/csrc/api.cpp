@@ -638,15 +638,24 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
             "HCM_ACT_REUSE_INSTRUCTION: the previous call on this handle was not an hcm_act step with this batch size and instruction length");
     h->stream = (hipStream_t)stream;
     h->reuse_instruction = reuse;
+    const bool host_frames = (flags & HCM_ACT_HOST_FRAMES) != 0;
+    if (host_frames && !h->stage_rgb) {           // device staging for the largest call: f32 RGB frames + f32 depth frames
+        const size_t n_rgb = (size_t)h->cfg.max_batch * h->cfg.rgb_h * h->cfg.rgb_w * 3 * 4, n_dep = (size_t)h->cfg.max_batch * h->cfg.depth_h * h->cfg.depth_w * 4;
+        if (hipMalloc(&h->stage_rgb, n_rgb) != hipSuccess || hipMalloc((void**)&h->stage_depth, n_dep) != hipSuccess)
+            return fail(h, HCM_ERR_NOMEM, "hipMalloc of the frame staging buffers failed");
+    }
+    h->host_frames = host_frames;
     const int ld = 7;
     const std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)rgb_dtype, (uint64_t)ids_dtype, (uint64_t)rgb, (uint64_t)depth, (uint64_t)ids,
                                        (uint64_t)hi_h_in, (uint64_t)lo_h_in, (uint64_t)mask, (uint64_t)record, (uint64_t)hi_h_out,
                                        (uint64_t)lo_h_out, (uint64_t)stream, (uint64_t)flags, (uint64_t)lengths};
-    rc = run_graphed(h, key, stream, [&]() {
+    auto body = [&]() {
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
-    });
+    };
+    rc = run_graphed(h, key, stream, body);
     h->reuse_instruction = false;
+    h->host_frames = false;
     if (rc == HCM_OK) { h->last_hi_batch = B; h->last_hi_L = L; } else drop_instruction_cache(h);
     return rc;
 }
@@ -718,6 +727,8 @@ void hcm_destroy(hcm_handle h) {
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
     if (h->calib_buf) (void)hipFree(h->calib_buf);
+    if (h->stage_rgb) (void)hipFree(h->stage_rgb);
+    if (h->stage_depth) (void)hipFree(h->stage_depth);
     if (h->len_buf) (void)hipFree(h->len_buf);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);

@@ -1122,6 +1122,16 @@ struct Fwd {
         constexpr int skip = 0;
 #endif
         if (multi) fork_join_begin(4);
+        if (ctx->host_frames && !dry) {
+            // HCM_ACT_HOST_FRAMES: each chain's frames come up from the pinned host buffers on that chain's own stream, so BERT and the other
+            // chain's compute run beside the copies.  The RGB frames go FIRST: the copy engine works in submission order and the RGB trunks are
+            // the long chain (the depth chain's kernels fill gaps, they can start 0.3 ms later)
+            const size_t n_rgb = (size_t)B * ctx->cfg.rgb_h * ctx->cfg.rgb_w * 3 * (rgb_dt == DT_U8 ? 1 : 4), n_dep = (size_t)B * ctx->cfg.depth_h * ctx->cfg.depth_w * 4;
+            ck(hipMemcpyAsync(ctx->stage_rgb, rgb, n_rgb, hipMemcpyHostToDevice, main_s), "rgb frames H2D");
+            ck(hipMemcpyAsync(ctx->stage_depth, depth, n_dep, hipMemcpyHostToDevice, a1), "depth frames H2D");
+            rgb = ctx->stage_rgb;
+            depth = ctx->stage_depth;
+        }
         // Host enqueue order = start order on the GPU: the chains made of many small dependent launches go first (BERT,
         // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
         // chain 3: BERT
@@ -1152,7 +1162,7 @@ struct Fwd {
         else if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
         static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
-        on(rgb_serial ? main_s : a0);
+        on((rgb_serial || ctx->host_frames) ? main_s : a0);        // (staged frames: behind their copy)
         if (do_hi && do_lo && !rpair && !rshare && !ctx->cfg.ablate_rgb && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         if (multi) fork_join_end(4);

@@ -193,6 +193,9 @@ struct hcm_ctx {
     // hcm_act_ex(HCM_ACT_REUSE_INSTRUCTION): skip BERT + the instruction stream of Visual_Ling_Attn and reuse the tensors the
     // previous step left in the workspace (same batch size required); set per call
     bool reuse_instruction = false;
+    // HCM_ACT_HOST_FRAMES: rgb / depth of the current hcm_act_ex call are host pointers; staged per chain into these device buffers
+    bool host_frames = false;
+    void* stage_rgb = nullptr; float* stage_depth = nullptr;
     int last_hi_batch = -1, last_hi_L = -1;   // shape of the cached instruction stream; -1 = none (invalidated by every other entry point)
     int cur_L = 0;                  // instruction length of the current call (<= cfg.instr_len)
     // fp16 range calibration (hcm_finalize's synthetic batch, hcm_calibrate's caller batch): while `calib` is set the forward code

@@ -173,9 +173,19 @@ class HCMEngine:
             t = t.to(dtypes[0])
         return t.to(self.device, non_blocking=True).contiguous()
 
-    def _obs(self, observations, need_ids):
-        rgb = self._dev(observations["rgb"], (torch.float32, torch.uint8))
-        depth = self._dev(observations["depth"], (torch.float32,))
+    def _host_frame(self, t, dtypes, name):
+        # HCM_ACT_HOST_FRAMES: the library copies the frames itself, chain by chain -- they must be page-locked host tensors as they are
+        if not isinstance(t, torch.Tensor) or t.device.type != "cpu" or not t.is_pinned() or not t.is_contiguous() or t.dtype not in dtypes:
+            raise ValueError(f"host_frames=True: {name} must be a contiguous pinned CPU tensor of dtype {' / '.join(str(d) for d in dtypes)}")
+        return t
+
+    def _obs(self, observations, need_ids, host_frames=False):
+        if host_frames:
+            rgb = self._host_frame(observations["rgb"], (torch.float32, torch.uint8), "rgb")
+            depth = self._host_frame(observations["depth"], (torch.float32,), "depth")
+        else:
+            rgb = self._dev(observations["rgb"], (torch.float32, torch.uint8))
+            depth = self._dev(observations["depth"], (torch.float32,))
         B = rgb.shape[0]
         c = self.cfg
         if tuple(rgb.shape[1:]) != (*c.rgb_shape, 3):
@@ -239,14 +249,15 @@ class HCMEngine:
         return vel, stop, h_out
 
     def _act_graph(self, observations, hi_hidden, lo_hidden, masks, flags=0):
+        host_frames = bool(flags & _lib.HCM_ACT_HOST_FRAMES)
         with torch.cuda.device(self.device):
-            rgb, depth, ids, lens, B = self._obs(observations, True)
+            rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
             L = ids.shape[1]
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             if self._gstream is None:
                 self._gstream = torch.cuda.Stream(device=self.device)
             st = self._static
-            if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype:
+            if st is None or st["B"] != B or st["rgb"].dtype != rgb.dtype or st["ids"].dtype != ids.dtype or st["rgb"].device != rgb.device:
                 # the static ids buffer holds the longest instruction; a call uses its first B*L elements, so the graph of a new L
                 # differs by its key only, not by the buffer address
                 st = {"B": B, "tick": 0, "rgb": torch.empty_like(rgb), "depth": torch.empty_like(depth),
@@ -273,6 +284,8 @@ class HCMEngine:
             st["hold"] = (rgb, depth, ids, m, lens)        # keep the caller's tensors alive while the graph may read them
             s_ids = st["ids"][:B * L].view(B, L)
             g_rgb, g_depth, g_ids, g_m = (rgb, depth, ids, m) if direct else (st["rgb"], st["depth"], s_ids, st["mask"])
+            if host_frames:                                # pinned host frames are always read in place (the library stages them)
+                g_rgb, g_depth = rgb, depth
             g_lens = None if lens is None else lens if direct else st["lens"]
             with torch.cuda.stream(gs):
                 i = st["tick"] & 1
@@ -321,11 +334,14 @@ class HCMEngine:
                                                      h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
-    def act(self, observations, hi_hidden, lo_hidden, masks, out=None, reuse_instruction=False):
+    def act(self, observations, hi_hidden, lo_hidden, masks, out=None, reuse_instruction=False, host_frames=False):
         """reuse_instruction=True: the caller asserts that every environment's instruction is the one of the previous act() call
         (no episode ended): BERT and the instruction stream of the cross-modal block are not recomputed (hcm_act_ex).  Off in
-        every parity test and in bench.py's headline number."""
-        flags = _lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0
+        every parity test and in bench.py's headline number.
+        host_frames=True: observations["rgb"] / ["depth"] are PINNED CPU tensors (an ObsStager's host side) and stay there: the
+        library copies each to the device at the head of the encoder chain that reads it (HCM_ACT_HOST_FRAMES), overlapping the copies
+        with BERT and with each other's compute; bit-identical to copying first."""
+        flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
         if self._graph:
             rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks, flags)
             if out is not None:
@@ -333,7 +349,7 @@ class HCMEngine:
                 rec = out
             return rec, hh2, lh2
         with torch.cuda.device(self.device):
-            rgb, depth, ids, lens, B = self._obs(observations, True)
+            rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
             hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)

@@ -122,3 +122,42 @@ def test_rollout_with_cached_instructions_equals_recomputing():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     eng.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("rgb_uint8", [True, False])
+def test_host_frames_equal_device_frames(graph, rgb_uint8):
+    """HCM_ACT_HOST_FRAMES: pinned host frames handed to the library (one host->device copy per encoder chain, inside the captured step)
+    give the same bits as frames the caller copied to the device first -- over several steps whose frames change IN the same pinned
+    buffers (a graph replay must read the new contents), eager and hipGraph, uint8 and float RGB."""
+    from robo_vln_amd.obs import ObsStager
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
+    B, T = 3, 6
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
+    eng_d = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
+    eng_h = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
+    frames = [synth.make_observations(cfg, B, step=t, seed=5, rgb_uint8=rgb_uint8) for t in range(T)]
+    host = {"rgb": torch.empty(B, 128, 128, 3, dtype=torch.uint8 if rgb_uint8 else torch.float32).pin_memory(),
+            "depth": torch.empty(B, 128, 128, 1).pin_memory()}
+    ids = torch.from_numpy(frames[0]["instruction"]).cuda()
+    R = cfg.num_recurrent_layers
+    hh_d = lh_d = hh_h = lh_h = torch.zeros(R, B, cfg.hidden, device="cuda")
+    m = torch.ones(B, device="cuda")
+    for t in range(T):
+        dev = {"rgb": torch.from_numpy(frames[t]["rgb"]).cuda(), "depth": torch.from_numpy(frames[t]["depth"]).cuda(), "instruction": ids}
+        rd, hh_d, lh_d = eng_d.act(dev, hh_d, lh_d, m)
+        rd, hh_d, lh_d = rd.clone(), hh_d.clone(), lh_d.clone()
+        torch.cuda.synchronize()                                   # the previous step has consumed the pinned buffers
+        host["rgb"].copy_(torch.from_numpy(frames[t]["rgb"]))
+        host["depth"].copy_(torch.from_numpy(frames[t]["depth"]))
+        rh, hh_h, lh_h = eng_h.act({"rgb": host["rgb"], "depth": host["depth"], "instruction": ids}, hh_h, lh_h, m, host_frames=True)
+        rh, hh_h, lh_h = rh.clone(), hh_h.clone(), lh_h.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(rd, rh) and torch.equal(hh_d, hh_h) and torch.equal(lh_d, lh_h), t
+    if graph:
+        from robo_vln_amd import _lib
+        assert eng_h.query(_lib.HCM_GRAPH_LAUNCHES) >= 2           # (the copies are nodes of the captured graph)
+    with pytest.raises(ValueError):
+        eng_h.act({"rgb": torch.zeros(B, 128, 128, 3, dtype=torch.uint8), "depth": host["depth"], "instruction": ids}, hh_h, lh_h, m, host_frames=True)
+    eng_d.close(); eng_h.close()
