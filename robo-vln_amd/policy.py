@@ -458,9 +458,9 @@ class Policy:
         self.high_level = Seq2Seq_HighLevel_CMA(engine)
         self.low_level = Seq2Seq_LowLevel(engine)
 
-    def act(self, observations, hi_hidden, lo_hidden, prev_actions, masks, deterministic=True, reuse_instruction=False):
+    def act(self, observations, hi_hidden, lo_hidden, prev_actions, masks, deterministic=True, reuse_instruction=False, host_frames=False):
         """-> (record (B,7) = [4 sub-task logits, lin_vel, ang_vel, stop logit], hi_hidden', lo_hidden')."""
-        return self.engine.act(observations, hi_hidden, lo_hidden, masks, reuse_instruction=reuse_instruction)
+        return self.engine.act(observations, hi_hidden, lo_hidden, masks, reuse_instruction=reuse_instruction, host_frames=host_frames)
 
     def get_value(self, *a, **k):
         """Imitation-learned agent: the reference has no critic / value head anywhere."""
