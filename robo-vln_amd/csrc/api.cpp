@@ -639,10 +639,10 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
     h->stream = (hipStream_t)stream;
     h->reuse_instruction = reuse;
     const bool host_frames = (flags & HCM_ACT_HOST_FRAMES) != 0;
-    if (host_frames && !h->stage_rgb) {           // device staging for the largest call: f32 RGB frames + f32 depth frames
+    if (host_frames && (!h->stage_rgb || !h->stage_depth)) {           // device staging for the largest call: f32 RGB frames + f32 depth frames
         const size_t n_rgb = (size_t)h->cfg.max_batch * h->cfg.rgb_h * h->cfg.rgb_w * 3 * 4, n_dep = (size_t)h->cfg.max_batch * h->cfg.depth_h * h->cfg.depth_w * 4;
-        if (hipMalloc(&h->stage_rgb, n_rgb) != hipSuccess || hipMalloc((void**)&h->stage_depth, n_dep) != hipSuccess)
-            return fail(h, HCM_ERR_NOMEM, "hipMalloc of the frame staging buffers failed");
+        if (!h->stage_rgb && hipMalloc(&h->stage_rgb, n_rgb) != hipSuccess) { h->stage_rgb = nullptr; return fail(h, HCM_ERR_NOMEM, "hipMalloc of the RGB frame staging buffer failed"); }
+        if (!h->stage_depth && hipMalloc((void**)&h->stage_depth, n_dep) != hipSuccess) { h->stage_depth = nullptr; return fail(h, HCM_ERR_NOMEM, "hipMalloc of the depth frame staging buffer failed"); }
     }
     h->host_frames = host_frames;
     const int ld = 7;
