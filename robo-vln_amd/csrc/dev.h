@@ -109,7 +109,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // erf-GELU for the 16-bit paths: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. 4 orders of magnitude below the
 // rounding of the fp16 / bf16 value it is stored as) in 12 instructions -- one v_rcp, one v_exp, FMAs -- instead of the ~50-instruction
 // branchy libm erff: a 256 x 256 output tile is 128 GELUs per thread, which with erff cost as much as the whole K = 768 main loop of
-// BERT's FFN1 (profiles/r2_gemm256.md).  The fp32 path keeps the exact gelu_erf.
+// BERT's FFN1 (44.8 -> 35.0 us per launch).  The fp32 path keeps the exact gelu_erf.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
