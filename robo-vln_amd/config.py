@@ -11,7 +11,7 @@ from dataclasses import dataclass, asdict
 class HCMConfig:
     # observation sizes (frames are NHWC)
     rgb_hw: int = 256              # RGB frame height (and width when rgb_w == 0)
-    rgb_w: int = 0                 # RGB frame width; 0 = square.  Non-square frames: TorchVisionResNet50 only (adaptive pools)
+    rgb_w: int = 0                 # RGB frame width; 0 = square (depth frames are square: habitat sizes its ResNet encoder from the height)
     depth_hw: int = 256
     instr_len: int = 80            # L: tokens per instruction of the synthetic workloads; an engine accepts any L <= its max_instr_len per call
     # encoders: cnn_type strings are the reference's
@@ -69,8 +69,6 @@ class HCMConfig:
             # give the map that formula predicts (192 -> 3x3 x 228 channels, 256 -> 4x4 x 128, 320 -> 5x5 x 82)
             if self.depth_hw % 64 or not 64 <= self.depth_hw <= 1024:
                 raise ValueError("depth frame size must be a multiple of 64 for the ResNet depth encoder")
-        if self.rgb_w and self.rgb_w != self.rgb_hw and self.rgb_encoder != "TorchVisionResNet50":
-            raise ValueError("non-square RGB frames: TorchVisionResNet50 only (SimpleRGBCNN is built for square frames)")
         return self
 
     @property
@@ -114,7 +112,7 @@ class CMAConfig:
     config/default.py:97-115,:180-216: bidirectional LSTM instruction encoder over a 2504-word vocabulary, both
     ResNet-50 encoders in spatial mode, two recurrent state encoders."""
     rgb_hw: int = 256              # RGB frame height (and width when rgb_w == 0)
-    rgb_w: int = 0                 # RGB frame width; 0 = square.  Non-square frames: TorchVisionResNet50 only (adaptive pools)
+    rgb_w: int = 0                 # RGB frame width; 0 = square (depth frames are square: habitat sizes its ResNet encoder from the height)
     depth_hw: int = 256
     instr_len: int = 80            # padded instruction length handed to the model (INSTRUCTION_ENCODER.max_length = 200)
     vocab_size: int = 2504         # INSTRUCTION_ENCODER.vocab_size

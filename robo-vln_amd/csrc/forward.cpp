@@ -370,9 +370,10 @@ struct Fwd {
 
     // SimpleAllCNN.cnn (simple_cnns.py:76-100) -> f32 features into out[b*ld + col0 ..]
     void simple_cnn(const SimpleCnnW& w, const void* x, int x_dt, float scale, int B, float* out, int ld) {
-        const int H = w.hw;
+        const int H = w.h, W = w.w;
         const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
-        void* y0 = alloc_t((size_t)B * h1 * h1 * 32);
+        const int w1 = (W - 8) / 4 + 1, w2 = (w1 - 4) / 2 + 1, w3 = (w2 - 3) / 1 + 1;
+        void* y0 = alloc_t((size_t)B * h1 * w1 * 32);
         static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
         if (w.c0_packed.w && !no_pack && (x_dt == DT_F32 || x_dt == DT_U8) && (w.cin == 3 || x_dt == DT_F32)) {
             // 16-bit path: convert / pack the frame once ([B][H][W][cp], cp = 4 for RGB, 1 for depth); a kernel row of an output
@@ -380,29 +381,29 @@ struct Fwd {
             // pixels" of 4 real ones (the stride): KH = 8, KW = 1, Cin = 8*cp, pixel stride 4*cp elements
             const int cp = w.cin == 3 ? 4 : 1;
             static const bool no_direct = getenv("HCM_NO_DEPTH_CONV0") != nullptr;
-            const bool direct = cp == 1 && !no_direct && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 && depth_conv8x8s4_ok(dt, H, ACT_RELU);
-            void* pk = direct ? nullptr : alloc_t((size_t)B * H * H * cp + 64);
+            const bool direct = cp == 1 && H == W && !no_direct && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 && depth_conv8x8s4_ok(dt, H, ACT_RELU);
+            void* pk = direct ? nullptr : alloc_t((size_t)B * H * W * cp + 64);
             if (direct) {
                 // depth: one pass over the raw f32 frame (simplecnn.hip), bit-identical to convert + implicit GEMM
                 if (!dry) ck(launch_depth_conv8x8s4((const float*)x, w.c0_packed.w, w.c0_packed.bias, y0, dt, B, H, ACT_RELU, s), "simple cnn conv0 (direct)");
             } else if (!dry) {
-                if (cp == 4) ck(launch_pack_frame(x, x_dt, pk, dt, B, H, H, scale, s, 0), "pack frame");
-                else ck(launch_convert_from_f32((const float*)x, pk, dt, (size_t)B * H * H, s), "depth convert");
+                if (cp == 4) ck(launch_pack_frame(x, x_dt, pk, dt, B, H, W, scale, s, 0), "pack frame");
+                else ck(launch_convert_from_f32((const float*)x, pk, dt, (size_t)B * H * W, s), "depth convert");
                 IGemm g;
                 g.x = pk; g.w = w.c0_packed.w; g.bias = w.c0_packed.bias; g.y = y0;
-                g.B = B; g.H = H; g.W = H / 4; g.Cin = 8 * cp; g.xC = 4 * cp;
-                g.Ho = h1; g.Wo = h1; g.KH = 8; g.KW = 1; g.stride = 4; g.stride_w = 1; g.pad = 0;
-                g.M = B * h1 * h1; g.N = 32; g.K = w.c0_packed.K; g.Kp = w.c0_packed.Kp; g.ldy = 32; g.ldr = 32; g.act = ACT_RELU;
+                g.B = B; g.H = H; g.W = W / 4; g.Cin = 8 * cp; g.xC = 4 * cp;
+                g.Ho = h1; g.Wo = w1; g.KH = 8; g.KW = 1; g.stride = 4; g.stride_w = 1; g.pad = 0;
+                g.M = B * h1 * w1; g.N = 32; g.K = w.c0_packed.K; g.Kp = w.c0_packed.Kp; g.ldy = 32; g.ldr = 32; g.act = ACT_RELU;
                 ck(launch_igemm(g, dt, s), "simple cnn conv0 (packed)");
             }
         } else {
-            stem_conv(w.c0, Stem{x, x_dt, scale, H, H, w.cin}, B, 8, 4, 0, y0, h1, h1, ACT_RELU);
+            stem_conv(w.c0, Stem{x, x_dt, scale, H, W, w.cin}, B, 8, 4, 0, y0, h1, w1, ACT_RELU);
         }
-        void* y1 = alloc_t((size_t)B * h2 * h2 * 64);
-        conv(w.c1, Act{y0, B, h1, h1, 32}, y1, 2, 0, nullptr, ACT_RELU, h2, h2);
-        void* y2 = alloc_t((size_t)B * h3 * h3 * 32);
-        conv(w.c2, Act{y1, B, h2, h2, 64}, y2, 1, 0, nullptr, ACT_NONE, h3, h3);
-        linear(w.fc, y2, B, h3 * h3 * 32, out, ld, ACT_RELU, true);
+        void* y1 = alloc_t((size_t)B * h2 * w2 * 64);
+        conv(w.c1, Act{y0, B, h1, w1, 32}, y1, 2, 0, nullptr, ACT_RELU, h2, w2);
+        void* y2 = alloc_t((size_t)B * h3 * w3 * 32);
+        conv(w.c2, Act{y1, B, h2, w2, 64}, y2, 1, 0, nullptr, ACT_NONE, h3, w3);
+        linear(w.fc, y2, B, h3 * w3 * 32, out, ld, ACT_RELU, true);
     }
 
     // ---------------------------------------------------------------- BERT encoder

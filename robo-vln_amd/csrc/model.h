@@ -60,7 +60,7 @@ struct SimpleCnnW {
     ConvW c0, c1, c2;          // 8x8/4 (narrow-channel gather), 4x4/2, 3x3/1
     ConvW c0_packed;           // 16-bit path: k = kh*KR + kw*cp + ci with cp = 4 (RGB, KR = 32) or 1 (depth, KR = 8)
     LinW fc;
-    int cin = 1, hw = 0, h3 = 0;
+    int cin = 1, h = 0, w = 0, h3 = 0, w3 = 0;      // frame H x W, final map h3 x w3
 };
 struct BertLayerW {
     LinW qkv, o, ff1, ff2;

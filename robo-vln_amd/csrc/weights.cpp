@@ -65,12 +65,12 @@ static int simple_cnn_out_hw(int hw) {
     for (int i = 0; i < 3; ++i) d = (d - ks[i]) / st[i] + 1;
     return d;
 }
-static void spec_simple_cnn(SpecB& s, const std::string& pre, int in_ch, int hw, int out_f) {
-    const int d = simple_cnn_out_hw(hw);
+static void spec_simple_cnn(SpecB& s, const std::string& pre, int in_ch, int h, int w, int out_f) {
+    const int dh = simple_cnn_out_hw(h), dw = simple_cnn_out_hw(w);          // simple_cnns.py:63-73: the two dimensions on their own
     s.add(pre + "cnn.0.weight", {32, in_ch, 8, 8}); s.add(pre + "cnn.0.bias", {32});
     s.add(pre + "cnn.2.weight", {64, 32, 4, 4}); s.add(pre + "cnn.2.bias", {64});
     s.add(pre + "cnn.4.weight", {32, 64, 3, 3}); s.add(pre + "cnn.4.bias", {32});
-    s.linear(pre + "cnn.7", out_f, 32 * d * d);
+    s.linear(pre + "cnn.7", out_f, 32 * dh * dw);
 }
 
 static void spec_rnn(SpecB& s, const std::string& pre, const hcm_config& c, int in_f) {
@@ -150,13 +150,13 @@ void build_spec_low(hcm_ctx* ctx) {
         spec_gn_resnet50(s, "depth_encoder.visual_encoder.", 1, c.depth_baseplanes, cc);
         s.linear("depth_encoder.visual_fc.1", c.depth_out, cc * fs * fs);
     } else {
-        spec_simple_cnn(s, "depth_encoder.", 1, c.depth_h, c.depth_out);
+        spec_simple_cnn(s, "depth_encoder.", 1, c.depth_h, c.depth_w, c.depth_out);
     }
     if (c.rgb_encoder == HCM_ENC_RESNET) {
         spec_tv_resnet50(s, "rgb_encoder.cnn.", true);
         s.linear("rgb_encoder.fc", c.rgb_out, 2048);
     } else {
-        spec_simple_cnn(s, "rgb_encoder.", 3, c.rgb_h, c.rgb_out);
+        spec_simple_cnn(s, "rgb_encoder.", 3, c.rgb_h, c.rgb_w, c.rgb_out);
     }
     s.add("sub_task_embedding.weight", {c.num_sub_tasks + 1, 32});
     spec_rnn(s, "state_encoder.rnn.", c, c.depth_out + c.rgb_out + 32);
@@ -629,11 +629,11 @@ static TrunkW make_tv_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     return t;
 }
 
-static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& pre, int cin, int hw) {
+static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& pre, int cin, int h, int w) {
     SimpleCnnW s;
-    s.cin = cin; s.hw = hw; s.h3 = simple_cnn_out_hw(hw);
+    s.cin = cin; s.h = h; s.w = w; s.h3 = simple_cnn_out_hw(h); s.w3 = simple_cnn_out_hw(w);
     s.c0 = make_conv(dt, up, T_(ctx, model, pre + "cnn.0.weight"), nullptr, &T_(ctx, model, pre + "cnn.0.bias").f);
-    if (dt != DT_F32 && (cin == 1 || cin == 3) && hw % 4 == 0) {
+    if (dt != DT_F32 && (cin == 1 || cin == 3) && w % 4 == 0) {
         // packed-frame layout of the 8x8/4 conv (forward.cpp simple_cnn): a kernel row is one contiguous run of 8 pixels
         const HostTensor& w0 = T_(ctx, model, pre + "cnn.0.weight");       // (32, cin, 8, 8)
         const int cp = cin == 3 ? 4 : 1, KR = 8 * cp;
@@ -652,7 +652,7 @@ static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model,
     s.c1 = make_conv(dt, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
     s.c2 = make_conv(dt, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
     // Flatten() of the NCHW (B,32,h,w) tensor: source column c*S + s; ours is NHWC: s*32 + c
-    const int S = s.h3 * s.h3;
+    const int S = s.h3 * s.w3;
     std::vector<int> perm((size_t)S * 32);
     for (int sp = 0; sp < S; ++sp)
         for (int c = 0; c < 32; ++c) perm[(size_t)sp * 32 + c] = c * S + sp;
@@ -829,13 +829,13 @@ void prepare_low(hcm_ctx* ctx) {
             for (int ch = 0; ch < ccp; ++ch) perm[(size_t)s * ccp + ch] = ch < cc ? ch * S + s : -1;
         l.depth_fc = make_linear(up, {&T_(ctx, M, "depth_encoder.visual_fc.1.weight")}, {&T_(ctx, M, "depth_encoder.visual_fc.1.bias")}, ctx->dt_depth, &perm);
     } else {
-        l.depth_s = make_simple_cnn(ctx, ctx->dt_depth, up, M, "depth_encoder.", 1, c.depth_h);
+        l.depth_s = make_simple_cnn(ctx, ctx->dt_depth, up, M, "depth_encoder.", 1, c.depth_h, c.depth_w);
     }
     if (!l.rgb_simple) {
         l.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
         l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt_rgb);
     } else {
-        l.rgb_s = make_simple_cnn(ctx, ctx->dt_rgb, up, M, "rgb_encoder.", 3, c.rgb_h);
+        l.rgb_s = make_simple_cnn(ctx, ctx->dt_rgb, up, M, "rgb_encoder.", 3, c.rgb_h, c.rgb_w);
     }
     l.subtask_emb = up.f32(T_(ctx, M, "sub_task_embedding.weight").f);
     l.rnn = make_rnn(ctx, up, M, "state_encoder.rnn.", ctx->cfg.depth_out + ctx->cfg.rgb_out);   // early: depth | rgb; late: sub-task embedding

@@ -136,13 +136,13 @@ def habitat_gn_resnet50_spec(prefix, in_ch, base, compress_ch):
 
 def simple_cnn_spec(prefix, in_ch, hw, out_f):
     """habitat SimpleCNN as used by simple_cnns.py:51-101 (cnn.{0,2,4,7})."""
-    d = hw
+    dh, dw = (hw, hw) if isinstance(hw, int) else hw          # simple_cnns.py:63-73: the two dimensions on their own
     for k, st in ((8, 4), (4, 2), (3, 1)):
-        d = (d - k) // st + 1
+        dh, dw = (dh - k) // st + 1, (dw - k) // st + 1
     s = [(prefix + "cnn.0.weight", (32, in_ch, 8, 8), "w", (in_ch * 64, RELU_GAIN)), (prefix + "cnn.0.bias", (32,), "b", None)]
     s += [(prefix + "cnn.2.weight", (64, 32, 4, 4), "w", (32 * 16, RELU_GAIN)), (prefix + "cnn.2.bias", (64,), "b", None)]
     s += [(prefix + "cnn.4.weight", (32, 64, 3, 3), "w", (64 * 9, 1.0)), (prefix + "cnn.4.bias", (32,), "b", None)]
-    s += _linear(prefix + "cnn.7", out_f, 32 * d * d, gain=RELU_GAIN)
+    s += _linear(prefix + "cnn.7", out_f, 32 * dh * dw, gain=RELU_GAIN)
     return s
 
 
@@ -250,7 +250,7 @@ def low_level_spec(cfg: HCMConfig):
         s += torchvision_resnet50_spec("rgb_encoder.cnn.", with_fc=True)
         s += _linear("rgb_encoder.fc", cfg.rgb_out, 2048, gain=RELU_GAIN)
     else:
-        s += simple_cnn_spec("rgb_encoder.", 3, cfg.rgb_hw, cfg.rgb_out)
+        s += simple_cnn_spec("rgb_encoder.", 3, cfg.rgb_shape, cfg.rgb_out)
     s += [("sub_task_embedding.weight", (cfg.num_sub_tasks + 1, 32), "emb", 1.0)]
     s += rnn_spec("state_encoder.rnn.", cfg, lo_rnn_input_size(cfg))
     s += _linear("progress_monitor", 1, cfg.hidden)
