@@ -69,7 +69,7 @@ typedef struct hcm_config {
     int32_t precision;        /* HCM_BF16 (16-bit storage + MFMA, fp32 accumulate; recurrent cells fp32) or HCM_F32 (fp32 MFMA) */
     int32_t max_batch;        /* workspace is sized for this many environments per call */
     int32_t rgb_h, rgb_w;     /* frames are NHWC; any H x W >= 32 with HCM_ENC_RESNET (adaptive pools, resnet_encoders.py:211-236), >= 36 with HCM_ENC_SIMPLECNN (simple_cnns.py:63-73) */
-    int32_t depth_h, depth_w; /* square (habitat sizes its encoders from the frame height); ResNet encoder: a multiple of 64, <= 1024 */
+    int32_t depth_h, depth_w; /* HCM_ENC_RESNET: square, a multiple of 64, <= 1024 (habitat sizes the encoder from the frame height); HCM_ENC_SIMPLECNN: any H x W >= 36 */
     int32_t instr_len;        /* MAXIMUM instruction length: sizes the workspace (and the positional tables); every forward call
                                  passes its own L <= instr_len (the reference model accepts any (B or 1, L) per call and its
                                  eval loop feeds unpadded ids, common/utils.py:18-20); <= bert_max_pos (512) */

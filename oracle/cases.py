@@ -37,6 +37,8 @@ CASES = {
     "rgb_200x152": (dict(rgb_hw=200, rgb_w=152, depth_hw=128, instr_len=20, bert_layers=1), 1, 1, "both"),
     # ... and through the low-level model's SimpleRGBCNN (FC sized from the two dimensions on their own, simple_cnns.py:63-73): 10 x 17 final map
     "lo_simplecnn_rgb_120x176": (dict(depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN", rgb_hw=120, rgb_w=176, depth_hw=128), 2, 2, "lo"),
+    # ... and SimpleDepthCNN on a non-square depth frame (the width is not a multiple of 4: the generic first-conv path)
+    "lo_simplecnn_depth_152x218": (dict(depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN", rgb_hw=128, depth_hw=152, depth_w=218), 2, 2, "lo"),
 }
 
 # The reference's eval loop feeds the model the UNPADDED token ids of the episode's instruction as a (1, L) tensor

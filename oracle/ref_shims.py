@@ -321,7 +321,7 @@ def obs_space(cfg):
     # declare the RGB *space* 224x224 (ctor NameError otherwise); tensors may differ
     return _DictSpace({
         "rgb": _Box(0, 255, (224, 224, 3), np.uint8),
-        "depth": _Box(0.0, 1.0, (cfg.depth_hw, cfg.depth_hw, 1), np.float32),
+        "depth": _Box(0.0, 1.0, ((*cfg.depth_shape, 1) if hasattr(cfg, "depth_shape") else (cfg.depth_hw, cfg.depth_hw, 1)), np.float32),
     })
 
 

@@ -12,7 +12,8 @@ class HCMConfig:
     # observation sizes (frames are NHWC)
     rgb_hw: int = 256              # RGB frame height (and width when rgb_w == 0)
     rgb_w: int = 0                 # RGB frame width; 0 = square (depth frames are square: habitat sizes its ResNet encoder from the height)
-    depth_hw: int = 256
+    depth_hw: int = 256            # depth frame height (and width when depth_w == 0)
+    depth_w: int = 0               # depth frame width; 0 = square.  Non-square: SimpleDepthCNN only (habitat's ResNet encoder assumes a square map)
     instr_len: int = 80            # L: tokens per instruction of the synthetic workloads; an engine accepts any L <= its max_instr_len per call
     # encoders: cnn_type strings are the reference's
     rgb_encoder: str = "TorchVisionResNet50"      # or "SimpleRGBCNN" (low-level only)
@@ -69,12 +70,20 @@ class HCMConfig:
             # give the map that formula predicts (192 -> 3x3 x 228 channels, 256 -> 4x4 x 128, 320 -> 5x5 x 82)
             if self.depth_hw % 64 or not 64 <= self.depth_hw <= 1024:
                 raise ValueError("depth frame size must be a multiple of 64 for the ResNet depth encoder")
+            if self.depth_w and self.depth_w != self.depth_hw:
+                raise ValueError("non-square depth frames: SimpleDepthCNN only (habitat's ResNetEncoder sizes itself from the frame height "
+                                 "and assumes a square final map, resnet_encoders.py:37-62)")
         return self
 
     @property
     def rgb_shape(self):
         """(H, W) of the RGB frames."""
         return self.rgb_hw, (self.rgb_w or self.rgb_hw)
+
+    @property
+    def depth_shape(self):
+        """(H, W) of the depth frames."""
+        return self.depth_hw, (self.depth_w or self.depth_hw)
 
     @property
     def num_recurrent_layers(self):

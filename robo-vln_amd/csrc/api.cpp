@@ -121,9 +121,12 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     // depth: habitat's ResNet encoder sizes itself from the frame HEIGHT and assumes a square final map (resnet_encoders.py:37-62); RGB: the
     // torchvision trunk ends in adaptive pools and takes any H x W (resnet_encoders.py:211-236), SimpleRGBCNN sizes its FC from the two
     // dimensions on their own (simple_cnns.py:63-73, >= 36 pixels each for a 1 x 1 final map)
-    REQUIRE(cfg->depth_h == cfg->depth_w, HCM_ERR_UNSUPPORTED, "depth frames must be square");
+    REQUIRE(cfg->depth_h == cfg->depth_w || cfg->depth_encoder == HCM_ENC_SIMPLECNN, HCM_ERR_UNSUPPORTED,
+            "depth frames must be square with the ResNet depth encoder");
     if (cfg->rgb_encoder == HCM_ENC_SIMPLECNN)
         REQUIRE(cfg->rgb_h >= 36 && cfg->rgb_w >= 36, HCM_ERR_UNSUPPORTED, "SimpleRGBCNN: rgb frame too small");
+    if (cfg->depth_encoder == HCM_ENC_SIMPLECNN)
+        REQUIRE(cfg->depth_h >= 36 && cfg->depth_w >= 36, HCM_ERR_UNSUPPORTED, "SimpleDepthCNN: depth frame too small");
     if (cfg->depth_encoder == HCM_ENC_RESNET)
         REQUIRE(cfg->depth_h >= 64 && cfg->depth_h % 64 == 0 && cfg->depth_h <= 1024, HCM_ERR_UNSUPPORTED,
                 "depth frame size must be a multiple of 64 (habitat's ResNetEncoder: final map (H/2)/32, resnet_encoders.py:37-62)");

@@ -13,7 +13,7 @@ import torch
 class ObsStager:
     """Reusable pinned staging buffers for a fixed number of environments."""
 
-    def __init__(self, num_envs: int, rgb_hw, depth_hw: int, instr_len: int, device: Optional[torch.device] = None,
+    def __init__(self, num_envs: int, rgb_hw, depth_hw, instr_len: int, device: Optional[torch.device] = None,
                  pin: Optional[bool] = None):
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         on_gpu = self.device.type == "cuda"
@@ -21,7 +21,7 @@ class ObsStager:
         self.n = num_envs
         self.host = {
             "rgb": torch.empty(num_envs, *((rgb_hw, rgb_hw) if isinstance(rgb_hw, int) else tuple(rgb_hw)), 3, dtype=torch.uint8, pin_memory=pin),
-            "depth": torch.empty(num_envs, depth_hw, depth_hw, 1, dtype=torch.float32, pin_memory=pin),
+            "depth": torch.empty(num_envs, *((depth_hw, depth_hw) if isinstance(depth_hw, int) else tuple(depth_hw)), 1, dtype=torch.float32, pin_memory=pin),
             "instruction": torch.empty(num_envs, instr_len, dtype=torch.int32, pin_memory=pin),
         }
         self.dev = {k: torch.empty_like(v, device=self.device) for k, v in self.host.items()} if on_gpu else self.host

@@ -36,7 +36,7 @@ def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_
     s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
     s.max_batch = max_batch
     s.rgb_h, s.rgb_w = cfg.rgb_shape
-    s.depth_h = s.depth_w = cfg.depth_hw
+    s.depth_h, s.depth_w = cfg.depth_shape
     s.instr_len = max_instr_len or cfg.instr_len           # the library's instr_len is the MAXIMUM L of a call
     s.rgb_encoder = _lib.HCM_ENC_RESNET if cfg.rgb_encoder == "TorchVisionResNet50" else _lib.HCM_ENC_SIMPLECNN
     s.depth_encoder = _lib.HCM_ENC_RESNET if cfg.depth_encoder == "VlnResnetDepthEncoder" else _lib.HCM_ENC_SIMPLECNN
@@ -190,8 +190,8 @@ class HCMEngine:
         c = self.cfg
         if tuple(rgb.shape[1:]) != (*c.rgb_shape, 3):
             raise ValueError(f"rgb must be (B,{c.rgb_shape[0]},{c.rgb_shape[1]},3), got {tuple(rgb.shape)}")
-        if tuple(depth.shape) != (B, c.depth_hw, c.depth_hw, 1):
-            raise ValueError(f"depth must be (B,{c.depth_hw},{c.depth_hw},1), got {tuple(depth.shape)}")
+        if tuple(depth.shape) != (B, *c.depth_shape, 1):
+            raise ValueError(f"depth must be (B,{c.depth_shape[0]},{c.depth_shape[1]},1), got {tuple(depth.shape)}")
         ids = lens = None
         if need_ids:
             ids = self._dev(observations["instruction"], (torch.int64, torch.int32, torch.float32))

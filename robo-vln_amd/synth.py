@@ -245,7 +245,7 @@ def low_level_spec(cfg: HCMConfig):
         s += habitat_gn_resnet50_spec("depth_encoder.visual_encoder.", 1, cfg.depth_baseplanes, cc)
         s += _linear("depth_encoder.visual_fc.1", cfg.depth_out, cc * fs * fs, gain=RELU_GAIN)
     else:
-        s += simple_cnn_spec("depth_encoder.", 1, cfg.depth_hw, cfg.depth_out)
+        s += simple_cnn_spec("depth_encoder.", 1, cfg.depth_shape, cfg.depth_out)
     if cfg.rgb_encoder == "TorchVisionResNet50":
         s += torchvision_resnet50_spec("rgb_encoder.cnn.", with_fc=True)
         s += _linear("rgb_encoder.fc", cfg.rgb_out, 2048, gain=RELU_GAIN)
@@ -345,7 +345,8 @@ def make_observations(cfg: HCMConfig, batch: int, step: int = 0, seed: int = 0, 
     rh, rw = cfg.rgb_shape
     rgb = np.floor(uniform01(tag + "/rgb", B * rh * rw * 3, seed) * 256.0)
     rgb = rgb.reshape(B, rh, rw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
-    depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
+    dh, dw = cfg.depth_shape if hasattr(cfg, "depth_shape") else (cfg.depth_hw, cfg.depth_hw)
+    depth = uniform01(tag + "/depth", B * dh * dw, seed).reshape(B, dh, dw, 1)
     # the instruction is per-episode, not per-step: keyed without `step`
     ids = randint("obs/instr", B * L, 1000, cfg.bert_vocab, seed).reshape(B, L)
     lens = randint("obs/instr_len", B, min(L, max(2, L // 2)), L + 1, seed)
@@ -371,7 +372,8 @@ def make_cma_observations(cfg, batch: int, step: int = 0, seed: int = 0, rgb_uin
     rh, rw = cfg.rgb_shape
     rgb = np.floor(uniform01(tag + "/rgb", B * rh * rw * 3, seed) * 256.0)
     rgb = rgb.reshape(B, rh, rw, 3).astype(np.uint8 if rgb_uint8 else np.float32)
-    depth = uniform01(tag + "/depth", B * cfg.depth_hw * cfg.depth_hw, seed).reshape(B, cfg.depth_hw, cfg.depth_hw, 1)
+    dh, dw = cfg.depth_shape if hasattr(cfg, "depth_shape") else (cfg.depth_hw, cfg.depth_hw)
+    depth = uniform01(tag + "/depth", B * dh * dw, seed).reshape(B, dh, dw, 1)
     ids = randint("obs/cma_instr", B * L, 1, cfg.vocab_size, seed).reshape(B, L)
     lens = randint("obs/cma_instr_len", B, max(2, L // 2), L + 1, seed)
     for b in range(B):

@@ -58,6 +58,9 @@ def test_create_rejects_broken_reference_flags():
     # SimpleRGBCNN is built for square frames only
     l, rc, h = _create(HCMConfig(), depth_h=256, depth_w=192)
     assert rc == -6 and b"square" in l.hcm_last_error(None)
+    with pytest.raises(ValueError):
+        HCMConfig(depth_hw=256, depth_w=192).validate()
+    assert HCMConfig(depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN", depth_hw=152, depth_w=218).validate().depth_shape == (152, 218)
     l, rc, h = _create(HCMConfig(rgb_encoder="SimpleRGBCNN", depth_encoder="SimpleDepthCNN"), rgb_h=160, rgb_w=32, build_high=0)
     assert rc == -6 and b"SimpleRGBCNN" in l.hcm_last_error(None)
     assert HCMConfig(rgb_encoder="SimpleRGBCNN", rgb_hw=160, rgb_w=224).validate().rgb_shape == (160, 224)

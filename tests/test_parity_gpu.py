@@ -43,7 +43,7 @@ def _check(name, precision, **kw):
 
 
 ALL_CASES = ["cfg0_128_L20_N2", "gru_128_L20", "lo_simplecnn_256", "native_224_256", "cfg4_L160_N6", "cfg1_256_L80_N1",
-             "ablate_depth_128", "ablate_rgb_128", "depth192_128", "depth320_128", "depth384_128", "rgb_160x224", "rgb_200x152", "lo_simplecnn_rgb_120x176"]
+             "ablate_depth_128", "ablate_rgb_128", "depth192_128", "depth320_128", "depth384_128", "rgb_160x224", "rgb_200x152", "lo_simplecnn_rgb_120x176", "lo_simplecnn_depth_152x218"]
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
