@@ -61,6 +61,8 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
     lo, hi = shard_range(global_envs, world, rank)
     st = RolloutState(num_envs, num_recurrent_layers, hidden, device)
     out = []
+    guard = getattr(getattr(policy, "engine", None), "nonfinite_steps", None)
+    bad_before = guard() if guard is not None else 0          # the counter is cumulative: this rollout answers for its own steps
     prev_done = None
     for t in range(steps):
         obs = obs_fn(t, lo, hi)
@@ -83,9 +85,8 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         st.after_step(hh, lh, prev_done)
     # overflow guard of the HIP engine (hcm_query(HCM_STEP_NONFINITE)): a NaN / inf anywhere upstream of the state encoders would
     # otherwise leave the squashing cells as a finite, wrong action -- checked once per rollout (it synchronises), loudly
-    eng = getattr(policy, "engine", None)
-    if eng is not None and hasattr(eng, "nonfinite_steps"):
-        bad = eng.nonfinite_steps()
+    if guard is not None:
+        bad = guard() - bad_before
         if bad:
             raise FloatingPointError(f"{bad} (environment, step) pairs of this rollout had non-finite activations in front of a recurrent "
                                      "cell: broken sensor frames, or a sub-network outside its fp16 range (engine.calibrate(observations))")

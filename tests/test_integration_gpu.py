@@ -161,3 +161,27 @@ def test_host_frames_equal_device_frames(graph, rgb_uint8):
     with pytest.raises(ValueError):
         eng_h.act({"rgb": torch.zeros(B, 128, 128, 3, dtype=torch.uint8), "depth": host["depth"], "instruction": ids}, hh_h, lh_h, m, host_frames=True)
     eng_d.close(); eng_h.close()
+
+
+def test_rollout_raises_on_poisoned_frames_and_recovers():
+    """rollout() answers for its own steps: a NaN pixel in one environment's depth frame makes it raise FloatingPointError (the
+    engine's overflow guard), the next clean rollout on the same engine passes."""
+    from robo_vln_amd.policy import HCMEngine, Policy
+    from robo_vln_amd.rollout import rollout
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    B, T = 2, 3
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=4)
+    pol = Policy(HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16"))
+    frames = [{k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, step=t, seed=4).items()} for t in range(T)]
+    dev = torch.device("cuda")
+    never = lambda t, lo, hi: torch.zeros(hi - lo, dtype=torch.bool)
+    recs = rollout(pol, lambda t, lo, hi: frames[t], never, B, T, cfg.num_recurrent_layers, cfg.hidden, dev)
+    assert torch.isfinite(recs).all()
+    bad = [dict(f) for f in frames]
+    bad[1]["depth"] = frames[1]["depth"].clone()
+    bad[1]["depth"][0, 5, 7, 0] = float("nan")
+    with pytest.raises(FloatingPointError):
+        rollout(pol, lambda t, lo, hi: bad[t], never, B, T, cfg.num_recurrent_layers, cfg.hidden, dev)
+    recs2 = rollout(pol, lambda t, lo, hi: frames[t], never, B, T, cfg.num_recurrent_layers, cfg.hidden, dev)
+    assert torch.equal(recs, recs2)
+    pol.engine.close()
