@@ -287,6 +287,11 @@ def main():
                     "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its communicator
+    # is created): keep the real stdout aside for the result line and point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     if os.environ.get("HCM_SKIP"):
         # a development build of the library (make DEV=1) drops whole encoder chains under this variable: whatever it measures is
@@ -484,7 +489,8 @@ def main():
             out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
         if not args.no_cpu_baseline and world == 1 and args.config == 1:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, *weights)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if hasattr(eng, "close"):
         eng.close()
     if use_dist:
