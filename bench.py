@@ -49,9 +49,9 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=5):
+def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=8):
     """The CPU oracle (kind 'port': torch-CPU fp32 restatement validated against the imported reference) timed on this
-    host's cores on a bounded sample of the same workload (batch 16 instead of 64: about 10-20 s of CPU work)."""
+    host's cores on a bounded sample of the same workload (8 steps at batch 16 instead of 64: 10-15 s of CPU work)."""
     import numpy as np
     import torch
     from oracle import hcm_oracle
