@@ -153,7 +153,7 @@ def test_cma_batch_split_consistency():
     eng = CMAEngine(cfg, sd, max_batch=B, precision="fp32")
     obs_np = synth.make_cma_observations(cfg, B, step=1, seed=cases.SEED + 3)
     obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
-    h = (torch.rand(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda") - 0.5) * 0.2
+    h = ((torch.rand(cfg.num_recurrent_layers, B, cfg.hidden, generator=torch.Generator().manual_seed(9)) - 0.5) * 0.2).cuda()
     m = torch.ones(B, device="cuda")
     full = [t.clone() for t in eng.forward(obs, h, m)]
     for lo in range(0, B, 4):

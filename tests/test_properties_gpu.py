@@ -538,12 +538,19 @@ def test_unusual_but_valid_configurations_match_the_oracle(name, precision):
     obs_np = synth.make_observations(cfg, B, step=0, seed=11)
     obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
     R = cfg.num_recurrent_layers
-    hh = (torch.rand(R, B, cfg.hidden) - 0.5); lh = (torch.rand(R, B, cfg.hidden) - 0.5)
+    g = torch.Generator().manual_seed(17)
+    hh = torch.rand(R, B, cfg.hidden, generator=g) - 0.5
+    lh = torch.rand(R, B, cfg.hidden, generator=g) - 0.5
     mask = torch.ones(B)
     rec, hh2, lh2 = eng.act(obs, hh.cuda(), lh.cuda(), mask.cuda())
     torch.cuda.synchronize()
     ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
-    orec, ohh, olh = ora.act({k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}, hh, lh, mask)
+    obs_t = {k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}
+    # the low-level model is conditioned on the high-level argmax: the oracle's low-level model gets the sub-task the GPU chose, so that a
+    # near-tie between two logits (inside the tolerance either way) is not counted as an error of 0.1 in the velocity outputs
+    logits, ohh = ora.hi.forward(obs_t, hh, mask)
+    vel, stop, olh = ora.lo.forward(obs_t, lh, mask, torch.argmax(rec[:, :4].cpu(), 1))
+    orec = torch.cat([logits, vel, stop], 1)
     err = (rec.cpu() - orec).abs().max().item()
     print(f"{name} [{precision}]: record max-abs {err:.3e}")
     assert err <= (1e-3 if precision == "fp32" else 1.5e-2)
@@ -610,7 +617,7 @@ def test_simplecnn_low_level_model_frame_sizes(sizes, precision):
     obs_np = synth.make_observations(cfg, B, step=0, seed=5)
     obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
     R = cfg.num_recurrent_layers
-    h = torch.rand(R, B, cfg.hidden) - 0.5
+    h = torch.rand(R, B, cfg.hidden, generator=torch.Generator().manual_seed(7)) - 0.5
     mask = torch.ones(B)
     st = torch.tensor([0, 3, 1])
     vel, stop, h2 = eng.low_forward(obs, h.cuda(), mask.cuda(), st.cuda())
