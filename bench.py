@@ -168,13 +168,17 @@ def pmc_traffic(config=1):
 
 
 def dtype_string(args, eng):
-    """What the 16-bit engine actually stores: fp16 everywhere unless the range calibration moved a sub-network to bf16."""
-    if args.precision != "bf16":
+    """What the 16-bit engine actually stores (the mode asked for and what the range calibration did to it)."""
+    if args.precision == "fp32":
         return "fp32"
+    if args.precision == "bf16":
+        return "bf16 (bf16 storage and MFMA in BERT, the RGB trunks and the cross-modal block; the GroupNorm depth trunks on range-folded fp16; fp32 accumulate, fp32 recurrent state; DESIGN.md section 5)"
     fb = sorted(eng.fp16_fallback)
+    fold = sorted(getattr(eng, "range_fold", ()))
+    tail = ("; range fold: " + ", ".join(fold)) if fold else ""
     if not fb:
-        return "fp16 (range-calibrated fp16 storage and MFMA in BERT, both trunks and the cross-modal block; fp32 accumulate, fp32 recurrent state; DESIGN.md section 5)"
-    return "fp16+bf16 (fp16 storage / MFMA, fp32 accumulate; moved to bf16 by the range calibration: " + ", ".join(fb) + ")"
+        return "fp16 (range-calibrated fp16 storage and MFMA in BERT, both trunks and the cross-modal block; fp32 accumulate, fp32 recurrent state; DESIGN.md section 5" + tail + ")"
+    return "fp16+bf16 (fp16 storage / MFMA, fp32 accumulate; moved to bf16 by the range calibration: " + ", ".join(fb) + tail + ")"
 
 
 # ------------------------------------------------------------------------------------------------------------ workloads
@@ -210,7 +214,7 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank):
         stager.host["instruction"].copy_(sets[0]["instruction"].cpu().int())
         stager.dev["instruction"].copy_(stager.host["instruction"])       # ids change per episode, not per step: resident
 
-    def step(mask=None):
+    def step(mask=None, gather=False):
         obs = sets[state["tick"] & 1]
         state["tick"] += 1
         host_frames = False
@@ -229,7 +233,7 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank):
             return logits
         r, state["hh"], state["lh"] = eng.act(obs, state["hh"], state["lh"], m,
                                               reuse_instruction=args.reuse_instruction and mask is None and state["tick"] > 3,
-                                              host_frames=host_frames)
+                                              host_frames=host_frames, gather=gather)
         return r
     return cfg, B, eng, step, (hi_sd, lo_sd)
 
@@ -244,10 +248,10 @@ def build_probe_workload(args):
     B, L = args.batch or BATCH[3], cfg.instr_len
     cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, cfg.depth_hw, 128), "probe_cnn", 0)
     vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
-    prec = "fp16" if args.precision == "bf16" else "fp32"
+    prec = args.precision
     # hipGraph replay over the two input sets in place (a rollout stages observations into fixed device buffers): no input copies
     probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec, graph=not args.no_graph)
-    tdt = torch.float16 if prec == "fp16" else torch.float32
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[prec]
     sets = []
     for k in range(2):
         depth = synth.uniform01(f"probe/depth{k}", B * 256 * 256, 0).reshape(B, 256, 256, 1)
@@ -277,7 +281,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the BASELINE size of the config)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: total environments, split evenly over the ranks (BASELINE configs[2]: 512); "
                                                                "default 0 = weak scaling at --batch per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"],
+                    help="fp16 = the measured 16-bit mode (range-calibrated fp16 tiles); bf16 = bf16 tiles in BERT / RGB trunks / cross-modal block")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: the per-step all-gather through torch.distributed instead of the library's own "
+                                                                "RCCL call behind the step (A/B of rounds 1-2 vs round 3)")
     ap.add_argument("--reuse-instruction", action="store_true",
                     help="NOT the headline configuration: steps after the first skip BERT (instructions unchanged; hcm_act_ex flag)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -338,12 +345,23 @@ def main():
     # bound that only a pipelined simulator could use).  `value` is the former; the latter is reported as an extra key.
     comm = torch.cuda.Stream() if use_dist else None
     pending = []
+    # the collective is enqueued by the LIBRARY behind the graph replay (hcm_act_gather, one ncclAllGather on the step's stream) unless
+    # --torch-gather asks for the torch.distributed call per step of rounds 1-2 (A/B)
+    lib_gather = use_dist and args.config == 1 and not args.torch_gather
+    if lib_gather:
+        eng.comm_init()
 
     def step(mask=None, overlap=False):
         if use_dist and overlap and len(pending) >= 2:
             torch.cuda.current_stream().wait_event(pending.pop(0))
+        if lib_gather and not overlap:
+            full = raw_step(mask, gather=True)          # ONE RCCL all-gather of the (B,7) records per step, in stream order, issued by libhcm
+            last["full"] = full
+            last["r"] = full[lo_e:hi_e]
+            return
         r = raw_step(mask)
         last["r"] = r
+        last["full"] = all_rec
         if not use_dist:
             return
         if not overlap:
@@ -365,6 +383,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             step(overlap=overlap)
+        last["host_s"] = (time.perf_counter() - t0) / n          # host time to ENQUEUE a step (no synchronisation inside)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -394,12 +413,14 @@ def main():
     for _ in range(args.warmup):
         step()
     dt = timed(args.steps)
+    host_us = last["host_s"] * 1e6
     # what the step returned is checked, not only timed: finite, and (N>1) this rank's rows of the gathered records are its own
     r = last["r"]
     assert torch.isfinite(r.float()).all(), "non-finite outputs"
     if use_dist:
-        assert torch.equal(all_rec[lo_e:hi_e], r), "gathered records do not contain this rank's rows"
-        chk = all_rec.double().sum().reshape(1)
+        full = last["full"]
+        assert full.shape == (global_B, 7) and torch.equal(full[lo_e:hi_e], r), "gathered records do not contain this rank's rows"
+        chk = full.double().sum().reshape(1)
         lo_c, hi_c = chk.clone(), chk.clone()
         dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
@@ -438,7 +459,11 @@ def main():
             "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": global_B,
                        "parallelism": (f"env-sharded data parallel x{world}, one all-gather of (B,7) records per step on the critical path"
                                        if world > 1 else "single GPU")},
+            "host_us_per_step": round(host_us, 1),
         }
+        if use_dist:
+            out["config"]["all_gather"] = ("ncclAllGather enqueued by libhcm on the step's stream behind the hipGraph replay (hcm_act_gather)" if lib_gather
+                                           else "torch.distributed.all_gather_into_tensor per step (--torch-gather)")
         if sustained:
             out["sustained"] = sustained
         if overlapped:
@@ -466,7 +491,7 @@ def main():
                 whole["basis"] = "cached-instruction variant: 36.9 - 13.83 (BERT) GFLOP per env-step x env-steps/s"
             roof = dict(whole)
             roof["scope"] = "whole step"
-            if args.precision == "bf16" and not args.no_kernel_probe and args.config in (1, 4):
+            if args.precision != "fp32" and not args.no_kernel_probe and args.config in (1, 4):
                 try:
                     L = cfg.instr_len
                     dk = dominant_kernel_probe(B, L)

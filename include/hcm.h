@@ -57,16 +57,22 @@ enum hcm_query_what {
     HCM_CALIB_NONFINITE = 12,      /* non-finite values seen in the last calibration forward */
     HCM_CALIB_MAX_RGB = 13,        /* as HCM_CALIB_MAX_BERT, over the conv outputs of the RGB trunks */
     HCM_CALIB_MAX_VLA = 14,        /* ... over the cross-modal block (its GEMM outputs and the fused layer's LDS-only intermediates) */
-    HCM_STEP_NONFINITE = 15        /* overflow guard: (sample, recurrent step) pairs since hcm_finalize whose gate pre-activations were not all
+    HCM_STEP_NONFINITE = 15,       /* overflow guard: (sample, recurrent step) pairs since hcm_finalize whose gate pre-activations were not all
                                       finite -- an fp16 overflow or a NaN anywhere upstream of the state encoder lands there, and the squashing
                                       cell would otherwise turn it into finite garbage.  0 on a healthy engine.  Synchronises the device. */
+    HCM_RANGE_FOLD = 16            /* bit 1: a power-of-two scale was folded into convs of the GroupNorm depth trunks, bit 2: into the RGB trunks
+                                      (the exact alternative to a bf16 fall-back where the network is scale-invariant; hcm_calibrate below) */
 };
 
 /* Model hyper-parameters: the values the reference reads from MODEL.* (config/default.py:131,:156-164,
  * :180-199).  Zero-initialise, set struct_size = sizeof(hcm_config), fill. */
 typedef struct hcm_config {
     int32_t struct_size;
-    int32_t precision;        /* HCM_BF16 (16-bit storage + MFMA, fp32 accumulate; recurrent cells fp32) or HCM_F32 (fp32 MFMA) */
+    int32_t precision;        /* HCM_F16: fp16 storage + fp16 MFMA tiles behind the range calibration below (the measured 16-bit mode);
+                                 HCM_BF16: bf16 storage + bf16 MFMA tiles in BERT, the RGB trunks and the cross-modal block (no range limit); the
+                                 GroupNorm depth trunks stay on range-folded fp16 tiles (GroupNorm's subtraction amplifies bf16's rounding 8x: 1.9e-2 on
+                                 the record from that trunk alone, DESIGN.md section 5 -- and the fold makes fp16 range-safe there by construction);
+                                 HCM_F32: fp32 MFMA.  fp32 accumulation and fp32 recurrent cells / heads in every mode */
     int32_t max_batch;        /* workspace is sized for this many environments per call */
     int32_t rgb_h, rgb_w;     /* frames are NHWC; any H x W >= 32 with HCM_ENC_RESNET (adaptive pools, resnet_encoders.py:211-236), >= 36 with HCM_ENC_SIMPLECNN (simple_cnns.py:63-73) */
     int32_t depth_h, depth_w; /* HCM_ENC_RESNET: square, a multiple of 64, <= 1024 (habitat sizes the encoder from the frame height); HCM_ENC_SIMPLECNN: any H x W >= 36 */
@@ -182,21 +188,50 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
 /* Companion of HCM_ACT_REUSE_INSTRUCTION for batched rollouts in which a few environments start a new episode: recomputes
  * the cached instruction stream of the n listed environments (HOST array of indices into the batch) from ids (B,L) (device),
  * leaving the other environments' cached tensors untouched.  Needs a previous hcm_act / hcm_act_ex step at this batch size. */
+/* ---- multi-GPU: environment-sharded replicas, ONE collective per step (no reference counterpart: the reference evaluates one
+ * environment in one process, hierarchical_trainer.py:1088-1107).  One process per GPU, every rank a full weight replica stepping its own
+ * B_local environments; the (B_local, 7) action records are all-gathered over RCCL / xGMI into the (world * B_local, 7) record of the whole batch,
+ * rank-major = environment order.  The collective is enqueued by the library on the step's stream right behind the (hipGraph-replayed) step:
+ * no Python call per step, no host synchronisation.  RCCL is resolved with dlopen when first asked for.
+ *   hcm_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank through any side channel (torch.distributed broadcast, a file, MPI)
+ *   hcm_comm_init        every rank, collectively: creates the handle's communicator (blocks until all `world` ranks have called)
+ *   hcm_act_gather       hcm_act_ex + ncclAllGather(record -> gathered) on `stream`; B must be the same on every rank */
+int hcm_comm_unique_id(void* out128);
+int hcm_comm_init(hcm_handle h, const void* unique_id128, int rank, int world);
+int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
+                   int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
+                   int flags, float* gathered, void* stream);
+
 int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
                             const int32_t* env_indices, int n, void* stream);
 
-/* fp16 range safety (no reference counterpart: the reference is fp32).  In the 16-bit mode BERT and the GroupNorm depth trunks store
- * activations as fp16, whose range ends at 65504.  hcm_finalize runs one forward on a synthetic batch with range hooks on every GEMM output
- * of those sub-networks; hcm_calibrate does the same on the caller's own observations (device pointers as for hcm_act; zero recurrent
- * state; synchronises the stream).  A sub-network whose max |x| exceeds 2^14 or that produced a non-finite value is re-built on bf16 tiles
- * (needs the host copies of the weights: hcm_config.reserved[4], else HCM_ERR_STATE) and hcm_query(HCM_FP16_FALLBACK) reports it; the forward is
- * then repeated on the re-built engine, so that what sat downstream of the overflow is judged on clean inputs and the reported ranges are
- * those of the engine as it runs.  At run time NaN / inf are never washed out (ReLU, max-pool and the variance clamps propagate them as
- * torch's do) and the recurrent cells count what reaches them: hcm_query(HCM_STEP_NONFINITE). */
+/* fp16 range safety (no reference counterpart: the reference is fp32).  Sub-networks that store fp16 (all four in HCM_F16 mode, the depth
+ * trunks in HCM_BF16 mode) have a range that ends at 65504.  hcm_finalize runs one forward on a synthetic batch with range hooks on every GEMM
+ * output of those sub-networks; hcm_calibrate does the same on the caller's own observations (device pointers as for hcm_act; zero recurrent
+ * state; synchronises the stream).  When max |x| exceeds 2^14 or a non-finite value appears (needs the host copies of the weights:
+ * hcm_config.reserved[4], else HCM_ERR_STATE):
+ *   - GroupNorm depth trunks: the un-normalised output of a conv is the only tensor that can grow without bound, and GroupNorm is invariant to
+ *     its scale: a power of two is folded into that conv's weights and the GroupNorm's eps is scaled to match -- exact, the trunk stays on
+ *     fp16 (hcm_query(HCM_RANGE_FOLD) bit 1);
+ *   - BatchNorm-folded RGB trunks: conv + bias + ReLU, pools and the residual additions are positively homogeneous, so ONE power of two is
+ *     carried by every activation of the trunk (stem weights and all folded biases scaled by it) and divided out in the weights of the
+ *     projections that consume the trunk features -- exact up to fp16's sub-normal floor, the trunk stays on fp16 (HCM_RANGE_FOLD bit 2);
+ *   - BERT and the cross-modal block (GELU / softmax are not homogeneous), or a trunk whose overflow the fold cannot reach: re-built on bf16
+ *     tiles, reported by hcm_query(HCM_FP16_FALLBACK).
+ * The forward is repeated on the re-built engine, so that what sat downstream of the overflow is judged on clean inputs and the reported
+ * ranges are those of the engine as it runs.  At run time NaN / inf are never washed out (ReLU, max-pool and the variance clamps propagate them
+ * as torch's do) and the recurrent cells count what reaches them: hcm_query(HCM_STEP_NONFINITE). */
 int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, int B, int L, void* stream);
 int hcm_release_host_weights(hcm_handle h);
 
 int hcm_query(hcm_handle h, int what, int64_t* out);
+
+/* The run-time overflow guard without a synchronisation (hcm_query(HCM_STEP_NONFINITE) waits for the device): enqueues a copy of the
+ * guard word to a pinned host word behind `stream` and returns in *out the value of the last copy that has COMPLETED -- i.e. the
+ * count as of an earlier poll.  Cheap enough to call every few steps from a rollout loop; a non-zero value means that some
+ * environment's recurrent cell saw non-finite gate pre-activations (a broken frame, or a sub-network outside its fp16 range:
+ * hcm_calibrate on real observations) and that its actions since then are not to be trusted. */
+int hcm_guard_poll(hcm_handle h, void* stream, int64_t* out);
 
 /* Message of the last failing call on this handle (or on creation when h is NULL). */
 const char* hcm_last_error(hcm_handle h);
@@ -209,7 +244,7 @@ void hcm_destroy(hcm_handle h);
  * (strict) -> hcm_finalize -> hcm_cma_forward ...; hcm_query / hcm_last_error / hcm_destroy work as for the HCM handles. */
 typedef struct hcm_cma_config {
     int32_t struct_size;
-    int32_t precision;            /* HCM_BF16 (16-bit trunks, fp32 text / recurrent / attention side) or HCM_F32 */
+    int32_t precision;            /* HCM_F16 / HCM_BF16 (16-bit trunks as in hcm_config.precision; fp32 text / recurrent / attention side) or HCM_F32 */
     int32_t max_batch;
     int32_t rgb_h, rgb_w, depth_h, depth_w;
     int32_t instr_len;            /* MAXIMUM padded token count per instruction (<= 256); every forward passes its own L <= instr_len */

@@ -14,7 +14,7 @@ CASES = {
     # BASELINE.json configs[0]: B=4 in the bench; goldens use B=2 to stay small
     "cfg0_128_L20_N2": (dict(rgb_hw=128, depth_hw=128, instr_len=20, vla_layers=2), 2, 3, "both"),
     # configs[1]/[2] shape: 256x256, L=80, N=1, full BERT
-    "cfg1_256_L80_N1": (dict(), 2, 2, "both"),
+    "cfg1_256_L80_N1": (dict(), 2, 3, "both"),
     # GRU state encoder (MODEL.STATE_ENCODER.rnn_type), short BERT to keep it quick
     "gru_128_L20": (dict(rgb_hw=128, depth_hw=128, instr_len=20, rnn_type="GRU", bert_layers=2), 2, 3, "both"),
     # low-level model with SimpleCNN encoders (configs[3] encoder; high-level cannot be built with them)

@@ -13,7 +13,9 @@ HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
  HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES, HCM_FP16_FALLBACK, HCM_CALIB_MAX_BERT, HCM_CALIB_MAX_DEPTH,
- HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE) = range(16)
+ HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE, HCM_RANGE_FOLD) = range(17)
+# `precision` of HCMEngine / CMAEngine -> hcm_config.precision (include/hcm.h): "fp16" is the measured 16-bit mode
+PRECISIONS = {"fp32": HCM_F32, "fp16": HCM_F16, "bf16": HCM_BF16}
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 HCM_ACT_REUSE_INSTRUCTION = 1
 HCM_ACT_HOST_FRAMES = 2
@@ -58,10 +60,15 @@ EXPORTS = {
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_act_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hcm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "hcm_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hcm_act_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "hcm_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hcm_release_host_weights": (C.c_int, [C.c_void_p]),
     "hcm_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "hcm_guard_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "hcm_last_error": (C.c_char_p, [C.c_void_p]),
     "hcm_destroy": (None, [C.c_void_p]),
     "hcm_debug_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),

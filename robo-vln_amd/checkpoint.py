@@ -89,8 +89,16 @@ def save_checkpoint(path_or_file, high_level_state_dict, low_level_state_dict, c
                 "config": config}, path_or_file)
 
 
-def engine_from_checkpoint(path, cfg, **engine_kwargs):
-    """Build an HCMEngine from a reference checkpoint (strict key/shape check inside libhcm)."""
+def engine_from_checkpoint(path, cfg, calibrate_on=None, **engine_kwargs):
+    """Build an HCMEngine from a reference checkpoint (strict key/shape check inside libhcm).
+    The fp16 range check of hcm_finalize runs on synthetic noise; a trained checkpoint on real frames deserves the real thing: the engine
+    keeps the f32 host copies of the weights (keep_host_weights) until `calibrate_on` -- a batch of real observations -- has been through
+    `engine.calibrate()`, which repeats the check and the repair (range fold / bf16 fall-back) on them and then releases the copies.
+    Without `calibrate_on` the copies stay: call `engine.calibrate(observations)` once real observations exist."""
     from .policy import HCMEngine
     hi_sd, lo_sd, _ = load_checkpoint(path)
-    return HCMEngine(cfg, hi_sd, lo_sd, **engine_kwargs)
+    engine_kwargs.setdefault("keep_host_weights", True)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, **engine_kwargs)
+    if calibrate_on is not None:
+        eng.calibrate(calibrate_on, release_host_weights=True)
+    return eng

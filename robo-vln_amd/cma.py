@@ -18,7 +18,7 @@ from .policy import _TORCH_DT, _np32
 def _to_struct(cfg: CMAConfig, max_batch, precision):
     s = _lib.HcmCmaConfigStruct()
     s.struct_size = C.sizeof(_lib.HcmCmaConfigStruct)
-    s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
+    s.precision = _lib.PRECISIONS[precision]
     s.max_batch = max_batch
     s.rgb_h, s.rgb_w = cfg.rgb_shape
     s.depth_h = s.depth_w = cfg.depth_hw
@@ -37,7 +37,7 @@ def _to_struct(cfg: CMAConfig, max_batch, precision):
 class CMAEngine:
     """Owns one libhcm CMANet handle (weights + workspace) on one GPU."""
 
-    def __init__(self, cfg: CMAConfig, state_dict, max_batch=64, precision="bf16", device=None, graph=False):
+    def __init__(self, cfg: CMAConfig, state_dict, max_batch=64, precision="fp16", device=None, graph=False):
         """graph=True: forward() runs on an engine-owned stream with engine-owned static I/O buffers so that libhcm replays one
         captured hipGraph per step; the returned tensors then alias those buffers and stay valid until the second-next call."""
         self._graph = bool(graph)
@@ -65,7 +65,8 @@ class CMAEngine:
 
     def query(self, what):
         out = C.c_int64()
-        _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
+        with torch.cuda.device(self.device):       # (HCM_STEP_NONFINITE waits for the handle's device)
+            _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
         return out.value
 
     def nonfinite_steps(self):

@@ -1,4 +1,5 @@
 // C ABI of libhcm (include/hcm.h).
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -16,6 +17,7 @@ void prepare_cma(hcm_ctx* ctx);
 void run_refresh_instruction(hcm_ctx* ctx, const void* ids, int ids_dt, int B, const int32_t* idx, int n);   // L = ctx->cur_L
 void run_cma(hcm_ctx* ctx, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B, const float* h_in,
              const float* mask, float* out, float* stop, float* h_out);
+void comm_destroy(hcm_ctx* ctx);
 void run_step(hcm_ctx* ctx, bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt,
               int B, const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask, float* logits,
               int ld_logits, float* vel, int ld_vel, float* stop, int ld_stop, float* hi_h_out, float* lo_h_out, int T = 1);
@@ -94,7 +96,7 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     hcm_ctx* h = nullptr;
     REQUIRE(cfg && out, HCM_ERR_ARG, "hcm_create: null argument");
     REQUIRE(cfg->struct_size == (int32_t)sizeof(hcm_config), HCM_ERR_ARG, "hcm_create: struct_size mismatch");
-    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16, HCM_ERR_ARG, "precision must be HCM_F32 or HCM_BF16");
+    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16 || cfg->precision == HCM_F16, HCM_ERR_ARG, "precision must be HCM_F32, HCM_F16 or HCM_BF16");
     REQUIRE(cfg->max_batch >= 1, HCM_ERR_ARG, "max_batch must be >= 1");
     // flags whose branches crash in the reference are rejected, not emulated
     REQUIRE(!cfg->use_prev_action, HCM_ERR_UNSUPPORTED,
@@ -135,18 +137,15 @@ int hcm_create(const hcm_config* cfg, hcm_handle* out) {
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
     REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0, HCM_ERR_UNSUPPORTED, "encoder output sizes must be multiples of 4");
     h = new hcm_ctx();
+    (void)hipGetDevice(&h->device);
     h->cfg = *cfg;
-    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
+    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : cfg->precision == HCM_F16 ? DT_F16 : DT_F32;
     // per-sub-network storage type; reserved[0..3] = (dtype + 1) overrides for depth / bert / vla / rgb, 0 = default.
+    //   HCM_F16:  all four store fp16 behind the range calibration (same MFMA rate as bf16, three more mantissa bits: DESIGN.md section 5);
+    //   HCM_BF16: BERT, the RGB trunks and the cross-modal block store bf16; the GroupNorm depth trunks stay on fp16 tiles, which the
+    //             range fold makes safe by construction (on bf16 that trunk alone costs 1.9e-2 of the 1e-2 record tolerance).
     h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
-    // 16-bit mode: every sub-network whose fp16 range is checked by the calibration forward (BERT, both ResNet trunk pairs) stores fp16 --
-    // same MFMA rate as bf16, three more mantissa bits; the cross-modal block and the small projections stay bf16.
-    // HCM_RGB_BF16=1: the RGB trunks on bf16 tiles as in round 1 (A/B knob).
-    if (h->dt == DT_BF16) {
-        h->dt_depth = DT_F16; h->dt_bert = DT_F16;
-        if (!getenv("HCM_RGB_BF16")) h->dt_rgb = DT_F16;
-        if (!getenv("HCM_VLA_BF16")) h->dt_vla = DT_F16;      // the cross-modal block too (fourth calibration slot; the fused layer checks its LDS-only intermediates itself)
-    }
+    if (h->dt == DT_BF16) h->dt_depth = DT_F16;
     {
         int* slots[4] = {&h->dt_depth, &h->dt_bert, &h->dt_vla, &h->dt_rgb};
         for (int i = 0; i < 4; ++i) {
@@ -174,7 +173,7 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     hcm_ctx* h = nullptr;
     REQUIRE(cfg && out, HCM_ERR_ARG, "hcm_cma_create: null argument");
     REQUIRE(cfg->struct_size == (int32_t)sizeof(hcm_cma_config), HCM_ERR_ARG, "hcm_cma_create: struct_size mismatch");
-    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16, HCM_ERR_ARG, "precision must be HCM_F32 or HCM_BF16");
+    REQUIRE(cfg->precision == HCM_F32 || cfg->precision == HCM_BF16 || cfg->precision == HCM_F16, HCM_ERR_ARG, "precision must be HCM_F32, HCM_F16 or HCM_BF16");
     REQUIRE(cfg->max_batch >= 1, HCM_ERR_ARG, "max_batch must be >= 1");
     REQUIRE(!cfg->use_prev_action && !cfg->rcm_state_encoder, HCM_ERR_UNSUPPORTED,
             "CMA.use_prev_action / CMA.rcm_state_encoder (default.py:211-212 default False) are not built");
@@ -192,6 +191,7 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     REQUIRE(cfg->depth_baseplanes == 32, HCM_ERR_UNSUPPORTED, "resnet_baseplanes is 32 in the reference (resnet_encoders.py:19)");
     REQUIRE(cfg->rgb_out % 4 == 0 && cfg->depth_out % 4 == 0 && cfg->num_actions >= 1, HCM_ERR_UNSUPPORTED, "bad output sizes");
     h = new hcm_ctx();
+    (void)hipGetDevice(&h->device);
     h->kind = 1;
     h->cma_cfg = *cfg;
     std::memset(&h->cfg, 0, sizeof(h->cfg));
@@ -202,10 +202,11 @@ int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out) {
     c.rgb_encoder = c.depth_encoder = HCM_ENC_RESNET;
     c.rgb_out = cfg->rgb_out; c.depth_out = cfg->depth_out; c.depth_baseplanes = cfg->depth_baseplanes;
     c.hidden = cfg->hidden; c.rnn_type = cfg->rnn_type; c.num_actions = cfg->num_actions;
-    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : DT_F32;
+    h->dt = cfg->precision == HCM_BF16 ? DT_BF16 : cfg->precision == HCM_F16 ? DT_F16 : DT_F32;
     h->dt_rgb = h->dt_bert = h->dt_vla = h->dt_depth = h->dt;
-    // both ResNet trunks on range-calibrated fp16 tiles, as in the HCM handle
-    if (h->dt == DT_BF16) { h->dt_depth = DT_F16; if (!getenv("HCM_RGB_BF16")) h->dt_rgb = DT_F16; }
+    // trunks as in the HCM handle: HCM_F16 both on range-calibrated fp16 tiles, HCM_BF16 the RGB trunk on bf16; the token-side
+    // projections (dt_vla) follow the RGB trunk's type
+    if (h->dt == DT_BF16) h->dt_depth = DT_F16;
     try {
         build_spec_cma(h);
     } catch (const std::exception& e) {
@@ -271,6 +272,13 @@ static void dry_run(hcm_ctx* h, int B) {
                      nullptr, 0, nullptr, nullptr, T);
         }
     }
+    // hcm_refresh_instruction of every environment at once: a second BERT / instruction-stream scratch set on top of the persistent
+    // step tensors -- with small frames and a long instruction that is more than any step needs
+    if (hi && lo) {
+        const size_t peak = h->arena.peak;
+        run_refresh_instruction(h, nullptr, DT_I64, B, nullptr, B);
+        if (h->arena.peak < peak) h->arena.peak = peak;
+    }
 }
 
 // ---- fp16 range calibration: BERT and the GroupNorm depth trunks store activations as fp16 (3 more mantissa
@@ -292,12 +300,14 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     const size_t R = (c.rnn_type == HCM_LSTM ? 2 : 1) * (h->kind == 1 ? 2 : 1);        // CMANet: two state encoders in one tensor
     const size_t n_hid = R * (size_t)B * c.hidden * 4;
     char* tmp = nullptr;
-    const size_t total = 4 * n_hid + (size_t)B * 64 * 4 + 4096;
+    const size_t total = 4 * n_hid + (size_t)B * 17 * 4 + 8 + (size_t)B * 8 + 4096;
     if (hipMalloc((void**)&tmp, total) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc of calibration scratch failed");
     (void)hipMemsetAsync(tmp, 0, total, stream);
     float* hh = (float*)tmp; float* lh = (float*)(tmp + n_hid); float* hh2 = (float*)(tmp + 2 * n_hid); float* lh2 = (float*)(tmp + 3 * n_hid);
-    float* mask = (float*)(tmp + 4 * n_hid); float* rec = mask + B; int64_t* st = (int64_t*)(rec + 16 * (size_t)B);
+    float* mask = (float*)(tmp + 4 * n_hid); float* rec = mask + B;
+    int64_t* st = (int64_t*)(((uintptr_t)(rec + 16 * (size_t)B) + 7) & ~(uintptr_t)7);      // 8-byte aligned for every B
     (void)hipMemsetAsync(h->calib_buf, 0, 32, stream);
+    (void)hipMemsetAsync(h->calib_buf + 16, 0, (hcm_ctx::kCalibWords - 16) * 4, stream);
     const bool conc = h->concurrent;
     h->concurrent = false;                       // one stream: the hooks are plain launches in program order
     h->stream = stream;
@@ -318,9 +328,10 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     } catch (const std::exception& e) { err = e.what(); }
     h->calib = false;
     h->concurrent = conc;
-    unsigned out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned out[hcm_ctx::kCalibWords];
+    std::memset(out, 0, sizeof(out));
     const hipError_t se = hipStreamSynchronize(stream);
-    if (se == hipSuccess) (void)hipMemcpy(out, h->calib_buf, 32, hipMemcpyDeviceToHost);
+    if (se == hipSuccess) (void)hipMemcpy(out, h->calib_buf, sizeof(out), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (!err.empty()) return fail(h, HCM_ERR_HIP, "calibration forward failed: " + err);
     if (se != hipSuccess) return fail(h, HCM_ERR_HIP, "calibration forward failed to complete");
@@ -335,8 +346,47 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     // cross-modal block while one of its three inputs was already non-finite say nothing about the block itself -- re-build the source
     // first; the forward below this re-build judges the block on clean inputs
     if ((rebuild & 8) && (rebuild & 7) && (h->calib_bad[0] || h->calib_bad[1] || h->calib_bad[2])) rebuild &= ~8;
-    if (!rebuild) return HCM_OK;
-    (void)hipMemset(h->calib_buf + hcm_ctx::kStepBadWord, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
+    // Range folding, where the network is exactly scale-invariant, instead of giving up fp16 (include/hcm.h, hcm_calibrate):
+    int refold = 0;                 // bit 1 / bit 2: the depth / RGB trunks are re-built with new folds, on the same storage type
+    auto pow2_down = [](float v, float target) { int e = 0; while (v > target && e < 60) { v *= 0.5f; ++e; } return std::ldexp(1.0f, -e); };
+    const bool has_gn_trunk = h->kind == 1 || h->cfg.depth_encoder == HCM_ENC_RESNET;
+    const bool has_bn_trunk = h->kind == 1 || h->cfg.rgb_encoder == HCM_ENC_RESNET || (h->cfg.build_high != 0);
+    if ((rebuild & 2) && has_gn_trunk) {
+        // GroupNorm depth trunks: per conv position, the un-normalised conv output (the only tensor there that can grow without bound).
+        // Finite overflows are folded down to <= 2^10 in one go; of the positions that went non-finite only the FIRST is touched (2^-16, re-centred
+        // by a later pass): everything behind it saw its NaNs.  An overflow with no position to blame sits behind a GroupNorm (huge gamma)
+        // or in the low-level model's SimpleCNN: bf16 as before.
+        bool any = false;
+        int first_bad = -1;
+        for (int pos = 0; pos < hcm_ctx::kDepthPos; ++pos) {
+            float mx; std::memcpy(&mx, &out[16 + 2 * pos], 4);
+            const unsigned bad = out[16 + 2 * pos + 1];
+            if (bad) { if (first_bad < 0) first_bad = pos; continue; }
+            if (first_bad >= 0) continue;                                  // finite, but computed from non-finite inputs further up?  no: bad would be set
+            if (mx > 16384.0f) { h->depth_fold[pos] *= pow2_down(mx, 1024.0f); any = true; }
+        }
+        if (first_bad >= 0 && h->depth_fold[first_bad] > 1e-12f) { h->depth_fold[first_bad] *= 1.0f / 65536.0f; any = true; }
+        if (any) { refold |= 2; rebuild &= ~2; }
+    }
+    if (h->dt_depth == DT_F16 && !(rebuild & 2) && has_gn_trunk) {
+        // re-centre a position whose (blind, 2^-16) fold left its values far below the range: back up to <= 2^10, never above the unfolded scale
+        for (int pos = 0; pos < hcm_ctx::kDepthPos; ++pos) {
+            float mx; std::memcpy(&mx, &out[16 + 2 * pos], 4);
+            if (h->depth_fold[pos] >= 1.f || out[16 + 2 * pos + 1] || !(mx > 0.f) || mx >= 256.0f) continue;
+            float f = h->depth_fold[pos];
+            while (f < 1.f && mx * 2.f <= 1024.0f) { f *= 2.f; mx *= 2.f; }
+            if (f != h->depth_fold[pos]) { h->depth_fold[pos] = f; refold |= 2; }
+        }
+    }
+    if ((rebuild & 4) && has_bn_trunk && h->rgb_fold > 1e-7f) {
+        // BatchNorm-folded RGB trunks: one power of two on every activation (target: the largest <= 2^12, so that the small early maps keep their
+        // distance from fp16's sub-normal floor).  Non-finite: 2^-8 per pass.  Gives up (bf16) below 2^-23.
+        h->rgb_fold *= h->calib_bad[2] ? 1.0f / 256.0f : pow2_down(h->calib_max[2], 4096.0f);
+        refold |= 4; rebuild &= ~4;
+        // the cross-modal block's verdict was formed on the unfolded features: judge it again behind the folded trunk
+        if ((rebuild & 8) && !h->calib_bad[0] && !h->calib_bad[1]) rebuild &= ~8;
+    }
+    if (!rebuild && !refold) return HCM_OK;
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
                     " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
@@ -344,6 +394,8 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     if (rebuild & 2) h->dt_depth = DT_BF16;
     if (rebuild & 4) h->dt_rgb = DT_BF16;
     if (rebuild & 8) h->dt_vla = DT_BF16;
+    h->range_fold |= refold;
+    (void)hipMemset(h->calib_buf + hcm_ctx::kStepBadWord, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
     h->fp16_fallback |= rebuild;
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);      // captured with the old weight pointers
     h->graphs.clear();
@@ -363,17 +415,23 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
             if (stream) (void)hipStreamSynchronize(stream); else (void)hipDeviceSynchronize();
             (void)hipFree(h->arena.base);
             h->arena.base = nullptr;
-            h->arena.cap = h->arena.peak + 4096;
-            if (hipMalloc((void**)&h->arena.base, h->arena.cap) != hipSuccess)
-                return fail(h, HCM_ERR_NOMEM, "hipMalloc of the workspace failed (" + std::to_string(h->arena.cap) + " bytes)");
+            h->arena.cap = 0;
+            const size_t want = h->arena.peak + 4096;
+            if (hipMalloc((void**)&h->arena.base, want) != hipSuccess) {
+                h->arena.base = nullptr;
+                h->unusable = true;                // no workspace: every forward entry point now answers HCM_ERR_STATE instead of writing through a null base
+                return fail(h, HCM_ERR_NOMEM, "hipMalloc of the workspace failed (" + std::to_string(want) + " bytes); the handle is unusable");
+            }
+            h->arena.cap = want;
         }
     } catch (const std::exception& e) {
         h->arena.dry = false;
         return fail(h, HCM_ERR_HIP, std::string("re-building a sub-network on bf16 tiles failed: ") + e.what());
     }
     // once more on the re-built engine: what was downstream of the overflow is measured on clean inputs now (the reported ranges are
-    // those of the engine as it runs); a sub-network is re-built at most once, so this ends after at most four passes
-    return pass < 4 ? calibrate_run(h, rgb, rgb_dt, depth, ids, ids_dt, B, L, stream, pass + 1) : HCM_OK;
+    // those of the engine as it runs).  A sub-network moves to bf16 at most once; folds converge in a pass or two per position (one blind step
+    // and one re-centring for a position that went non-finite), the pass limit bounds a pathological chain of them.
+    return pass < 16 ? calibrate_run(h, rgb, rgb_dt, depth, ids, ids_dt, B, L, stream, pass + 1) : HCM_OK;
 }
 // deterministic synthetic calibration batch for hcm_finalize: frames of mid-range noise, ids spread over the vocabulary
 static int calibrate_synthetic(hcm_ctx* h) {
@@ -433,8 +491,8 @@ int hcm_finalize(hcm_handle h) {
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
-        if (hipMalloc((void**)&h->calib_buf, 64) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
-        if (hipMemset(h->calib_buf, 0, 64) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipMemset failed");       // words 0-7: calibration, 12: step guard
+        if (hipMalloc((void**)&h->calib_buf, hcm_ctx::kCalibWords * 4) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+        if (hipMemset(h->calib_buf, 0, hcm_ctx::kCalibWords * 4) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipMemset failed");       // words 0-7: calibration, 12: step guard, 16..: conv positions
         // fp16 range check on a synthetic batch; a real batch can follow through hcm_calibrate (reserved[4]: keep the host weights for it)
         if (!getenv("HCM_NO_CALIB")) {
             const int rc = calibrate_synthetic(h);
@@ -518,6 +576,7 @@ int hcm_release_host_weights(hcm_handle h) {
 static int check_fwd(hcm_ctx* h, int B) {
     REQUIRE(h, HCM_ERR_ARG, "null handle");
     REQUIRE(h->finalized, HCM_ERR_STATE, "forward before hcm_finalize");
+    REQUIRE(!h->unusable, HCM_ERR_STATE, "the handle lost its workspace in a failed re-build (hcm_calibrate): destroy it");
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, HCM_ERR_ARG, "batch must be in [1, max_batch]");
     return HCM_OK;
 }
@@ -706,6 +765,7 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_GRAPH_LAUNCHES: *out = h->graph_launches; break;
         case HCM_EAGER_LAUNCHES: *out = h->eager_launches; break;
         case HCM_FP16_FALLBACK: *out = h->fp16_fallback; break;
+        case HCM_RANGE_FOLD: *out = h->range_fold; break;
         case HCM_CALIB_MAX_BERT: *out = (int64_t)h->calib_max[0]; break;
         case HCM_CALIB_MAX_DEPTH: *out = (int64_t)h->calib_max[1]; break;
         case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1] + (int64_t)h->calib_bad[2] + (int64_t)h->calib_bad[3]; break;
@@ -714,8 +774,13 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_STEP_NONFINITE: {           // (synchronises the device: a diagnostic, not a per-step call)
             unsigned v = 0;
             if (!h->calib_buf) { *out = 0; break; }
-            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->calib_buf + hcm_ctx::kStepBadWord, 4, hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(h, HCM_ERR_HIP, "hcm_query: reading the overflow guard failed");
+            // wait for the steps in flight on the HANDLE's device, whatever device is current in the calling thread
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (h->device >= 0 && cur != h->device) (void)hipSetDevice(h->device);
+            const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&v, h->calib_buf + hcm_ctx::kStepBadWord, 4, hipMemcpyDeviceToHost) == hipSuccess;
+            if (h->device >= 0 && cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
+            if (!ok) return fail(h, HCM_ERR_HIP, "hcm_query: reading the overflow guard failed");
             *out = (int64_t)v;
             break;
         }
@@ -724,10 +789,30 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
     return HCM_OK;
 }
 
+int hcm_guard_poll(hcm_handle h, void* stream, int64_t* out) {
+    REQUIRE(h && out, HCM_ERR_ARG, "null argument");
+    REQUIRE(h->finalized && h->calib_buf, HCM_ERR_STATE, "hcm_guard_poll before hcm_finalize");
+    if (!h->guard_host) {
+        if (hipHostMalloc((void**)&h->guard_host, 8, hipHostMallocDefault) != hipSuccess) { h->guard_host = nullptr; return fail(h, HCM_ERR_NOMEM, "hipHostMalloc failed"); }
+        *h->guard_host = 0u;
+        if (hipEventCreateWithFlags(&h->guard_ev, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
+    }
+    if (h->guard_pending && hipEventQuery(h->guard_ev) == hipSuccess) { h->guard_last = *h->guard_host; h->guard_pending = false; }
+    if (!h->guard_pending) {
+        if (hipMemcpyAsync(h->guard_host, h->calib_buf + hcm_ctx::kStepBadWord, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+            hipEventRecord(h->guard_ev, (hipStream_t)stream) != hipSuccess)
+            return fail(h, HCM_ERR_HIP, "hcm_guard_poll: enqueueing the read failed");
+        h->guard_pending = true;
+    }
+    *out = (int64_t)h->guard_last;
+    return HCM_OK;
+}
+
 const char* hcm_last_error(hcm_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 void hcm_destroy(hcm_handle h) {
     if (!h) return;
+    comm_destroy(h);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
@@ -735,6 +820,8 @@ void hcm_destroy(hcm_handle h) {
     if (h->stage_rgb) (void)hipFree(h->stage_rgb);
     if (h->stage_depth) (void)hipFree(h->stage_depth);
     if (h->len_buf) (void)hipFree(h->len_buf);
+    if (h->guard_ev) (void)hipEventDestroy(h->guard_ev);
+    if (h->guard_host) (void)hipHostFree(h->guard_host);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 4; ++i) {

@@ -261,8 +261,8 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     const int CH = dt_chunk(dt);
     if ((ldq % CH) || (ldk % CH) || (ldv % CH) || (ldo % CH)) return hipErrorInvalidValue;
     if (q_batch_mod <= 0) q_batch_mod = B;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -270,7 +270,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<f16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<bf16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<f16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_once.done();
     }
     static const char* valu = getenv("HCM_ATT_VALU");
     if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 512 && !(valu && atoi(valu))) {

@@ -89,6 +89,33 @@ __device__ __forceinline__ void st_chunk(f16* p, const float (&o)[8]) {
     *reinterpret_cast<half8_t*>(p) = __builtin_convertvector(f, half8_t);
 }
 
+// 8 floats -> 16 bytes of T in registers (one rounding each, as st_chunk)
+template <typename T> __device__ __forceinline__ uint4 pack_chunk(const float (&o)[8]);
+template <> __device__ __forceinline__ uint4 pack_chunk<bf16>(const float (&o)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <> __device__ __forceinline__ uint4 pack_chunk<f16>(const float (&o)[8]) {
+    float8_t f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = o[i];
+    return __builtin_bit_cast(uint4, __builtin_convertvector(f, half8_t));
+}
+// Accumulator tiles of two ADJACENT 16-channel blocks (a: channels c0 + fg*4 + r, b: channels c0 + 16 + fg*4 + r of pixel `lane & 15`) ->
+// 8 CONSECUTIVE channels of that pixel per lane, v[0..7] = channels c0 + (fg & 1) * 16 + (fg >> 1) * 8 + 0..7: v_permlane16_swap_b32 exchanges the
+// odd 16-lane rows of its first operand with the even rows of its second, which is exactly this regrouping.  No LDS, no barrier: the
+// epilogue that follows stores 16 bytes per lane (64 contiguous bytes per pixel and wave instruction).
+template <typename V4> __device__ __forceinline__ void swap_pair(const V4& a, const V4& b, float (&v)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        v[r] = __uint_as_float(s[0]);
+        v[4 + r] = __uint_as_float(s[1]);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -35,9 +35,12 @@ struct Fwd {
     }
     // fp16 calibration: which range slot the launches being enqueued belong to (-1: none)
     int calib_slot = -1;
-    void calib_check(const void* y, int ydt, int rows, int cols, int ld) {
+    // pos >= 0: y is the UN-NORMALISED output of GroupNorm-trunk conv `pos` -- also reduced into that position's own range slot, from which a
+    // calibration folds a power of two into the conv's weights instead of giving up fp16 (api.cpp calibrate_run)
+    void calib_check(const void* y, int ydt, int rows, int cols, int ld, int pos = -1) {
         if (dry || !ctx->calib || calib_slot < 0 || ydt != DT_F16) return;
         ck(launch_absmax(y, ydt, rows, cols, ld, ctx->calib_buf + 2 * calib_slot, s), "calibration range check");
+        if (pos >= 0 && calib_slot == 1) ck(launch_absmax(y, ydt, rows, cols, ld, ctx->calib_buf + 16 + 2 * pos, s), "calibration range check (conv position)");
     }
     void* alloc_t(size_t elems) { return ar.alloc(elems * esz); }
     float* alloc_f(size_t elems) { return (float*)ar.alloc(elems * 4); }
@@ -65,11 +68,12 @@ struct Fwd {
                  int Wo, int cg_true = 0) {
         static const bool no_fuse = getenv("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
+        const float eps = 1e-5f * w.fold * w.fold;          // range-folded conv (ConvW::fold): GroupNorm((fold * x), eps * fold^2) == GroupNorm(x, eps)
         if (cg_true) {
             // zero-padded output channels (compression conv of 64*k-pixel frames, k not a power of two): the statistics count the real
             // channels of each group only -- the stand-alone slab kernel knows how
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
-            gn(out, res, n, in.B, hw, C, G, relu, cg_true);
+            gn(out, res, n, in.B, hw, C, G, relu, cg_true, eps);
             return;
         }
         // the fused epilogue needs 64x128 tiles: not worth it when that leaves a long-K conv on a handful of workgroups
@@ -78,7 +82,7 @@ struct Fwd {
         const bool fuse = !no_fuse && hw <= 64 && 64 % hw == 0 && cg % 8 == 0 && 128 % cg == 0 && w.Cout % cg == 0 && !w.bias &&
                           (blocks >= 64 || w.K < 4096);
         if (fuse) {
-            conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg);
+            conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg, nullptr, 0, 0, 0, eps);
         } else {
             // large maps: the statistics come out of the conv's epilogue (column sums of the f32 tile image per 64-row block and
             // group), so GroupNorm is one launch over the map instead of two
@@ -86,19 +90,19 @@ struct Fwd {
             if (!no_cs && !w.bias && groupnorm_apply_ok(w.dt, hw, C, G) && w.Cout % cg == 0) {
                 float* stats = alloc_f(gn_stats_floats(in.B, hw, G));
                 conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo, nullptr, 0, stats, cg, hw, G);
-                if (!dry) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, 1e-5f, relu ? 1 : 0, s), "groupnorm apply");
+                if (!dry) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, eps, relu ? 1 : 0, s), "groupnorm apply");
                 return;
             }
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
-            gn(out, res, n, in.B, hw, C, G, relu);
+            gn(out, res, n, in.B, hw, C, G, relu, 0, eps);
         }
     }
     void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo,
-              const NormW* gnw = nullptr, int gn_cg = 0, float* cs_part = nullptr, int cs_cg = 0, int cs_hw = 0, int cs_G = 0) {
+              const NormW* gnw = nullptr, int gn_cg = 0, float* cs_part = nullptr, int cs_cg = 0, int cs_hw = 0, int cs_G = 0, float gn_eps = 1e-5f) {
         if (dry) return;
         IGemm g;
         g.cs_part = cs_part; g.cs_cg = cs_cg; g.cs_hw = cs_hw; g.cs_G = cs_G;
-        if (gnw) { g.gn_gamma = gnw->gamma; g.gn_beta = gnw->beta; g.gn_cg = gn_cg; g.gn_hw = Ho * Wo; g.gn_eps = 1e-5f; }
+        if (gnw) { g.gn_gamma = gnw->gamma; g.gn_beta = gnw->beta; g.gn_cg = gn_cg; g.gn_hw = Ho * Wo; g.gn_eps = gn_eps; }
         g.x = in.p; g.w = w.w; g.bias = w.bias; g.res = res; g.y = out;
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
         g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
@@ -108,7 +112,8 @@ struct Fwd {
             g.groups = w.groups; g.g_x = w.Cin; g.g_w = (long long)w.Cout * w.Kp; g.g_b = w.Cout; g.g_y = w.Cout;
         }
         ck(launch_igemm(g, w.dt, s), "conv igemm");
-        calib_check(out, w.dt, g.M, w.groups * w.Cout, w.groups * w.Cout);
+        // (with the fused GroupNorm epilogue the un-normalised values never leave f32 registers: `out` is the normalised map)
+        calib_check(out, w.dt, g.M, w.groups * w.Cout, w.groups * w.Cout, gnw ? -1 : w.calib_pos);
     }
     // y[M][ldy(+col)] = act(A[M][lda] @ W^T + b (+res))
     // Skinny long-K layers (the M = batch projections behind the encoders, SimpleCNN's 25088-wide FC) would run on a few
@@ -143,10 +148,10 @@ struct Fwd {
         ck(launch_igemm(g, wd, s), "linear igemm");
         if (!out_f32) calib_check(y, wd, M, w.N, ldy);
     }
-    void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu, int cg_true = 0) {
+    void gn(void* x, const void* res, const NormW& n, int B, int HW, int C, int G, bool relu, int cg_true = 0, float eps = 1e-5f) {
         float* stats = alloc_f(gn_stats_floats(B, HW, G));
         if (dry) return;
-        ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, 1e-5f, relu ? 1 : 0, s, cg_true), "groupnorm");
+        ck(launch_groupnorm(x, res, n.gamma, n.beta, stats, dt, B, HW, C, G, eps, relu ? 1 : 0, s, cg_true), "groupnorm");
     }
     void ln(const void* x, const void* res, const NormW& n, const float* post, int post_rows, void* y, int rows, int D, float eps) {
         if (dry) return;
@@ -170,6 +175,7 @@ struct Fwd {
         // 8x8/4, where it coincides with the plain layout); the vector gather exists for f32 frames only
         g.x_rowrun = (w.K == w.KH * 24 && st.Cin == 3 && st.x_dt == DT_F32) ? 1 : 0;
         ck(launch_igemm(g, w.dt, s), "stem conv");
+        calib_check(out, w.dt, g.M, w.Cout, w.Cout, w.calib_pos);
     }
 
     // 16-bit RGB trunks: pack the frame once, then the stem is an ordinary LDS-DMA implicit GEMM (kernels.h: launch_pack_frame)
@@ -224,15 +230,16 @@ struct Fwd {
                 g.M = B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = ACT_NONE;
                 if (stem_stats) { g.cs_part = stem_stats; g.cs_cg = c1 / G; g.cs_hw = Ho * Wo; g.cs_G = G; }
                 ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
-                calib_check(slot[0], w.dt, g.M, w.Cout, w.Cout);
+                calib_check(slot[0], w.dt, g.M, w.Cout, w.Cout, w.calib_pos);
             }
         } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
+        const float stem_eps = 1e-5f * t.conv1.fold * t.conv1.fold;      // (conv1 and conv1_packed carry the same fold)
         if (t.gn && stem_stats) {
             if (!dry) ck(launch_groupnorm_apply(slot[0], nullptr, t.n_conv1.gamma, t.n_conv1.beta, stem_stats, Ho * Wo / 64, t.conv1_packed.dt, B, Ho * Wo, c1, G,
-                                                1e-5f, 1, s), "groupnorm apply (stem)");
-        } else if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true);
+                                                stem_eps, 1, s), "groupnorm apply (stem)");
+        } else if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true, 0, stem_eps);
         if (!hpool) tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
         if (hpool) {
@@ -419,16 +426,42 @@ struct Fwd {
         void* hbuf = alloc_t(rmax * c.bert_inter);
         if (!dry) ck(launch_bert_embed(ids, ids_dt, w.word, w.pos, w.type0, w.ln.gamma, w.ln.beta, x, dt, B, L, D, c.bert_vocab, 1e-12f, s), "bert_embed");
         tap("hi.bert_emb", x, true, {B, L, D});
+        // bf16 tiles (precision "bf16", or BERT after a range fall-back): the RESIDUAL STREAM stays in f32.  bf16 keeps 8 significant bits; rounding
+        // the stream itself four times per layer (both sums in front of the LayerNorms, both LayerNorm outputs) is what costs 6-9e-3 of the 1e-2
+        // record tolerance.  Here only the GEMM operands are bf16: the projections write `sum = branch + stream` in f32, the LayerNorm
+        // reads that and writes the stream in f32 beside its bf16 operand copy (HCM_BERT_BF16_STREAM=0: the all-16-bit form, for the A/B).
+        static const bool f32_stream_off = getenv("HCM_BERT_BF16_STREAM") && atoi(getenv("HCM_BERT_BF16_STREAM")) == 0;
+        const bool f32_stream = dt == DT_BF16 && !f32_stream_off && (D == 768 || D == 256 || D == 512);
+        float* xf = f32_stream ? alloc_f(rmax * D) : nullptr;       // the stream
+        float* sumf = f32_stream ? alloc_f(rmax * D) : nullptr;     // branch + stream, in front of a LayerNorm
+        if (f32_stream && !dry) ck(launch_convert_to_f32(x, dt, xf, (size_t)rows * D, s), "bert stream init");
+        auto linear_res_f32 = [&](const LinW& lw, const void* a, int lda) {     // sumf = a @ W^T + b + xf
+            if (dry) return;
+            IGemm g;
+            g.x = a; g.w = lw.w; g.bias = lw.bias; g.res = xf; g.res_f32 = 1; g.y = sumf; g.out_f32 = 1;
+            g.B = rows; g.Cin = lw.K; g.xC = lda; g.M = rows; g.N = lw.N; g.K = lw.K; g.Kp = lw.Kp; g.ldy = D; g.ldr = D; g.act = ACT_NONE;
+            ck(launch_igemm(g, lw.dt, s), "bert linear (f32 stream)");
+        };
         int li = 0;
         for (const BertLayerW& l : w.layers) {
             linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
             if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
                                           L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
-            linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
-            ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
+            if (f32_stream) {
+                linear_res_f32(l.o, ctxb, D);
+                if (!dry) ck(launch_layernorm_f32in(sumf, l.ln1.gamma, l.ln1.beta, x, xf, dt, rows, D, 1e-12f, s), "bert layernorm (f32 stream)");
+            } else {
+                linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
+                ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
+            }
             linear(l.ff1, x, rows, D, hbuf, c.bert_inter, ACT_GELU, false);
-            linear(l.ff2, hbuf, rows, c.bert_inter, tmp, D, ACT_NONE, false, x, D);
-            ln(tmp, nullptr, l.ln2, nullptr, 0, x, rows, D, 1e-12f);
+            if (f32_stream) {
+                linear_res_f32(l.ff2, hbuf, c.bert_inter);
+                if (!dry) ck(launch_layernorm_f32in(sumf, l.ln2.gamma, l.ln2.beta, x, xf, dt, rows, D, 1e-12f, s), "bert layernorm (f32 stream)");
+            } else {
+                linear(l.ff2, hbuf, rows, c.bert_inter, tmp, D, ACT_NONE, false, x, D);
+                ln(tmp, nullptr, l.ln2, nullptr, 0, x, rows, D, 1e-12f);
+            }
             if (li == 0) tap("hi.bert_l0", x, true, {B, L, D});
             ++li;
         }
@@ -941,8 +974,8 @@ struct Fwd {
         HiBufs hb = hi_alloc(B);                                  // same offsets as in step(): the persistent tensors
         const int L = ctx->cur_L, d = c.d_model;
         const size_t idsz = ids_dt == DT_I64 ? 8 : 4;
-        char* sub_ids = (char*)ar.alloc((size_t)n * L * idsz);
-        int* sub_lens = ctx->cur_lens ? (int*)ar.alloc((size_t)n * sizeof(int)) : nullptr;
+        char* sub_ids = (char*)ar.alloc((size_t)n * c.instr_len * idsz);
+        int* sub_lens = (ctx->cur_lens || dry) ? (int*)ar.alloc((size_t)n * sizeof(int)) : nullptr;
         HiBufs hn;
         use(ctx->dt_bert);
         hn.emb = alloc_t((size_t)n * c.instr_len * c.bert_hidden);
@@ -950,15 +983,18 @@ struct Fwd {
         hn.I = alloc_t((size_t)n * c.instr_len * d);
         hn.Q.resize(hb.Q.size());
         for (auto& q : hn.Q) q = alloc_t((size_t)n * c.instr_len * d);
-        for (int i = 0; i < n; ++i)
-            ck(hipMemcpyAsync(sub_ids + (size_t)i * L * idsz, (const char*)ids + (size_t)idx[i] * L * idsz, (size_t)L * idsz, hipMemcpyDeviceToDevice, s), "ids gather");
-        if (sub_lens)
+        if (!dry) {
             for (int i = 0; i < n; ++i)
-                ck(hipMemcpyAsync(sub_lens + i, ctx->cur_lens + idx[i], sizeof(int), hipMemcpyDeviceToDevice, s), "lengths gather");
+                ck(hipMemcpyAsync(sub_ids + (size_t)i * L * idsz, (const char*)ids + (size_t)idx[i] * L * idsz, (size_t)L * idsz, hipMemcpyDeviceToDevice, s), "ids gather");
+            if (ctx->cur_lens)
+                for (int i = 0; i < n; ++i)
+                    ck(hipMemcpyAsync(sub_lens + i, ctx->cur_lens + idx[i], sizeof(int), hipMemcpyDeviceToDevice, s), "lengths gather");
+        }
         use(ctx->dt_bert);
-        bert(ctx->hi.bert, sub_ids, ids_dt, n, hn.emb, sub_lens);
+        bert(ctx->hi.bert, sub_ids, ids_dt, n, hn.emb, ctx->cur_lens ? sub_lens : nullptr);
         hi_ins_pre(n, hn);
         use(ctx->dt_vla);
+        if (dry) return;                                          // (hcm_finalize's sizing pass: allocations only)
         const size_t row = (size_t)L * d * esz;
         for (int i = 0; i < n; ++i) {
             ck(hipMemcpyAsync((char*)hb.I + idx[i] * row, (char*)hn.I + i * row, row, hipMemcpyDeviceToDevice, s), "I scatter");

@@ -46,6 +46,7 @@ struct IGemmDev {
     int B, H, W, Cin, xC, Ho, Wo, KH, KW, stride, pad;
     int stride_w;                  // horizontal stride (== stride except for the packed-frame stem, see launch_pack_frame)
     int M, N, K, Kp, ldy, ldr, act, out_f32;
+    int res_f32;                   // the residual is an f32 tensor [M][ldr] (16-bit kernels: the f32 residual stream of the bf16 BERT)
     int cin_shift, kw_rcp, tilesM, tilesN, map;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
     float x_scale;                 // narrow-channel first-layer gather: value = src * x_scale
@@ -257,7 +258,15 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
         }
-        if (p.res) {
+        if (p.res && p.res_f32) {
+            const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldr + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            if (hi_ok) {
+                const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+        } else if (p.res) {
             const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
             if constexpr (sizeof(T) == 2) {
                 if (have_pre) {                 // residual chunk prefetched at kernel start (see igemm_dma_kernel)
@@ -490,7 +499,15 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
         }
-        if (p.res) {
+        if (p.res && p.res_f32) {
+            const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldr + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            if (hi_ok) {
+                const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+                v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+        } else if (p.res) {
             const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n;
             if constexpr (sizeof(T) == 2) {
                 if (have_pre) {                 // residual chunk prefetched at kernel start (see igemm_dma_kernel)
@@ -964,7 +981,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     uint4 rpre[E_NP];
     bool have_pre = false;
     if constexpr (sizeof(T) == 2 && NW == 8 && E_NP <= 8) {
-        if (p.res && (p.ldr % 8) == 0 && (p.N % 8) == 0) {
+        if (p.res && !p.res_f32 && (p.ldr % 8) == 0 && (p.N % 8) == 0) {
             have_pre = true;
             const int n = n0 + (tid % E_TPR) * 8;
 #pragma unroll
@@ -1749,6 +1766,317 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
     igemm_epilogue_split<T, BM, CN, NW, WMc, 1, R_SPLIT>(pr, acc3, smem + T_BYTES + W3_BYTES, m0, 0, tid, wm, wn, fr, fg, none, false);
 }
 
+// bneck231_kernel with REGISTER epilogues (round 3).  The f32 LDS image of the shared epilogue -- write the accumulators, barrier, read
+// rows back, barrier, per 64-row slab -- was most of this kernel's 42 barriers per pixel tile and the reason it ran at 0.44 of the HBM rate
+// its bytes ask for.  Here phase B re-partitions the 8 waves as 4 (pixels) x 2 (channels): a wave owns BM/4 pixels x 32 channels of a 64-wide
+// output slice, i.e. PAIRS of adjacent 16-channel accumulator tiles, and swap_pair (v_permlane16_swap_b32, dev.h) turns a pair into 8
+// consecutive channels of one pixel per lane.  Bias + identity + ReLU + the one rounding then happen in registers and the lane stores its
+// 16 bytes twice: to y, and into the slice block in LDS that the next block's reduction reads as its MFMA operand.  Per slice that leaves TWO
+// barriers (weights landed / slice block complete); the reduction's weight slices are double-buffered so that nothing else has to be waited
+// for.  Same MFMA sequence, same f32 operations in the same order as bneck231_kernel: bit-identical to it and to the stand-alone launches.
+template <typename T, int BM, int C1, int CN, int KD = 0>
+__global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
+    BneckDev& q = qq.t;
+    constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
+    constexpr int TM = BM / WMc / 16;              // phase A: BM / 2 pixels x C1 / 4 channels per wave
+    constexpr int TN1 = C1 / WNc / 16;
+    constexpr int WM2 = 4, WN2 = 2;                // phase B: BM / 4 pixels x 32 channels (of a slice) or CN / 2 channels (reduction) per wave
+    constexpr int TMB = BM / WM2 / 16;
+    constexpr int TN2 = SW / WN2 / 16;             // 2: one pair
+    constexpr int TN3 = CN / WN2 / 16;             // 2 or 4: one or two pairs
+    constexpr int A_IT = BM / 8 / NW, B_IT = C1 / 8 / NW;
+    constexpr int TILE_BYTES = (BM + C1) * 128;
+    constexpr int KT1 = C1 / BK;
+    constexpr int NT = 4 * C1 / SW;
+    constexpr int KTB = KT1 + KD;
+    constexpr int T_BYTES = KTB * BM * 128, W3_BYTES = KTB * SW * 128;
+    constexpr int YS_OFF = T_BYTES + W3_BYTES, YS_BYTES = BM * 128;
+    constexpr int W1_OFF = YS_OFF + YS_BYTES, W1_BYTES = CN * 128;      // two buffers
+    static_assert(A_IT >= 1 && B_IT >= 1 && TN1 >= 1 && TMB >= 1 && TN2 == 2 && TN3 % 2 == 0 && sizeof(T) == 2, "bneck231r tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    IGemmDev& p = q.a;
+    if (p.groups > 1) {
+        const long long g = blockIdx.y;
+        p.x += g * p.g_x * 2;
+        p.w += g * p.g_w * 2;
+        p.bias += g * p.g_b;
+        q.w3 += g * q.g_w3 * 2;
+        q.b3 += g * q.g_b3;
+        q.res += g * q.g_y3 * 2;
+        q.y += g * q.g_y3 * 2;
+        qq.w1 += g * qq.g_w1 * 2;
+        qq.b1 += g * qq.g_b1;
+        qq.o1 += g * qq.g_o1 * 2;
+        if (KD) qq.xd += g * qq.g_xd * 2;
+    }
+    const int m0 = blockIdx.x * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNc, wn = wave % WNc;
+    const int wm2 = wave / WN2, wn2 = wave % WN2;
+    const int rin = lane >> 3;
+    const int c = (lane & 7) ^ rin;
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+    const int coff = (fg & 1) * 16 + (fg >> 1) * 8;        // the lane's 8 channels inside a 32-channel pair (swap_pair)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // identity rows of every output slice, requested first: they arrive while phase A runs (16 B per lane, pixel tile and slice)
+    uint4 rpre[NT][TMB] = {};
+    if constexpr (KD == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < TMB; ++j) {
+                const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
+                if (m < p.M) rpre[nt][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
+            }
+    }
+
+    int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + rin;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_pix[i] = b * p.H * p.W;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+        } else {
+            a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+        }
+    }
+    const v4i_t rx = make_rsrc(p.x, p.x_bytes);
+    const v4i_t rw = make_rsrc(p.w, p.w_bytes);
+    const v4i_t rw3 = make_rsrc(q.w3, q.w3_bytes);
+    const v4i_t rw1 = make_rsrc(qq.w1, qq.w1_bytes);
+    const v4i_t rxd = make_rsrc(qq.xd, KD ? qq.xd_bytes : 0u);
+
+    auto stage = [&](int kt, int buf) {
+        const unsigned sa = lds_base + buf * TILE_BYTES;
+        const unsigned sb = sa + BM * 128;
+        const int k = kt * BK + c * CH;
+        const int khw = k >> p.cin_shift;
+        const int ci = k & (p.Cin - 1);
+        const int kh = (khw * p.kw_rcp) >> 16;
+        const int kw = khw - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * 2u;
+            dma16(sa + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = (wave + NW * i) * 8 + rin;
+            const unsigned off = (unsigned)(n * p.Kp + k) * 2u;
+            dma16(sb + (wave + NW * i) * 1024, (k < p.Kp) ? off : 0xFFFFFFFFu, rw);
+        }
+    };
+    auto stage_xd = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < KD; ++kt)
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const unsigned off = (unsigned)((a_pix[i] + (a_iy0[i] + p.pad) * p.W + a_ix0[i] + p.pad) * qq.xdC + kt * BK + c * CH) * 2u;
+                dma16(lds_base + (KT1 + kt) * (BM * 128) + (wave + NW * i) * 1024, a_pix[i] >= 0 ? off : 0xFFFFFFFFu, rxd);
+            }
+    };
+    auto stage_w3 = [&](int nt) {
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt) {
+            const int n = nt * SW + wave * 8 + rin;
+            const unsigned off = (unsigned)(n * q.Kp3 + kt * BK + c * CH) * 2u;
+            dma16(lds_base + T_BYTES + kt * (SW * 128) + wave * 1024, off, rw3);
+        }
+    };
+    auto stage_w1 = [&](int nt) {
+#pragma unroll
+        for (int i = 0; i < CN / 8 / NW; ++i) {
+            const int n = (wave + NW * i) * 8 + rin;
+            const unsigned off = (unsigned)(n * (4 * C1) + nt * SW + c * CH) * 2u;
+            dma16(lds_base + W1_OFF + (nt & 1) * W1_BYTES + (wave + NW * i) * 1024, off, rw1);
+        }
+    };
+
+    // ---- phase A: 3x3 conv, BM x C1 (as in bneck23_kernel)
+    f32x4 acc1[TN1][TM];
+#pragma unroll
+    for (int i = 0; i < TN1; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + BK - 1) / BK;
+    constexpr int LPT = A_IT + B_IT;
+    stage(0, 0);
+    if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[TM], wb[TN1];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / WMc) + j * 16 + fr;
+                xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i) {
+                const int r = wn * (C1 / WNc) + i * 16 + fr;
+                wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
+        }
+        if (more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    stage_w3(0);
+    stage_w1(0);
+    if constexpr (KD > 0) stage_xd();
+#pragma unroll
+    for (int i = 0; i < TN1; ++i) {
+        const int cc = wn * (C1 / WNc) + i * 16 + fg * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cc);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * (BM / WMc) + j * 16 + fr;
+            T o4[4];
+            Tr<T>::st(&o4[0], relu_f(acc1[i][j][0] + b4.x));
+            Tr<T>::st(&o4[1], relu_f(acc1[i][j][1] + b4.y));
+            Tr<T>::st(&o4[2], relu_f(acc1[i][j][2] + b4.z));
+            Tr<T>::st(&o4[3], relu_f(acc1[i][j][3] + b4.w));
+            char* dst = smem + (cc >> 6) * (BM * 128) + r * 128 + ((((cc & 63) >> 3) ^ (r & 7)) << 4) + (cc & 7) * 2;
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o4);
+        }
+    }
+    // ---- phase B: NT slices of BM x 64 output channels, each followed by its K slice of the next block's reduction
+    f32x4 acc3[TN3][TMB];
+#pragma unroll
+    for (int i = 0; i < TN3; ++i)
+#pragma unroll
+        for (int j = 0; j < TMB; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    T* const yp = reinterpret_cast<T*>(q.y);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        // the lane's 8 expansion biases of this slice: in flight over the barrier and the MFMAs
+        const int nb = nt * SW + wn2 * 32 + coff;
+        const float4 b30 = *reinterpret_cast<const float4*>(q.b3 + nb), b31 = *reinterpret_cast<const float4*>(q.b3 + nb + 4);
+        wait_vmcnt<0>();                                   // this slice's weights (both matrices) have landed (and the bias, the identity rows)
+        __syncthreads();                                   // ... for every wave; parked tile complete; the previous reduction has left the slice block
+        f32x4 acc2[TN2][TMB];
+#pragma unroll
+        for (int i = 0; i < TN2; ++i)
+#pragma unroll
+            for (int j = 0; j < TMB; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt) {
+            const char* sa = smem + kt * (BM * 128);
+            const char* sb = smem + T_BYTES + kt * (SW * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TMB], wb[TN2];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TMB; ++j) {
+                    const int r = wm2 * (BM / WM2) + j * 16 + fr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i) {
+                    const int r = wn2 * 32 + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMB; ++j) Mma<T>::run(acc2[i][j], wb[i], xa[j]);
+            }
+        }
+        // register epilogue of the slice: bias + identity + ReLU, one rounding, 16 bytes per lane to y and into the slice block
+        const float bias8[8] = {b30.x, b30.y, b30.z, b30.w, b31.x, b31.y, b31.z, b31.w};
+#pragma unroll
+        for (int j = 0; j < TMB; ++j) {
+            float v[8];
+            swap_pair(acc2[0][j], acc2[1][j], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+            if constexpr (KD == 0) {
+                float rr[8];
+                cvt_chunk<T>(rpre[nt][j], rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
+            const uint4 o = pack_chunk<T>(v);
+            const int r = wm2 * (BM / WM2) + j * 16 + fr;
+            const int m = m0 + r;
+            if (m < p.M) *reinterpret_cast<uint4*>(yp + (size_t)m * q.ldy3 + nb) = o;
+            const int ch = (wn2 * 32 + coff) >> 3;
+            *reinterpret_cast<uint4*>(smem + YS_OFF + r * 128 + ((ch ^ (r & 7)) << 4)) = o;
+        }
+        __syncthreads();                                   // slice block complete; every wave is done with the expansion weights
+        if (nt + 1 < NT) { stage_w3(nt + 1); stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
+        {
+            const char* sa = smem + YS_OFF;
+            const char* sb = smem + W1_OFF + (nt & 1) * W1_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TMB], wb[TN3];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TMB; ++j) {
+                    const int r = wm2 * (BM / WM2) + j * 16 + fr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN3; ++i) {
+                    const int r = wn2 * (CN / WN2) + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN3; ++i)
+#pragma unroll
+                    for (int j = 0; j < TMB; ++j) Mma<T>::run(acc3[i][j], wb[i], xa[j]);
+            }
+        }
+    }
+    // the reduction's own epilogue (bias + ReLU), in registers as well
+    T* const op = reinterpret_cast<T*>(qq.o1);
+#pragma unroll
+    for (int i = 0; i < TN3; i += 2) {
+        const int nb = wn2 * (CN / WN2) + i * 16 + coff;
+        const float4 b0 = *reinterpret_cast<const float4*>(qq.b1 + nb), b1 = *reinterpret_cast<const float4*>(qq.b1 + nb + 4);
+        const float bias8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < TMB; ++j) {
+            float v[8];
+            swap_pair(acc3[i][j], acc3[i + 1][j], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e] + bias8[e]);
+            const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
+            if (m < p.M) *reinterpret_cast<uint4*>(op + (size_t)m * qq.ldo + nb) = pack_chunk<T>(v);
+        }
+    }
+}
+
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset) {
     std::vector<unsigned long long> h((size_t)kProfSlots * 8);
     hipError_t e = hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_igemm_prof), h.size() * 8);
@@ -1779,8 +2107,8 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     size_t lds = ((variant == 2 || variant == 5 || variant >= 7) ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024 + (d.cs_part ? 64 * 8 * 2 * 4 : 0);    // f32 output-tile image of the epilogue (+ fused-GroupNorm statistics, + column-sum slices)
     if (lds_c > lds) lds = lds_c;
-    static bool attr_done = false;                            // one flag per template instantiation
-    if (!attr_done) {
+    static DeviceOnce attr_once;                            // one flag per template instantiation
+    if (attr_once.need()) {
         const void* fns[4] = {reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
                               reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 2>),
                               reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 3>),
@@ -1797,7 +2125,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
                 if (e != hipSuccess) return e;
             }
         }
-        attr_done = true;
+        attr_once.done();
     }
     if constexpr (BN >= 64) {
         if constexpr (std::is_same<T, bf16>::value && BN == 128) {
@@ -1909,12 +2237,12 @@ static hipError_t launch_narrow(IGemmDev d, hipStream_t s) {
         size_t lds = 2 * (size_t)(BM + 128) * 128;
         const size_t lds_c = (size_t)BM * (128 + 4) * 4;
         if (lds_c > lds) lds = lds_c;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static DeviceOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<T, BM, 128, S>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            attr_once.done();
         }
         hipLaunchKernelGGL((igemm_kernel<T, BM, 128, S>), dim3(tm8 * 8 * d.tilesN), dim3(256), lds, s, d);
     }
@@ -2123,7 +2451,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.Ho = g.Ho; d.Wo = g.Wo; d.KH = g.KH; d.KW = g.KW; d.stride = g.stride; d.pad = g.pad;
     d.stride_w = g.stride_w > 0 ? g.stride_w : g.stride;
     d.M = g.M; d.N = g.N; d.K = g.K; d.Kp = g.Kp ? g.Kp : g.K;
-    d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32;
+    d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32; d.res_f32 = g.res_f32;
     const int CH = dt_chunk(dt);
     d.cin_shift = 0;
     d.kw_rcp = (65536 + g.KW - 1) / g.KW;
@@ -2301,23 +2629,36 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             if (xdb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
             qq.xd = (const char*)b.xd; qq.xdC = b.xdC; qq.xd_bytes = (unsigned)xdb; qq.g_xd = b.g_xd;
             const int BMd = 64;
-            size_t ldsd = (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BMd * 128 + (size_t)b.CN * 128;
+            // register-epilogue form (bneck231r_kernel, the default) or the LDS-image form (HCM_BNECK_IMAGE=1: A/B and the toggle test); bit-identical
+            static const bool image_d = getenv("HCM_BNECK_IMAGE") != nullptr;
+            size_t ldsd = image_d ? (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BMd * 128 + (size_t)b.CN * 128
+                                  : (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (size_t)BMd * 128 + (size_t)2 * b.CN * 128;
             const size_t ringd = 3 * (size_t)(BMd + b.C1) * 128;
             if (ringd > ldsd) ldsd = ringd;
-            const void* fd = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 64, 64, 1>);
+            const void* fd = image_d ? (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 64, 64, 1>))
+                                     : (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 64, 64, 1>));
             hipError_t ed = hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (ed != hipSuccess) return ed;
             void* ad[] = {&qq};
             return hipLaunchKernel(fd, dim3((d.M + BMd - 1) / BMd, d.groups), dim3(512), ad, ldsd, s);
         }
-        size_t lds1 = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128;
+        static const bool image = getenv("HCM_BNECK_IMAGE") != nullptr;
+        size_t lds1 = image ? (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128
+                            : (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)2 * b.CN * 128;
         const size_t ring1 = 3 * (size_t)(BM + b.C1) * 128;
         if (ring1 > lds1) lds1 = ring1;
         const void* f1;
-        if (dt == DT_BF16) f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 128, 128>)
-                              : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 128>);
-        else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 128, 128>)
-                : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 128>);
+        if (image) {
+            if (dt == DT_BF16) f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 128, 128>)
+                                  : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<bf16, 128, 64, 128>);
+            else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 128, 128>)
+                    : b.CN == 64 ? reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 128, 64, 128>);
+        } else {
+            if (dt == DT_BF16) f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 128, 128>)
+                                  : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 128>);
+            else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128>)
+                    : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128>);
+        }
         hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e1 != hipSuccess) return e1;
         void* a1[] = {&qq};

@@ -4,8 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 namespace hcm {
+
+// One-time kernel-attribute setup is PER DEVICE (hipFuncSetAttribute acts on the current device): a process-wide flag would leave the
+// second GPU of a process with the default 64 KB dynamic-LDS limit and its 130-160 KB launches failing.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0ull};
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool need() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 enum { DT_F32 = 0, DT_BF16 = 1, DT_I32 = 2, DT_I64 = 3, DT_U8 = 4, DT_F16 = 5 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
@@ -28,6 +38,7 @@ struct IGemm {
     int ldy = 0, ldr = 0;
     int act = ACT_NONE;
     int out_f32 = 0;
+    int res_f32 = 0;             // `res` is f32 [M][ldr] although T is a 16-bit type (launch_igemm's own kernels only: not gemm256, not grouped launches)
     // narrow-channel first layers (Cin = 1 or 3): x is the RAW frame of dtype x_src_dt (DT_F32 / DT_U8 / the storage
     // type), gathered element-wise and multiplied by x_scale; -1 = x is an ordinary T activation
     int x_src_dt = -1;
@@ -122,6 +133,9 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
 // LayerNorm rows: y = LN(x (+res)) * gamma + beta (+ post[row % post_rows][:])
 hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, const float* beta,
                             const float* post, int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s);
+// LayerNorm of an f32 tensor with two outputs: y16 (T: the next GEMM's operand) and y32 (f32: the residual stream); D = 768 / 256 / 512
+hipError_t launch_layernorm_f32in(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int dt, int rows, int D, float eps,
+                                  hipStream_t s);
 // BERT embeddings: y[b,l,:] = LN(word[id] + pos[l] + type0) ; tables f32
 hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, const float* pos, const float* type0,
                              const float* gamma, const float* beta, void* y, int dt, int B, int L, int D, int vocab,

@@ -26,6 +26,11 @@ struct ConvW {                 // [Cout][Kp] in the sub-network's storage dtype,
     float* bias = nullptr;     // f32 [Cout] or null
     int Cout = 0, Cin = 0, KH = 1, KW = 1, K = 0, Kp = 0;
     int groups = 1;            // 2: hi|lo pair trunk -- w holds [2][Cout][Kp], bias [2][Cout]; Cout / Cin are per group
+    // fp16 range folding (api.cpp calibrate_run): a GroupNorm-trunk conv whose un-normalised output left the fp16 guard band has the
+    // power of two `fold` multiplied into its weights; the GroupNorm behind it runs with eps * fold^2 and returns exactly what it would
+    // have returned for the unscaled conv.  calib_pos = position of the conv in the trunk topology (the per-position range slot).
+    float fold = 1.f;
+    int calib_pos = -1;
 };
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct LinW {                  // [N][Kp]; dt = compute dtype or f32 (recurrent weights)
@@ -169,6 +174,11 @@ struct hcm_ctx {
     hcm::CmaW cma;
     int* len_buf = nullptr;         // CMANet: per-sample instruction lengths
     bool finalized = false;
+    int device = -1;                // the HIP device the handle was created on
+    // hcm_guard_poll: the overflow-guard word travels to a pinned host word behind the caller's stream; read back without a synchronisation
+    unsigned* guard_host = nullptr; hipEvent_t guard_ev = nullptr; bool guard_pending = false; unsigned guard_last = 0u;
+    void* comm = nullptr; int comm_world = 1, comm_rank = 0;      // RCCL communicator of hcm_comm_init (comm.cpp)
+    bool unusable = false;          // a re-build after calibration could not get its workspace back
     std::vector<void*> dev_allocs;
     size_t weight_bytes = 0;
     hcm::HighW hi;
@@ -176,6 +186,7 @@ struct hcm_ctx {
     hcm::Arena arena;
     int64_t* pred_buf = nullptr;    // argmax output for hcm_act
     std::string err;
+    hcm_ctx() { for (auto& f : depth_fold) f = 1.f; }
     bool taps_on = false;
     std::map<std::string, hcm::Tap> taps;
     hipStream_t stream = nullptr;   // the caller's stream of the current call
@@ -201,12 +212,23 @@ struct hcm_ctx {
     // fp16 range calibration (hcm_finalize's synthetic batch, hcm_calibrate's caller batch): while `calib` is set the forward code
     // reduces max |x| / non-finite counts of every GEMM output of the fp16 sub-networks into calib_buf[2 * slot] (0 BERT, 1 depth trunks)
     bool calib = false;
-    unsigned* calib_buf = nullptr;       // device, 16 words: [2 * slot] = max |x| bits, [2 * slot + 1] = non-finite count (slots 0 BERT, 1 depth, 2 RGB,
-                                         // 3 cross-modal block); [kStepBadWord] = the run-time overflow guard of the recurrent cells
+    unsigned* calib_buf = nullptr;       // device, kCalibWords words: [2 * slot] = max |x| bits, [2 * slot + 1] = non-finite count (slots 0 BERT, 1 depth, 2 RGB,
+                                         // 3 cross-modal block); [kStepBadWord] = the run-time overflow guard of the recurrent cells;
+                                         // [16 + 2 * pos ..] = the same pair per GroupNorm-trunk conv position (un-normalised conv outputs)
     static constexpr int kStepBadWord = 12;
     int fp16_fallback = 0;               // bit 0: BERT was re-built on bf16 tiles, bit 1: the depth trunks
     float calib_max[4] = {0.f, 0.f, 0.f, 0.f};     // last calibration's max |x| per sub-network: BERT, depth trunks, RGB trunks, cross-modal block
     unsigned calib_bad[4] = {0u, 0u, 0u, 0u};
     bool host_weights = true;            // the f32 host copies of the state_dicts are still held (needed to re-build a sub-network)
+    // fp16 range folding instead of a bf16 fall-back where the network is exactly scale-invariant:
+    //   depth_fold[pos]  power of two folded into the weights of GroupNorm-trunk conv `pos` (GroupNorm removes it; eps scaled to match)
+    //   rgb_fold         power of two carried by EVERY activation of the BatchNorm-folded RGB trunks (ReLU / max-pool / average pools are
+    //                    positively homogeneous): stem weights and all folded biases are multiplied by it, the trunk-feature columns of
+    //                    the consuming projections (rgb_kv, rgb_linear, the low-level model's fc) by its inverse
+    static constexpr int kDepthPos = 66;  // conv1, 16 blocks x (c1, c2, c3, down-sample), compression
+    static constexpr int kCalibWords = 16 + 2 * kDepthPos;
+    float depth_fold[kDepthPos];
+    float rgb_fold = 1.f;
+    int range_fold = 0;                  // hcm_query(HCM_RANGE_FOLD): bit 1 depth, bit 2 RGB
     const int* cur_lens = nullptr;  // optional per-environment instruction lengths of the current call (device, [B]); null = all L
 };

@@ -462,11 +462,11 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
     // the pooled mean is complete inside one workgroup only when the block covers the whole instruction
     if ((p.pooled[0] || p.pooled[1]) && p.L > V_RB) return hipErrorInvalidValue;
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(vla_post_kernel<bf16>) : reinterpret_cast<const void*>(vla_post_kernel<f16>);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_once.done();
     }
     VlaPost q = p;
 #ifdef HCM_DEV_KNOBS

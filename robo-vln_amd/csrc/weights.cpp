@@ -240,9 +240,10 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // conv weight OIHW (+ optional per-channel scale) -> [O][Kp] with k = (kh*KW+kw)*I + ci
 static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vector<float>* scale,
-                       const std::vector<float>* bias, int cout_pad = 0) {
+                       const std::vector<float>* bias, int cout_pad = 0, float fold = 1.f, int pos = -1) {
     ConvW c;
     c.dt = dt;
+    c.fold = fold; c.calib_pos = pos;
     c.Cout = (int)w.shape[0]; c.Cin = (int)w.shape[1]; c.KH = (int)w.shape[2]; c.KW = (int)w.shape[3];
     c.K = c.KH * c.KW * c.Cin;
     c.Kp = round_up(c.K, 32);
@@ -250,7 +251,7 @@ static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vec
     if (cout_pad > c.Cout) c.Cout = cout_pad;                 // zero rows: output channels that are exactly 0 (bias-free convs only)
     std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
     for (int o = 0; o < co; ++o) {
-        const float sc = scale ? (*scale)[o] : 1.f;
+        const float sc = (scale ? (*scale)[o] : 1.f) * fold;
         for (int i = 0; i < c.Cin; ++i)
             for (int kh = 0; kh < c.KH; ++kh)
                 for (int kw = 0; kw < c.KW; ++kw)
@@ -263,19 +264,12 @@ static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vec
 }
 
 // eval-mode BatchNorm2d folded into the preceding bias-free conv: y = conv(x)*g/sqrt(v+eps) + (b - m*g/sqrt(v+eps))
-static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
+static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias, bool stem = false);
+static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn, bool stem = false) {
     const HostTensor& w = T_(ctx, model, wkey);
-    const HostTensor& g = T_(ctx, model, bn + ".weight");
-    const HostTensor& b = T_(ctx, model, bn + ".bias");
-    const HostTensor& m = T_(ctx, model, bn + ".running_mean");
-    const HostTensor& v = T_(ctx, model, bn + ".running_var");
     const int C = (int)w.shape[0];
-    std::vector<float> scale(C), bias(C);
-    for (int o = 0; o < C; ++o) {
-        const float s = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
-        scale[o] = s;
-        bias[o] = b.f[o] - m.f[o] * s;
-    }
+    std::vector<float> scale, bias;
+    bn_fold(ctx, model, bn, C, scale, bias, stem);
     return make_conv(dt, up, w, &scale, &bias);
 }
 
@@ -291,8 +285,9 @@ static NormW make_norm(hcm_ctx* ctx, Uploader& up, int model, const std::string&
 
 // Linear weight [N][K] (rows optionally concatenated from several tensors), K zero-padded to a multiple of 32.
 // `perm` maps new column j -> source column perm[j] (-1: a zero column); its size is the new K.
+// `col_scale` multiplies the first `scale_cols` (new) columns: the RGB trunk-feature columns of the projections behind a range-folded trunk.
 static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs,
-                        int dt, const std::vector<int>* perm = nullptr) {
+                        int dt, const std::vector<int>* perm = nullptr, int scale_cols = 0, float col_scale = 1.f) {
     LinW l;
     const int Ksrc = (int)ws[0]->shape[1];
     l.K = perm ? (int)perm->size() : Ksrc;                   // a perm may also widen the row: entries of -1 are zero columns
@@ -308,7 +303,7 @@ static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, 
         for (int i = 0; i < n; ++i, ++row)
             for (int j = 0; j < l.K; ++j) {
                 const int src = perm ? (*perm)[j] : j;
-                if (src >= 0) r[(size_t)row * l.Kp + j] = w->f[(size_t)i * Ksrc + src];
+                if (src >= 0) r[(size_t)row * l.Kp + j] = w->f[(size_t)i * Ksrc + src] * (j < scale_cols ? col_scale : 1.f);
             }
     }
     l.w = up.typed(r, dt);
@@ -324,18 +319,14 @@ static LinW make_linear(Uploader& up, const std::vector<const HostTensor*>& ws, 
 // slots 21..23 of every run are zero; K = 7*24 = 168, rows padded to 192.  BN folded as usual.
 static ConvW make_stem_rowrun(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
     const HostTensor& w = T_(ctx, model, wkey);
-    const HostTensor& g = T_(ctx, model, bn + ".weight");
-    const HostTensor& b = T_(ctx, model, bn + ".bias");
-    const HostTensor& m = T_(ctx, model, bn + ".running_mean");
-    const HostTensor& v = T_(ctx, model, bn + ".running_var");
     ConvW c;
     c.dt = dt;
     c.Cout = (int)w.shape[0]; c.Cin = 3; c.KH = 7; c.KW = 7;
     c.K = 7 * 24; c.Kp = 192;
-    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f), bias(c.Cout);
+    std::vector<float> r((size_t)c.Cout * c.Kp, 0.f), scale, bias;
+    bn_fold(ctx, model, bn, c.Cout, scale, bias, true);
     for (int o = 0; o < c.Cout; ++o) {
-        const float sc = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
-        bias[o] = b.f[o] - m.f[o] * sc;
+        const float sc = scale[o];
         for (int ci = 0; ci < 3; ++ci)
             for (int kh = 0; kh < 7; ++kh)
                 for (int kw = 0; kw < 7; ++kw)
@@ -346,7 +337,6 @@ static ConvW make_stem_rowrun(hcm_ctx* ctx, int dt, Uploader& up, int model, con
     return c;
 }
 
-static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias);
 // 7x7x3 stem weights for the packed-frame path (kernels.h: launch_pack_frame): k = kh*32 + kw*4 + ci; slots with
 // ci = 3 or kw = 7 are zero; K = Kp = 224.  BN folded as usual.
 static ConvW make_stem_packed(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn) {
@@ -356,7 +346,7 @@ static ConvW make_stem_packed(hcm_ctx* ctx, int dt, Uploader& up, int model, con
     c.Cout = (int)w.shape[0]; c.Cin = 3; c.KH = 7; c.KW = 7;
     c.K = 224; c.Kp = 224;
     std::vector<float> scale, bias;
-    bn_fold(ctx, model, bn, c.Cout, scale, bias);
+    bn_fold(ctx, model, bn, c.Cout, scale, bias, true);
     std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
     for (int o = 0; o < c.Cout; ++o)
         for (int ci = 0; ci < 3; ++ci)
@@ -374,7 +364,7 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     const int dt = ctx->dt_rgb;
     t.gn = false;
     t.cin1 = 3;
-    t.conv1 = make_conv_bn(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
+    t.conv1 = make_conv_bn(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1", true);
     t.conv1_rowrun = make_stem_rowrun(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     if (dt != DT_F32) t.conv1_packed = make_stem_packed(ctx, dt, up, model, pre + "conv1.weight", pre + "bn1");
     for (int li = 0; li < 4; ++li)
@@ -395,20 +385,24 @@ static TrunkW make_tv_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
 
 // 7x7 stem of the 1-channel depth trunk for the packed-frame path: k = kh*8 + kw (slot kw = 7 is zero), K = 56, Kp = 64;
 // the rows of several models are concatenated along Cout (hi|lo pair: shared frame)
-static ConvW make_depth_stem_packed(int dt, Uploader& up, const std::vector<const HostTensor*>& ws) {
+static ConvW make_depth_stem_packed(int dt, Uploader& up, const std::vector<const HostTensor*>& ws, float fold = 1.f) {
     ConvW c;
     c.dt = dt;
+    c.fold = fold; c.calib_pos = 0;
     const int Co = (int)ws[0]->shape[0];
     c.Cout = Co * (int)ws.size(); c.Cin = 1; c.KH = 7; c.KW = 7; c.K = 56; c.Kp = 64;
     std::vector<float> r((size_t)c.Cout * c.Kp, 0.f);
     for (size_t g = 0; g < ws.size(); ++g)
         for (int o = 0; o < Co; ++o)
             for (int kh = 0; kh < 7; ++kh)
-                for (int kw = 0; kw < 7; ++kw) r[((size_t)g * Co + o) * c.Kp + kh * 8 + kw] = ws[g]->f[((size_t)o * 7 + kh) * 7 + kw];
+                for (int kw = 0; kw < 7; ++kw) r[((size_t)g * Co + o) * c.Kp + kh * 8 + kw] = ws[g]->f[((size_t)o * 7 + kh) * 7 + kw] * fold;
     c.w = up.typed(r, dt);
     return c;
 }
 
+// fp16 range folding of the GroupNorm trunks: position of a conv in the trunk topology -> hcm_ctx::depth_fold (model.h)
+static int gn_pos(int block, int which) { return 1 + 4 * block + which; }      // which: 0 c1, 1 c2, 2 c3, 3 down-sample
+static float gn_fold(hcm_ctx* ctx, int pos) { return ctx->dt_depth == DT_F16 ? ctx->depth_fold[pos] : 1.f; }
 static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::string& pre) {
     TrunkW t;
     const int dt = ctx->dt_depth;
@@ -416,26 +410,28 @@ static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
     t.groups = ctx->cfg.depth_baseplanes / 2;          // resnet_encoders.py:30
     t.cin1 = 1;
     const std::string bb = pre + "backbone.";
-    t.conv1 = make_conv(dt, up, T_(ctx, model, bb + "conv1.0.weight"), nullptr, nullptr);
-    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, model, bb + "conv1.0.weight")});
+    auto W1 = [&](const std::string& k, int pos, int pad = 0) { return make_conv(dt, up, T_(ctx, model, k), nullptr, nullptr, pad, gn_fold(ctx, pos), pos); };
+    t.conv1 = W1(bb + "conv1.0.weight", 0);
+    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, model, bb + "conv1.0.weight")}, gn_fold(ctx, 0));
     t.n_conv1 = make_norm(ctx, up, model, bb + "conv1.1");
+    int blk = 0;
     for (int li = 0; li < 4; ++li)
-        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi, ++blk) {
             const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
             BottleneckW b;
             b.stride = (li > 0 && bi == 0) ? 2 : 1;
-            b.c1 = make_conv(dt, up, T_(ctx, model, p + "convs.0.weight"), nullptr, nullptr); b.n1 = make_norm(ctx, up, model, p + "convs.1");
-            b.c2 = make_conv(dt, up, T_(ctx, model, p + "convs.3.weight"), nullptr, nullptr); b.n2 = make_norm(ctx, up, model, p + "convs.4");
-            b.c3 = make_conv(dt, up, T_(ctx, model, p + "convs.6.weight"), nullptr, nullptr); b.n3 = make_norm(ctx, up, model, p + "convs.7");
+            b.c1 = W1(p + "convs.0.weight", gn_pos(blk, 0)); b.n1 = make_norm(ctx, up, model, p + "convs.1");
+            b.c2 = W1(p + "convs.3.weight", gn_pos(blk, 1)); b.n2 = make_norm(ctx, up, model, p + "convs.4");
+            b.c3 = W1(p + "convs.6.weight", gn_pos(blk, 2)); b.n3 = make_norm(ctx, up, model, p + "convs.7");
             if (bi == 0) {
                 b.has_ds = true;
-                b.ds = make_conv(dt, up, T_(ctx, model, p + "downsample.0.weight"), nullptr, nullptr);
+                b.ds = W1(p + "downsample.0.weight", gn_pos(blk, 3));
                 b.nds = make_norm(ctx, up, model, p + "downsample.1");
             }
             t.blocks.push_back(b);
         }
     const int cc = depth_compress_channels(ctx->cfg), ccp = depth_compress_padded(ctx->cfg);
-    t.compress = make_conv(dt, up, T_(ctx, model, pre + "compression.0.weight"), nullptr, nullptr, ccp);
+    t.compress = W1(pre + "compression.0.weight", hcm_ctx::kDepthPos - 1, ccp);
     t.n_compress = make_norm(ctx, up, model, pre + "compression.1", ccp);
     t.compress_true = ccp != cc ? cc : 0;
     t.out_c = t.compress.Cout;
@@ -443,9 +439,10 @@ static TrunkW make_gn_trunk(hcm_ctx* ctx, Uploader& up, int model, const std::st
 }
 
 // ---- hi|lo pair of the GroupNorm depth trunk (see HighW::depth_pair)
-static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const HostTensor& b, bool concat_n, int cout_pad = 0) {
+static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const HostTensor& b, bool concat_n, int cout_pad = 0, float fold = 1.f, int pos = -1) {
     ConvW c;
     c.dt = dt;
+    c.fold = fold; c.calib_pos = pos;
     c.Cout = (int)a.shape[0]; c.Cin = (int)a.shape[1]; c.KH = (int)a.shape[2]; c.KW = (int)a.shape[3];
     c.K = c.KH * c.KW * c.Cin;
     c.Kp = round_up(c.K, 32);
@@ -459,7 +456,7 @@ static ConvW make_conv_pair(int dt, Uploader& up, const HostTensor& a, const Hos
                 for (int kh = 0; kh < c.KH; ++kh)
                     for (int kw = 0; kw < c.KW; ++kw)
                         r[((size_t)g * c.Cout + o) * c.Kp + (size_t)(kh * c.KW + kw) * c.Cin + i] =
-                            ws[g]->f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw];
+                            ws[g]->f[(((size_t)o * c.Cin + i) * c.KH + kh) * c.KW + kw] * fold;
     c.w = up.typed(r, dt);
     if (concat_n) c.Cout *= 2;          // shared input (stem): one ordinary conv with the output channels concatenated
     else c.groups = 2;
@@ -484,28 +481,32 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
     t.pair = true;
     t.groups = ctx->cfg.depth_baseplanes / 2;
     t.cin1 = 1;
-    auto W2 = [&](const std::string& k, bool cat, int pad = 0) { return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat, pad); };
+    // (a position's fold is shared by the hi, the lo and the pair trunk: its range slot sees whichever of them runs)
+    auto W2 = [&](const std::string& k, bool cat, int pos, int pad = 0) {
+        return make_conv_pair(dt, up, T_(ctx, HCM_HIGH, k), T_(ctx, HCM_LOW, k), cat, pad, gn_fold(ctx, pos), pos);
+    };
     const std::string bb = pre + "backbone.";
-    t.conv1 = W2(bb + "conv1.0.weight", true);
-    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, HCM_HIGH, bb + "conv1.0.weight"), &T_(ctx, HCM_LOW, bb + "conv1.0.weight")});
+    t.conv1 = W2(bb + "conv1.0.weight", true, 0);
+    if (dt != DT_F32) t.conv1_packed = make_depth_stem_packed(dt, up, {&T_(ctx, HCM_HIGH, bb + "conv1.0.weight"), &T_(ctx, HCM_LOW, bb + "conv1.0.weight")}, gn_fold(ctx, 0));
     t.n_conv1 = make_norm_pair(ctx, up, bb + "conv1.1");
+    int blk = 0;
     for (int li = 0; li < 4; ++li)
-        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi) {
+        for (int bi = 0; bi < RESNET50_BLOCKS[li]; ++bi, ++blk) {
             const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
             BottleneckW b;
             b.stride = (li > 0 && bi == 0) ? 2 : 1;
-            b.c1 = W2(p + "convs.0.weight", false); b.n1 = make_norm_pair(ctx, up, p + "convs.1");
-            b.c2 = W2(p + "convs.3.weight", false); b.n2 = make_norm_pair(ctx, up, p + "convs.4");
-            b.c3 = W2(p + "convs.6.weight", false); b.n3 = make_norm_pair(ctx, up, p + "convs.7");
+            b.c1 = W2(p + "convs.0.weight", false, gn_pos(blk, 0)); b.n1 = make_norm_pair(ctx, up, p + "convs.1");
+            b.c2 = W2(p + "convs.3.weight", false, gn_pos(blk, 1)); b.n2 = make_norm_pair(ctx, up, p + "convs.4");
+            b.c3 = W2(p + "convs.6.weight", false, gn_pos(blk, 2)); b.n3 = make_norm_pair(ctx, up, p + "convs.7");
             if (bi == 0) {
                 b.has_ds = true;
-                b.ds = W2(p + "downsample.0.weight", false);
+                b.ds = W2(p + "downsample.0.weight", false, gn_pos(blk, 3));
                 b.nds = make_norm_pair(ctx, up, p + "downsample.1");
             }
             t.blocks.push_back(b);
         }
     const int cc = depth_compress_channels(ctx->cfg), ccp = depth_compress_padded(ctx->cfg);
-    t.compress = W2(pre + "compression.0.weight", false, ccp);
+    t.compress = W2(pre + "compression.0.weight", false, hcm_ctx::kDepthPos - 1, ccp);
     t.n_compress = make_norm_pair(ctx, up, pre + "compression.1", ccp);
     t.compress_true = ccp != cc ? cc : 0;
     t.out_c = t.compress.Cout;      // per model
@@ -513,16 +514,20 @@ static TrunkW make_gn_trunk_pair(hcm_ctx* ctx, Uploader& up, const std::string& 
 }
 
 // ---- hi|lo pair of the torchvision (BatchNorm-folded) RGB trunk: grouped convs with per-model folded scale/bias
-static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias) {
+// eval-mode BatchNorm2d of the RGB trunk folded into the preceding bias-free conv: y = conv(x) * scale + bias.  fp16 range folding
+// (hcm_ctx::rgb_fold = s, a power of two, 1 unless a calibration asked for it): every activation of the trunk carries the factor s -- the stem
+// multiplies its weights by s (its input, the frame, is unscaled), every later conv sees inputs that already carry s and only scales its bias.
+static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias, bool stem) {
     const HostTensor& g = T_(ctx, model, bn + ".weight");
     const HostTensor& b = T_(ctx, model, bn + ".bias");
     const HostTensor& m = T_(ctx, model, bn + ".running_mean");
     const HostTensor& v = T_(ctx, model, bn + ".running_var");
+    const float f = ctx->dt_rgb == DT_F16 ? ctx->rgb_fold : 1.f;
     scale.resize(C); bias.resize(C);
     for (int o = 0; o < C; ++o) {
         const float s = g.f[o] / std::sqrt(v.f[o] + 1e-5f);
-        scale[o] = s;
-        bias[o] = b.f[o] - m.f[o] * s;
+        scale[o] = stem ? s * f : s;
+        bias[o] = (b.f[o] - m.f[o] * s) * f;
     }
 }
 // Expansion conv3 and the block's 1x1 down-sample conv (both BN-folded) K-concatenated for the fused bottleneck launch that folds the
@@ -590,7 +595,7 @@ static void make_stem_pair(hcm_ctx* ctx, int dt, Uploader& up, const std::string
     std::vector<float> rp((size_t)2 * Co * plain.Kp, 0.f), rr((size_t)2 * Co * rowrun.Kp, 0.f), rk((size_t)2 * Co * packed.Kp, 0.f), bias_all;
     for (int g = 0; g < 2; ++g) {
         std::vector<float> scale, bias;
-        bn_fold(ctx, g == 0 ? HCM_HIGH : HCM_LOW, bn, Co, scale, bias);
+        bn_fold(ctx, g == 0 ? HCM_HIGH : HCM_LOW, bn, Co, scale, bias, true);
         bias_all.insert(bias_all.end(), bias.begin(), bias.end());
         for (int o = 0; o < Co; ++o)
             for (int ci = 0; ci < 3; ++ci)
@@ -737,13 +742,15 @@ void prepare_high(hcm_ctx* ctx) {
         h.bert.layers.push_back(L);
     }
     // Conv1d(k=1) weights (out,in,1) are linear layers over the token axis
-    h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
+    // (behind a range-folded RGB trunk the 2048 feature columns of a token row carry rgb_fold, the 64 position channels do not)
+    const float rgb_unfold = ctx->dt_rgb == DT_F16 ? 1.f / ctx->rgb_fold : 1.f;
+    h.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla, nullptr, 2048, rgb_unfold);
     {
         std::vector<int> perm((size_t)h.depth_C);
         for (int n = 0; n < h.depth_C; ++n) perm[n] = depth_tok_src(n, cc, ccp);
         h.depth_kv = make_linear(up, {&T_(ctx, M, "depth_kv.weight")}, {&T_(ctx, M, "depth_kv.bias")}, ctx->dt_vla, &perm);
     }
-    h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
+    h.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla, nullptr, 2048, rgb_unfold);
     {
         // depth_linear: Flatten of (B, dC, S) -> column c*S + s; ours [B][S][dC] -> s*dC + c
         const int S = h.depth_S, dC = h.depth_C;
@@ -833,7 +840,8 @@ void prepare_low(hcm_ctx* ctx) {
     }
     if (!l.rgb_simple) {
         l.rgb = make_tv_trunk(ctx, up, M, "rgb_encoder.cnn.");
-        l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt_rgb);
+        l.rgb_fc = make_linear(up, {&T_(ctx, M, "rgb_encoder.fc.weight")}, {&T_(ctx, M, "rgb_encoder.fc.bias")}, ctx->dt_rgb, nullptr, 2048,
+                               ctx->dt_rgb == DT_F16 ? 1.f / ctx->rgb_fold : 1.f);
     } else {
         l.rgb_s = make_simple_cnn(ctx, ctx->dt_rgb, up, M, "rgb_encoder.", 3, c.rgb_h, c.rgb_w);
     }
@@ -886,7 +894,8 @@ void prepare_cma(hcm_ctx* ctx) {
             w.hh_t[d] = up.f32(t);
         }
     }
-    w.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla);
+    const float rgb_unfold = ctx->dt_rgb == DT_F16 ? 1.f / ctx->rgb_fold : 1.f;
+    w.rgb_linear = make_linear(up, {&T_(ctx, M, "rgb_linear.2.weight")}, {&T_(ctx, M, "rgb_linear.2.bias")}, ctx->dt_vla, nullptr, 2048, rgb_unfold);
     {
         const int S = w.depth_S, dC = w.depth_C;          // Flatten of (B, dC, S): column c*S + s; ours [B][S][dC]
         std::vector<int> perm((size_t)S * dC);
@@ -897,7 +906,7 @@ void prepare_cma(hcm_ctx* ctx) {
             }
         w.depth_linear = make_linear(up, {&T_(ctx, M, "depth_linear.1.weight")}, {&T_(ctx, M, "depth_linear.1.bias")}, ctx->dt_vla, &perm);
     }
-    w.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla);
+    w.rgb_kv = make_linear(up, {&T_(ctx, M, "rgb_kv.weight")}, {&T_(ctx, M, "rgb_kv.bias")}, ctx->dt_vla, nullptr, 2048, rgb_unfold);
     {
         std::vector<int> perm((size_t)w.depth_C);
         for (int n = 0; n < w.depth_C; ++n) perm[n] = depth_tok_src(n, cc, ccp);

@@ -33,7 +33,9 @@ def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_
         s.reserved[_SUB_SLOTS[name]] = _SUB_DT[p] + 1
     s.reserved[4] = int(bool(keep_host_weights))
     s.struct_size = C.sizeof(_lib.HcmConfigStruct)
-    s.precision = {"bf16": _lib.HCM_BF16, "fp32": _lib.HCM_F32}[precision]
+    if precision not in _lib.PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+    s.precision = _lib.PRECISIONS[precision]
     s.max_batch = max_batch
     s.rgb_h, s.rgb_w = cfg.rgb_shape
     s.depth_h, s.depth_w = cfg.depth_shape
@@ -68,10 +70,17 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="bf16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False):
-        """precision: "bf16" (16-bit storage + MFMA with fp32 accumulate; by default the GroupNorm depth trunk uses
-        fp16 tiles and everything else bf16, recurrent cells/heads fp32) or "fp32".  `sub_precision` overrides the
-        storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
+                 precision="fp16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False, guard_every=64):
+        """precision (fp32 accumulation, fp32 recurrent cells / heads in every mode):
+          "fp16"  fp16 storage + fp16 MFMA tiles in every sub-network, behind the range calibration of hcm_finalize (the measured 16-bit mode:
+                  record error 2.6e-3 at B = 64).  A trunk that leaves the fp16 range gets an exact power-of-two range fold (`range_fold`),
+                  BERT / the cross-modal block fall back to bf16 tiles (`fp16_fallback`);
+          "bf16"  bf16 storage + bf16 MFMA tiles in BERT, the RGB trunks and the cross-modal block; the GroupNorm depth trunks stay on
+                  range-folded fp16 tiles (on bf16 that trunk alone costs 1.9e-2 of the 1e-2 record tolerance);
+          "fp32"  fp32 storage + fp32 MFMA.
+        `sub_precision` overrides the storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
+        guard_every: act() polls the run-time overflow guard every this many steps without synchronising (hcm_guard_poll) and raises
+        FloatingPointError once a recurrent cell has seen non-finite gate pre-activations; 0 disables.
         graph=True: act() runs on an engine-owned stream with engine-owned static I/O buffers, so that libhcm replays
         one captured hipGraph per step; the returned record / hidden tensors then alias those buffers and stay valid
         until the second-next act() call (ping-pong), which is what a rollout loop that rebinds them every step needs.
@@ -79,10 +88,14 @@ class HCMEngine:
         (B or 1, L <= max_instr_len) ids, as the reference model does (its eval loop feeds the unpadded tokens of the episode's
         instruction, common/utils.py:18-20).  Default: cfg.instr_len.  BERT's position table allows up to 512."""
         self.max_instr_len = int(max_instr_len or cfg.instr_len)
-        # fp16 range safety: hcm_finalize checks the fp16 sub-networks (BERT, depth trunks) on a synthetic batch and re-builds on bf16
-        # tiles what would overflow (`fp16_fallback`); keep_host_weights=True keeps the f32 host copies so that `calibrate(observations)`
-        # can repeat the check -- and the re-build -- on real observations
+        # fp16 range safety: hcm_finalize checks the fp16 sub-networks on a synthetic batch and repairs what would overflow (`range_fold`,
+        # `fp16_fallback`); keep_host_weights=True keeps the f32 host copies so that `calibrate(observations)` can repeat the check -- and
+        # the repair -- on real observations
         self._graph = bool(graph)
+        self.comm_world, self.comm_rank = 0, 0          # > 0 once comm_init() has created the RCCL communicator
+        self._guard_every = int(guard_every)
+        self._guard_tick = 0
+        self._guard_seen = 0
         self._gstream = None
         self._static = None
         cfg.validate()
@@ -117,8 +130,24 @@ class HCMEngine:
 
     def query(self, what):
         out = C.c_int64()
-        _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
+        with torch.cuda.device(self.device):       # (HCM_STEP_NONFINITE waits for the handle's device)
+            _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
         return out.value
+
+    def _guard_poll(self, stream):
+        """Every `guard_every` act() calls: non-blocking read of the overflow guard (the value is the one an EARLIER poll enqueued)."""
+        if self._guard_every <= 0:
+            return
+        self._guard_tick += 1
+        if self._guard_tick % self._guard_every:
+            return
+        out = C.c_int64()
+        _lib.check(self._lib.hcm_guard_poll(self._h, stream, C.byref(out)), self._h)
+        if out.value > self._guard_seen:
+            new, self._guard_seen = out.value - self._guard_seen, out.value
+            raise FloatingPointError(f"overflow guard: {new} (environment, recurrent step) pairs had non-finite activations in front of a recurrent "
+                                     "cell since the last check -- broken sensor frames, or a sub-network outside its fp16 range "
+                                     "(engine.calibrate(observations) on real observations; engine.calibration_report())")
 
     @property
     def num_recurrent_layers(self):
@@ -130,10 +159,17 @@ class HCMEngine:
         bits = self.query(_lib.HCM_FP16_FALLBACK)
         return {n for b, n in ((1, "bert"), (2, "depth"), (4, "rgb"), (8, "vla")) if bits & b}
 
+    @property
+    def range_fold(self):
+        """Trunks the range calibration kept on fp16 by folding a power of two into their weights (exact): subset of {"depth", "rgb"}."""
+        bits = self.query(_lib.HCM_RANGE_FOLD)
+        return {n for b, n in ((2, "depth"), (4, "rgb")) if bits & b}
+
     def calibration_report(self):
         return {"bert_max_abs": self.query(_lib.HCM_CALIB_MAX_BERT), "depth_max_abs": self.query(_lib.HCM_CALIB_MAX_DEPTH),
                 "rgb_max_abs": self.query(_lib.HCM_CALIB_MAX_RGB), "vla_max_abs": self.query(_lib.HCM_CALIB_MAX_VLA),
-                "non_finite": self.query(_lib.HCM_CALIB_NONFINITE), "fp16_fallback": sorted(self.fp16_fallback)}
+                "non_finite": self.query(_lib.HCM_CALIB_NONFINITE), "fp16_fallback": sorted(self.fp16_fallback),
+                "range_fold": sorted(self.range_fold)}
 
     def nonfinite_steps(self):
         """Overflow guard (hcm_query(HCM_STEP_NONFINITE)): number of (sample, recurrent step) pairs since construction whose gate
@@ -141,6 +177,27 @@ class HCMEngine:
         squashing cell would otherwise turn it into finite garbage.  0 on a healthy engine.  Synchronises the device: call it per episode
         or per evaluation, not per step."""
         return self.query(_lib.HCM_STEP_NONFINITE)
+
+    def comm_init(self, group=None):
+        """Create the library's own RCCL communicator over the ranks of a torch.distributed process group (one process per GPU): rank 0 draws the
+        ncclUniqueId (hcm_comm_unique_id), the existing group broadcasts its 128 bytes, every rank calls hcm_comm_init.  Afterwards
+        act(..., gather=True) returns the all-gathered (world * B, 7) record of the whole rollout batch, the collective being enqueued by the
+        library behind the step on the step's stream (hcm_act_gather) -- no torch.distributed call per step."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(self._lib.hcm_comm_unique_id(ident))
+        t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+        on_dev = dist.get_backend(group) == "nccl"
+        if on_dev:
+            t = t.to(self.device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(t.cpu().numpy().tobytes())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hcm_comm_init(self._h, C.c_char_p(raw), rank, world), self._h)
+        self.comm_world, self.comm_rank = world, rank
+        return world
 
     def calibrate(self, observations, release_host_weights=True):
         """Range-check the fp16 sub-networks on these observations (hcm_calibrate); returns calibration_report().  Needs
@@ -248,7 +305,7 @@ class HCMEngine:
                                                  stop.data_ptr(), h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
-    def _act_graph(self, observations, hi_hidden, lo_hidden, masks, flags=0):
+    def _act_graph(self, observations, hi_hidden, lo_hidden, masks, flags=0, gather=False):
         host_frames = bool(flags & _lib.HCM_ACT_HOST_FRAMES)
         with torch.cuda.device(self.device):
             rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
@@ -293,13 +350,23 @@ class HCMEngine:
                                  (st["hh"][1 - i], hh), (st["lh"][1 - i], lh)):
                     if dst is not None and dst.data_ptr() != src.data_ptr():
                         dst.copy_(src, non_blocking=True)
-                _lib.check(self._lib.hcm_act_ex(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
-                                                g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
-                                                st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
-                                                st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
+                if gather:
+                    if "gat" not in st:
+                        st["gat"] = [torch.empty(self.comm_world * B, 7, device=self.device) for _ in range(2)]
+                    _lib.check(self._lib.hcm_act_gather(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
+                                                        g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
+                                                        st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
+                                                        st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, st["gat"][i].data_ptr(),
+                                                        C.c_void_p(gs.cuda_stream)), self._h)
+                else:
+                    _lib.check(self._lib.hcm_act_ex(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
+                                                    g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
+                                                    st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
+                                                    st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
                 st["tick"] += 1
+                self._guard_poll(C.c_void_p(gs.cuda_stream))
             cur.wait_stream(gs)
-        return st["rec"][i], st["hh"][i], st["lh"][i]
+        return (st["gat"][i] if gather else st["rec"][i]), st["hh"][i], st["lh"][i]
 
     # ---- training / validation path: T*N frames per call, RNNStateEncoder.seq_forward (state_encoder.py:83-133)
     def high_forward_seq(self, observations, hidden, masks):
@@ -334,16 +401,20 @@ class HCMEngine:
                                                      h_out.data_ptr(), self._stream()), self._h)
         return vel, stop, h_out
 
-    def act(self, observations, hi_hidden, lo_hidden, masks, out=None, reuse_instruction=False, host_frames=False):
+    def act(self, observations, hi_hidden, lo_hidden, masks, out=None, reuse_instruction=False, host_frames=False, gather=False):
         """reuse_instruction=True: the caller asserts that every environment's instruction is the one of the previous act() call
         (no episode ended): BERT and the instruction stream of the cross-modal block are not recomputed (hcm_act_ex).  Off in
         every parity test and in bench.py's headline number.
         host_frames=True: observations["rgb"] / ["depth"] are PINNED CPU tensors (an ObsStager's host side) and stay there: the
         library copies each to the device at the head of the encoder chain that reads it (HCM_ACT_HOST_FRAMES), overlapping the copies
-        with BERT and with each other's compute; bit-identical to copying first."""
+        with BERT and with each other's compute; bit-identical to copying first.
+        gather=True (after comm_init()): the returned record is the all-gathered (world * B, 7) record of every rank's environments, rank-major
+        (hcm_act_gather: one ncclAllGather enqueued by the library behind the step)."""
+        if gather and not self.comm_world:
+            raise RuntimeError("act(gather=True) needs comm_init() first")
         flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
         if self._graph:
-            rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks, flags)
+            rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks, flags, gather)
             if out is not None:
                 out.copy_(rec)
                 rec = out
@@ -351,11 +422,19 @@ class HCMEngine:
         with torch.cuda.device(self.device):
             rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
-            rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
             hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)
-            _lib.check(self._lib.hcm_act_ex(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
-                                            _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
-                                            rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
+            if gather:
+                local = torch.empty(B, 7, device=self.device, dtype=torch.float32)
+                rec = out if out is not None else torch.empty(self.comm_world * B, 7, device=self.device, dtype=torch.float32)
+                _lib.check(self._lib.hcm_act_gather(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
+                                                    _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
+                                                    local.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, rec.data_ptr(), self._stream()), self._h)
+            else:
+                rec = out if out is not None else torch.empty(B, 7, device=self.device, dtype=torch.float32)
+                _lib.check(self._lib.hcm_act_ex(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
+                                                _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
+                                                rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
+            self._guard_poll(self._stream())
         return rec, hh2, lh2
 
     def refresh_instruction(self, instruction, env_indices, instruction_lengths=None):
@@ -458,9 +537,10 @@ class Policy:
         self.high_level = Seq2Seq_HighLevel_CMA(engine)
         self.low_level = Seq2Seq_LowLevel(engine)
 
-    def act(self, observations, hi_hidden, lo_hidden, prev_actions, masks, deterministic=True, reuse_instruction=False, host_frames=False):
-        """-> (record (B,7) = [4 sub-task logits, lin_vel, ang_vel, stop logit], hi_hidden', lo_hidden')."""
-        return self.engine.act(observations, hi_hidden, lo_hidden, masks, reuse_instruction=reuse_instruction, host_frames=host_frames)
+    def act(self, observations, hi_hidden, lo_hidden, prev_actions, masks, deterministic=True, reuse_instruction=False, host_frames=False, gather=False):
+        """-> (record (B,7) = [4 sub-task logits, lin_vel, ang_vel, stop logit], hi_hidden', lo_hidden'); gather=True (env-sharded ranks, after
+        engine.comm_init()): the record of ALL ranks' environments, (world * B, 7)."""
+        return self.engine.act(observations, hi_hidden, lo_hidden, masks, reuse_instruction=reuse_instruction, host_frames=host_frames, gather=gather)
 
     def get_value(self, *a, **k):
         """Imitation-learned agent: the reference has no critic / value head anywhere."""

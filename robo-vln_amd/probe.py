@@ -34,7 +34,7 @@ def sinusoid_table(L, d):
 class DepthCnnVlaProbe:
     """cnn_sd: SimpleDepthCNN state_dict (keys cnn.{0,2,4,7}.{weight,bias}); vla_sd: Visual_Ling_Attn state_dict (N = 1)."""
 
-    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="bf16", device="cuda", graph=False, fused_layer=True, overlap=True):
+    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="fp16", device="cuda", graph=False, fused_layer=True, overlap=True):
         """graph=True: forward() is captured once per batch size into a hipGraph (torch.cuda.CUDAGraph over the library's launches on
         the capture stream) with engine-owned static input / output buffers, and replayed: the ~16 dependent launches then cost one."""
         self._graph = bool(graph)

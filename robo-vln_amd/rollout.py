@@ -3,7 +3,8 @@
 :1103 masks to ones, :1143-1159 reset on episode end) for a batch of environments, and the
 environment-sharded data-parallel variant (SURVEY.md 8e): env e lives on rank e // (B/world), each rank
 holds a full weight replica and its own recurrent state, and the only data-path collective is ONE
-all-gather of the (B/world, 7) action records per step (RCCL over xGMI on GPU; gloo in the CPU tests).
+all-gather of the (B/world, 7) action records per step (RCCL over xGMI on GPU -- enqueued by libhcm itself behind the step once
+`engine.comm_init()` has created its communicator, through torch.distributed otherwise; gloo in the CPU tests).
 """
 import torch
 import torch.distributed as dist
@@ -64,6 +65,9 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
     guard = getattr(getattr(policy, "engine", None), "nonfinite_steps", None)
     bad_before = guard() if guard is not None else 0          # the counter is cumulative: this rollout answers for its own steps
     prev_done = None
+    # the library's own collective (hcm_act_gather, after engine.comm_init()) when there is one; torch.distributed otherwise (gloo CPU tests,
+    # engines without a communicator)
+    lib_gather = world > 1 and getattr(getattr(policy, "engine", None), "comm_world", 0) == world
     for t in range(steps):
         obs = obs_fn(t, lo, hi)
         reuse = cache_instruction and t > 0
@@ -73,9 +77,12 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
                 policy.engine.refresh_instruction(obs["instruction"], idx, obs["instruction_lengths"])
             else:
                 policy.engine.refresh_instruction(obs["instruction"], idx)
-        rec, hh, lh = (policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, reuse_instruction=True) if reuse
-                       else policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks))
-        if world > 1:
+        kw = {"gather": True} if lib_gather else {}
+        rec, hh, lh = (policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, reuse_instruction=True, **kw) if reuse
+                       else policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, **kw))
+        if lib_gather:
+            full = rec
+        elif world > 1:
             full = torch.empty(global_envs, RECORD_WIDTH, device=rec.device, dtype=rec.dtype)
             gather_records(rec, full)
         else:

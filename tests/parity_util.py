@@ -23,11 +23,13 @@ def _cmp(a, b):
     return float(d.max()), float(d.mean()), float(np.abs(b).max()), rel
 
 
-def run_case(name, precision, taps=True, rgb_uint8=False, sub_precision=None, batch=None):
+def run_case(name, precision, taps=True, rgb_uint8=False, sub_precision=None, batch=None, steps=None):
     """Returns dict: per-step record errors vs oracle and vs the committed golden, per-tap errors (step 0)."""
     cfg, B, T, which = cases.case_config(name)
     if batch is not None:
         B = batch
+    if steps is not None:
+        T = steps
     eng, hi_sd, lo_sd = build_engine(cfg, which, precision, B, sub_precision)
     hi_o = hcm_oracle.HighLevelOracle(cfg, hi_sd) if hi_sd is not None else None
     lo_o = hcm_oracle.LowLevelOracle(cfg, lo_sd) if lo_sd is not None else None

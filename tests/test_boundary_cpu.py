@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def _create(cfg, **over):
     l = _lib.lib()
-    st = _to_struct(cfg, 4, "bf16", True, True)
+    st = _to_struct(cfg, 4, "fp16", True, True)
     for k, v in over.items():
         setattr(st, k, v)
     h = C.c_void_p()

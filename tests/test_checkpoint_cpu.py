@@ -38,7 +38,7 @@ def test_checkpoint_roundtrip_and_strict_load():
     assert conf2["MODEL"]["STATE_ENCODER"]["rnn_type"] == "LSTM"
     # every tensor of the loaded dicts is accepted by the library's strict loader
     l = _lib.lib()
-    st = _to_struct(cfg, 2, "bf16", True, True)
+    st = _to_struct(cfg, 2, "fp16", True, True)
     h = C.c_void_p()
     assert l.hcm_create(C.byref(st), C.byref(h)) == 0
     try:
@@ -68,7 +68,7 @@ GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "gold
 
 def _strict_load(cfg, hi_sd, lo_sd):
     l = _lib.lib()
-    st = _to_struct(cfg, 2, "bf16", True, True)
+    st = _to_struct(cfg, 2, "fp16", True, True)
     h = C.c_void_p()
     assert l.hcm_create(C.byref(st), C.byref(h)) == 0
     try:

@@ -22,7 +22,7 @@ def cfg4():
     assert cfg.instr_len == 160 and cfg.vla_layers == 6 and cfg.rgb_hw == 256
     B = 128
     hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", cases.SEED)
-    eng = HCMEngine(cfg, hi_sd, None, max_batch=B, precision="bf16")
+    eng = HCMEngine(cfg, hi_sd, None, max_batch=B, precision="fp16")
     obs_np = synth.make_observations(cfg, B, step=0, seed=7, rgb_uint8=True)
     obs = {k: torch.from_numpy(v).cuda() for k, v in obs_np.items()}
     R = cfg.num_recurrent_layers
@@ -139,7 +139,7 @@ def test_config3_encoder_low_level_model_full_size():
     cfg = HCMConfig(depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN").validate()
     B = 256
     lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", cases.SEED)
-    eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="bf16")
+    eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="fp16")
     obs_np = synth.make_observations(cfg, B, step=1, seed=9, rgb_uint8=True)
     obs = {k: torch.from_numpy(v).cuda() for k, v in obs_np.items() if k != "instruction"}
     R = cfg.num_recurrent_layers

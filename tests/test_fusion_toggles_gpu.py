@@ -26,7 +26,7 @@ cfg = HCMConfig(rgb_hw=128, depth_hw=int(os.environ.get("HCMT_DEPTH_HW", "128"))
                 vla_layers=int(os.environ.get("HCMT_VLA_LAYERS", "1")), bert_layers=1).validate()
 B = 3
 hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
-eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=False)
+eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=False)
 obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=5).items()}
 if os.environ.get("HCMT_RAGGED"):
     obs["instruction_lengths"] = torch.tensor([cfg.instr_len, 3, cfg.instr_len // 2], dtype=torch.int32).cuda()
@@ -54,9 +54,14 @@ def test_fused_rgb_trunk_launches_equal_the_separate_ones():
         plain = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK_FUSE": "1", "HCM_NO_STEM_HPOOL": "1", "HCM_NO_PRED_FUSE": "1"}, os.path.join(d, "b.npz"))
         nonext = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK_NEXT": "1"}, os.path.join(d, "c.npz"))
         default = _run({}, os.path.join(d, "e.npz"))
+        # the register-epilogue form of the fused bottleneck launch (v_permlane16_swap regrouping, the default) against its LDS-image form
+        image = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_BNECK_IMAGE": "1"}, os.path.join(d, "f.npz"))
+        image_ds = _run({"HCM_BNECK_IMAGE": "1"}, os.path.join(d, "g.npz"))
     for k in ("rec", "hh", "lh"):
         assert np.array_equal(fused[k], plain[k]), k
         assert np.array_equal(fused[k], nonext[k]), k
+        assert np.array_equal(fused[k], image[k]), k
+        assert np.array_equal(default[k], image_ds[k]), k          # ... also with the down-sample conv folded into the expansion GEMM
     assert np.isfinite(default["rec"]).all()
     # shipped configuration (down-sample conv folded into the expansion GEMM): one rounding fewer on that path
     assert np.abs(default["rec"] - plain["rec"]).max() <= 1e-2

@@ -65,7 +65,7 @@ def test_c_abi_error_codes():
     from robo_vln_amd.policy import _to_struct
     lib = _lib.lib()
     cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
-    st = _to_struct(cfg, 2, "bf16", True, True)
+    st = _to_struct(cfg, 2, "fp16", True, True)
     h = C.c_void_p()
     assert lib.hcm_create(C.byref(st), C.byref(h)) == 0
     d = torch.zeros(64, device="cuda")
@@ -79,7 +79,7 @@ def test_c_abi_error_codes():
     # a finalized engine: null pointer / bad batch / wrong handle kind
     hi_sd, lo_sd = synth.make_weights(cfg, seed=0)
     from robo_vln_amd.policy import HCMEngine
-    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=2, precision="bf16")
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=2, precision="fp16")
     hh = eng._h
     assert lib.hcm_act(hh, None, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 1, 20, p, p, p, p, p, p, None) == -1          # null rgb
     assert lib.hcm_act(hh, p, _lib.HCM_F32, p, p, _lib.HCM_I64, None, 3, 20, p, p, p, p, p, p, None) == -1             # B > max_batch
@@ -101,7 +101,7 @@ def test_rollout_with_cached_instructions_equals_recomputing():
     cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, vla_layers=1, bert_layers=2).validate()
     n, T = 6, 5
     hi_sd, lo_sd = synth.make_weights(cfg, seed=8)
-    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision="bf16")
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision="fp16")
     pol = Policy(eng)
     frames = [synth.make_observations(cfg, n, step=t, seed=8, rgb_uint8=True) for t in range(T)]
     dones = [torch.tensor([t == 1 and e in (1, 4) or t == 3 and e == 0 for e in range(n)]) for t in range(T)]
@@ -135,8 +135,8 @@ def test_host_frames_equal_device_frames(graph, rgb_uint8):
     cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
     B, T = 3, 6
     hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
-    eng_d = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
-    eng_h = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
+    eng_d = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
+    eng_h = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
     frames = [synth.make_observations(cfg, B, step=t, seed=5, rgb_uint8=rgb_uint8) for t in range(T)]
     host = {"rgb": torch.empty(B, 128, 128, 3, dtype=torch.uint8 if rgb_uint8 else torch.float32).pin_memory(),
             "depth": torch.empty(B, 128, 128, 1).pin_memory()}
@@ -171,7 +171,7 @@ def test_rollout_raises_on_poisoned_frames_and_recovers():
     cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
     B, T = 2, 3
     hi_sd, lo_sd = synth.make_weights(cfg, seed=4)
-    pol = Policy(HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16"))
+    pol = Policy(HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16"))
     frames = [{k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, step=t, seed=4).items()} for t in range(T)]
     dev = torch.device("cuda")
     never = lambda t, lo, hi: torch.zeros(hi - lo, dtype=torch.bool)
@@ -185,3 +185,45 @@ def test_rollout_raises_on_poisoned_frames_and_recovers():
     recs2 = rollout(pol, lambda t, lo, hi: frames[t], never, B, T, cfg.num_recurrent_layers, cfg.hidden, dev)
     assert torch.equal(recs, recs2)
     pol.engine.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_library_all_gather_world_one(graph):
+    """hcm_comm_unique_id / hcm_comm_init / hcm_act_gather on a world of ONE rank (the box has one GPU): the library creates its own RCCL
+    communicator from an id passed through a torch.distributed group (gloo here), and act(gather=True) -- the step plus ONE ncclAllGather
+    enqueued by the library on the step's stream -- returns the gathered record, which for one rank is the step's own record, bit for bit;
+    the raw C entry points answer a missing communicator with HCM_ERR_STATE."""
+    import torch.distributed as dist
+    from robo_vln_amd import _lib
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1).validate()
+    B = 2
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=4)
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=4).items()}
+    R = cfg.num_recurrent_layers
+    z = torch.zeros(R, B, cfg.hidden, device="cuda")
+    m = torch.zeros(B, device="cuda")
+    with pytest.raises(RuntimeError):
+        eng.act(obs, z, z, m, gather=True)                       # no communicator yet
+    lib = _lib.lib()
+    buf = torch.empty(B, 7, device="cuda")
+    rc = lib.hcm_act_gather(eng._h, obs["rgb"].data_ptr(), _lib.HCM_F32, obs["depth"].data_ptr(), obs["instruction"].data_ptr(), _lib.HCM_I64, None, B, 20,
+                            z.data_ptr(), z.data_ptr(), m.data_ptr(), buf.data_ptr(), z.clone().data_ptr(), z.clone().data_ptr(), 0, buf.data_ptr(), None)
+    assert rc == -2                                              # HCM_ERR_STATE
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29567", rank=0, world_size=1)
+    try:
+        assert eng.comm_init() == 1
+        ref = [eng.act(obs, z, z, m)[0].clone() for _ in range(3)][-1]
+        for _ in range(4):                                       # eager, capture, replay
+            got, hh, lh = eng.act(obs, z, z, m, gather=True)
+        torch.cuda.synchronize()
+        assert got.shape == (B, 7) and torch.equal(got, ref)
+        with pytest.raises(RuntimeError):
+            eng.comm_init()                                      # one communicator per handle
+    finally:
+        if created:
+            dist.destroy_process_group()
+    eng.close()

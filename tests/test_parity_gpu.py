@@ -10,15 +10,15 @@ from oracle import cases
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-# BASELINE.json north_star: outputs match the reference within 1e-3 (fp32) / 1e-2 (bf16); hidden-state rel 1e-2
-TOL = {"fp32": 1e-3, "bf16": 1e-2}
+# BASELINE.json north_star: outputs match the reference within 1e-3 (fp32) / 1e-2 (16-bit: "fp16" = the measured mode, "bf16"); hidden-state rel 1e-2
+TOL = {"fp32": 1e-3, "fp16": 1e-2, "bf16": 1e-2}
 
 
 # Intermediate tensors (step 0, whole tensors vs the oracle): relative l2 bounds.  The fp32 path only re-orders sums; the 16-bit
 # path rounds storage to 11 significant bits per layer (fp16 everywhere since the end of round 2).  Measured over all cases: fp32
 # <= 1.3e-5; 16-bit <= 9.7e-3 (worst: hi.vla_depth, fed by the depth trunk's few-channel GroupNorm groups; 1.2e-2 while the cross-modal block
 # was on bf16).
-TAP_REL = {"fp32": 1e-4, "bf16": 1.5e-2}
+TAP_REL = {"fp32": 1e-4, "fp16": 1.5e-2}
 
 
 def _check(name, precision, **kw):
@@ -34,11 +34,29 @@ def _check(name, precision, **kw):
     # hidden states: relative (l2) error <= 1e-2; an all-zero reference (model absent) compares exactly
     for key in ("hi_hidden", "lo_hidden"):
         assert rep[key][3] <= 1e-2 or rep[key][0] == 0.0, (key, rep[key])
-    # golden vectors from the imported reference (valid whenever the hi branch choice agreed with the oracle)
-    gold = np.load(os.path.join(GOLD, name + ".npz"))
-    if all(s["same_branch"] for s in rep["steps"]):
-        d = np.abs(rep["records"] - gold["records"]).max()
-        assert d <= tol, f"{name}[{precision}] vs golden: {d:.3e} > {tol}"
+    # golden vectors from the imported reference.  The four sub-task logits are compared always.  The low-level columns of an environment
+    # are compared as long as its branch (argmax of those logits) agrees with the reference's; a flip is accepted ONLY at a genuine
+    # near-tie of the reference's own logits (gap within twice the tolerance) -- and said loudly -- never silently.
+    gold = np.load(os.path.join(GOLD, name + ".npz"))["records"]
+    rec = rep["records"]
+    assert rec.shape == gold.shape, (rec.shape, gold.shape)
+    tainted = np.zeros(rec.shape[1], bool)
+    for t in range(rec.shape[0]):
+        d = np.abs(rec[t, :, :4] - gold[t, :, :4]).max()
+        assert d <= tol, f"{name}[{precision}] step {t} sub-task logits vs golden: {d:.3e} > {tol}"
+        flip = rec[t, :, :4].argmax(1) != gold[t, :, :4].argmax(1)
+        for b in np.nonzero(flip)[0]:
+            top = np.sort(gold[t, b, :4])[::-1]
+            assert top[0] - top[1] <= 2 * tol, f"{name}[{precision}] step {t} env {b}: branch differs from the reference without a near-tie (gap {top[0] - top[1]:.3e})"
+        tainted |= flip
+        ok = ~tainted
+        if ok.any():
+            d = np.abs(rec[t, ok, 4:] - gold[t, ok, 4:]).max()
+            assert d <= tol, f"{name}[{precision}] step {t} low-level outputs vs golden: {d:.3e} > {tol}"
+    if tainted.any():
+        import warnings
+        warnings.warn(f"{name}[{precision}]: environments {np.nonzero(tainted)[0].tolist()} took another sub-task branch than the reference at a logit "
+                      "near-tie; their low-level outputs were compared with the oracle (fed the same branch) only")
     return rep
 
 
@@ -52,11 +70,11 @@ def test_fp32_path_matches_oracle(name):
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_bf16_path_matches_oracle(name):
-    _check(name, "bf16")
+def test_fp16_path_matches_oracle(name):
+    _check(name, "fp16")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_unpadded_variable_length_instructions(precision, graph):
     """ONE engine stepped through the reference eval loop's inputs: unpadded (1, L) instructions, L in {7, 37, 80, 123, 200, 320}
@@ -104,7 +122,7 @@ def test_unpadded_variable_length_instructions(precision, graph):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_ragged_batch_equals_per_environment_unpadded_calls(precision):
     """`instruction_lengths`: a padded batch of instructions of different lengths gives every environment, bit for bit, the
     result of its own unpadded (1, L_b) call -- the reference evaluates one environment at a time -- and matches the oracle
@@ -152,24 +170,52 @@ def test_ragged_batch_equals_per_environment_unpadded_calls(precision):
     eng.close()
 
 
-def test_baseline_config2_batch64_bf16():
-    """BASELINE.json configs[1]: batch=64, 256x256 RGB-D, 80-token instruction, full HCM model, 16-bit path on one
-    MI355X -- parity vs the CPU oracle within 1e-2 on the (B,7) record over consecutive steps."""
+def test_baseline_config2_batch64_16bit():
+    """BASELINE.json configs[1]: batch=64, 256x256 RGB-D, 80-token instruction, full HCM model, the measured 16-bit mode on one
+    MI355X -- parity vs the CPU oracle within 1e-2 on the (B,7) record over THREE consecutive steps, with an episode reset."""
     from tests import parity_util
     import torch
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    rep = parity_util.run_case("cfg1_256_L80_N1", "bf16", taps=False, batch=64)
+    rep = parity_util.run_case("cfg1_256_L80_N1", "fp16", taps=False, batch=64)
     print(parity_util.format_report(rep))
     for s in rep["steps"]:
         assert s["max_abs"] <= 1e-2, s
-    assert rep["records"].shape == (2, 64, 7)
+    assert rep["records"].shape == (3, 64, 7)
+    for key in ("hi_hidden", "lo_hidden"):
+        assert rep[key][3] <= 1e-2, (key, rep[key])
+
+
+@pytest.mark.parametrize("name,batch", [("cfg1_256_L80_N1", 64), ("gru_128_L20", 64), ("cfg0_128_L20_N2", 16)])
+def test_bf16_mode_batch64_three_steps(name, batch):
+    """precision="bf16": bf16 storage and bf16 MFMA tiles in BERT, the RGB trunks and the cross-modal block (the GroupNorm depth trunks on
+    range-folded fp16 tiles) -- the north_star's bf16 tolerance, 1e-2 on the record, at the full batch over three consecutive steps."""
+    from tests import parity_util
+    import torch
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rep = parity_util.run_case(name, "bf16", taps=False, batch=batch, steps=3)
+    print(parity_util.format_report(rep))
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-2, s
+
+
+@pytest.mark.parametrize("sub", [{"bert": "bf16"}, {"vla": "bf16"}, {"bert": "bf16", "vla": "bf16"}])
+def test_mode_after_a_bf16_fallback_batch64_three_steps(sub):
+    """What the library runs after the range calibration moved BERT and / or the cross-modal block to bf16 tiles (the only sub-networks
+    that can still fall back: the trunks are range-folded instead) -- configs[1] at B = 64 over three steps, still inside 1e-2."""
+    from tests import parity_util
+    import torch
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rep = parity_util.run_case("cfg1_256_L80_N1", "fp16", taps=False, batch=64, steps=3, sub_precision=sub)
+    print(parity_util.format_report(rep))
+    for s in rep["steps"]:
+        assert s["max_abs"] <= 1e-2, (sub, s)
 
 
 def test_uint8_rgb_equals_float_rgb():
     """The boundary accepts uint8 RGB (converted on device) as well as the reference's f32 0..255 frames."""
     from tests import parity_util
-    a = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=False)
-    b = parity_util.run_case("cfg0_128_L20_N2", "bf16", taps=False, rgb_uint8=True)
+    a = parity_util.run_case("cfg0_128_L20_N2", "fp16", taps=False, rgb_uint8=False)
+    b = parity_util.run_case("cfg0_128_L20_N2", "fp16", taps=False, rgb_uint8=True)
     # same values, different stem gather (f32 frames: row-run vector gather; uint8: element-wise) -> only the fp32
     # summation order inside the 7x7 stem differs
     assert np.abs(a["records"] - b["records"]).max() <= 2e-3
@@ -182,7 +228,7 @@ def test_uint8_frames_other_configs(name):
     """uint8 RGB frames through every model variant (GRU state encoders, the reference's native 224/256 frame sizes, the
     high-level model alone)."""
     from tests import parity_util
-    rep = parity_util.run_case(name, "bf16", taps=False, rgb_uint8=True)
+    rep = parity_util.run_case(name, "fp16", taps=False, rgb_uint8=True)
     for s in rep["steps"]:
         assert s["max_abs"] <= 1e-2, s
 
@@ -191,7 +237,7 @@ def test_simplecnn_uint8_frames():
     """Low-level model with SimpleCNN encoders fed uint8 RGB frames (the 8x8/4 first conv gathers element-wise from the
     raw frame; regression: its K = 8*8*3 = 192 equals the 7x7 stem's row-run K and used to select the f32-only gather)."""
     from tests import parity_util
-    rep = parity_util.run_case("lo_simplecnn_256", "bf16", taps=False, rgb_uint8=True)
+    rep = parity_util.run_case("lo_simplecnn_256", "fp16", taps=False, rgb_uint8=True)
     for s in rep["steps"]:
         assert s["max_abs"] <= 1e-2, s
     rep = parity_util.run_case("lo_simplecnn_256", "fp32", taps=False, rgb_uint8=True)
@@ -210,7 +256,7 @@ def test_hipgraph_replay_equals_eager():
     hi_sd, lo_sd = synth.make_weights(cfg, seed=cases.SEED)
     outs = []
     for graph in (False, True):
-        eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=graph)
+        eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
         R = cfg.num_recurrent_layers
         hh = torch.zeros(R, B, cfg.hidden, device="cuda")
         lh = torch.zeros(R, B, cfg.hidden, device="cuda")
@@ -230,7 +276,7 @@ def test_hipgraph_replay_equals_eager():
 
 
 @pytest.mark.parametrize("name", ["seq_T4_N2_gru", "seq_T4_N2_lstm"])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_seq_forward_matches_oracle(name, precision):
     """the training/validation-path call -- T*N frames at once, masked T-step recurrent scan
     (RNNStateEncoder.seq_forward) -- through the reference-shaped model wrappers."""
@@ -266,7 +312,7 @@ def test_seq_forward_matches_oracle(name, precision):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 @pytest.mark.parametrize("kw,batch", [
     (dict(rgb_hw=128, depth_hw=128, instr_len=37, bert_layers=2), 3),      # odd instruction length, odd batch
     (dict(rgb_hw=128, depth_hw=128, instr_len=7, bert_layers=1, vla_layers=2), 5),
