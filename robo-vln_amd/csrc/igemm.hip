@@ -46,6 +46,7 @@ struct IGemmDev {
     int B, H, W, Cin, xC, Ho, Wo, KH, KW, stride, pad;
     int stride_w;                  // horizontal stride (== stride except for the packed-frame stem, see launch_pack_frame)
     int M, N, K, Kp, ldy, ldr, act, out_f32;
+    int image_epi;                 // force the LDS-image epilogue where the register epilogue would apply (HCM_IGEMM_IMAGE=1: A/B, toggle test)
     int res_f32;                   // the residual is an f32 tensor [M][ldr] (16-bit kernels: the f32 residual stream of the bf16 BERT)
     int cin_shift, kw_rcp, tilesM, tilesN, map;
     unsigned x_bytes, w_bytes;     // extents for the bounds-checked buffer loads of the DMA variant
@@ -826,6 +827,56 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
     igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, no_pre, false);
 }
 
+// Register epilogue (round 3) for the plain case -- 16-bit output, bias / residual / activation only, a wave tile of an EVEN number of
+// 16-channel accumulator tiles: swap_pair (v_permlane16_swap_b32, dev.h) regroups two adjacent tiles into 8 consecutive channels of one pixel per
+// lane, so bias + residual + activation + the one rounding happen in registers and every lane stores its 16 bytes directly -- no f32 LDS
+// image, no barrier.  The same f32 operations in the same order as igemm_epilogue: bit-identical.  A wave instruction stores 64
+// contiguous bytes per pixel (16 pixels); the neighbouring channel wave completes the 128-byte lines within the same few hundred cycles.
+// rpre (optional): the residual chunks in THIS function's lane mapping, rpre[ip * TM + j].
+template <typename T, int BM, int BN, int NW, int WMc, int NPRE>
+__device__ __forceinline__ void igemm_epilogue_regs(const IGemmDev& p, f32x4 (&acc)[BN / (NW / WMc) / 16][BM / WMc / 16], int m0, int n0,
+                                                    int wm, int wn, int fr, int fg, const uint4 (&rpre)[NPRE], bool have_pre) {
+    constexpr int WNc = NW / WMc;
+    constexpr int TM = BM / WMc / 16;
+    constexpr int TN = BN / WNc / 16;
+    static_assert(TN % 2 == 0 && sizeof(T) == 2 && (TN / 2) * TM == NPRE, "register epilogue: tile pairs");
+    const int coff = (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+    for (int ip = 0; ip < TN / 2; ++ip) {
+        const int n = n0 + wn * (BN / WNc) + ip * 32 + coff;
+        const bool n_ok = n + 8 <= p.N;                    // N % 8 == 0 (checked by the caller): a chunk is all-valid or all-invalid
+        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n_ok) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            float v[8];
+            swap_pair(acc[2 * ip][j], acc[2 * ip + 1][j], v);
+            const int m = m0 + wm * (BM / WMc) + j * 16 + fr;
+            const bool ok = n_ok && m < p.M;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+            if (p.res) {
+                float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (have_pre) cvt_chunk<T>(rpre[ip * TM + j], rr);
+                else if (ok) ld_chunk(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n, rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+            }
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
+            } else if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+            }
+            if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = pack_chunk<T>(v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Main variant: LDS-DMA staging, 3-deep ring, counted waits.
 //   * both tiles go L2/HBM -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write pass).  The DMA
@@ -980,15 +1031,35 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     constexpr int E_TPR = BN / 8, E_RPP = 64 * NW / E_TPR, E_NP = BM / E_RPP;
     uint4 rpre[E_NP];
     bool have_pre = false;
+    // register epilogue (igemm_epilogue_regs) for the plain 16-bit case; the LDS-image epilogue keeps the fused GroupNorm / statistics / pool /
+    // f32-output forms and every tile whose wave holds a single 16-channel accumulator tile (p.image_epi: HCM_IGEMM_IMAGE=1, A/B)
+    constexpr bool kRegsOk = sizeof(T) == 2 && !HPOOL && (TN % 2 == 0) && ((TN / 2) * TM == E_NP);
+    const bool regs_epi = kRegsOk && !p.out_f32 && !p.gn_cg && !p.cs_part && !p.res_f32 && (p.ldy % 8) == 0 && (p.N % 8) == 0 &&
+                          (!p.res || (p.ldr % 8) == 0) && !p.image_epi;
     if constexpr (sizeof(T) == 2 && NW == 8 && E_NP <= 8) {
         if (p.res && !p.res_f32 && (p.ldr % 8) == 0 && (p.N % 8) == 0) {
             have_pre = true;
-            const int n = n0 + (tid % E_TPR) * 8;
+            if (regs_epi) {
+                if constexpr (kRegsOk) {
+                    const int coff = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
 #pragma unroll
-            for (int pass = 0; pass < E_NP; ++pass) {
-                const int m = m0 + pass * E_RPP + tid / E_TPR;
-                rpre[pass] = make_uint4(0u, 0u, 0u, 0u);
-                if (m < p.M && n + 8 <= p.N) rpre[pass] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n);
+                    for (int ip = 0; ip < TN / 2; ++ip)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) {
+                            const int m = m0 + wm * (BM / WMc) + j * 16 + (lane & 15);
+                            const int n = n0 + wn * (BN / WNc) + ip * 32 + coff;
+                            rpre[ip * TM + j] = make_uint4(0u, 0u, 0u, 0u);
+                            if (m < p.M && n + 8 <= p.N) rpre[ip * TM + j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n);
+                        }
+                }
+            } else {
+                const int n = n0 + (tid % E_TPR) * 8;
+#pragma unroll
+                for (int pass = 0; pass < E_NP; ++pass) {
+                    const int m = m0 + pass * E_RPP + tid / E_TPR;
+                    rpre[pass] = make_uint4(0u, 0u, 0u, 0u);
+                    if (m < p.M && n + 8 <= p.N) rpre[pass] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n);
+                }
             }
         }
     }
@@ -1227,8 +1298,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
     if constexpr (HPOOL) igemm_epilogue_hpool<T, BM, BN, NW, WMc>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg);
-    else
-    igemm_epilogue<T, BM, BN, NW, WMc, E_NP>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, rpre, have_pre);
+    else {
+        if constexpr (kRegsOk) {
+            if (regs_epi) igemm_epilogue_regs<T, BM, BN, NW, WMc, E_NP>(p, acc, m0, n0, wm, wn, fr, fg, rpre, have_pre);
+            else igemm_epilogue<T, BM, BN, NW, WMc, E_NP>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, rpre, have_pre);
+        } else igemm_epilogue<T, BM, BN, NW, WMc, E_NP>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, rpre, have_pre);
+    }
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lap(5);
@@ -1774,8 +1849,16 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
 // 16 bytes twice: to y, and into the slice block in LDS that the next block's reduction reads as its MFMA operand.  Per slice that leaves TWO
 // barriers (weights landed / slice block complete); the reduction's weight slices are double-buffered so that nothing else has to be waited
 // for.  Same MFMA sequence, same f32 operations in the same order as bneck231_kernel: bit-identical to it and to the stand-alone launches.
-template <typename T, int BM, int C1, int CN, int KD = 0>
+template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false>
 __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
+    // phase timing (HCM_IGEMM_PROF=1 builds, read through hcm_debug_igemm_prof): per-wave cycle totals [0] prologue up to the first barrier,
+    // [1] phase A K loop, [2] park + top-of-slice waits and barriers, [3] expansion MFMAs, [4] register epilogues, [5] slice-block barrier +
+    // reduction MFMAs + final epilogue, [6] waves, [7] K iterations
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if constexpr (PROF) t_prev = prof_now();
+    auto lap = [&](int slot) {
+        if constexpr (PROF) { const unsigned long long t = prof_now(); pt[slot] += t - t_prev; t_prev = t; }
+    };
     BneckDev& q = qq.t;
     constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
     constexpr int TM = BM / WMc / 16;              // phase A: BM / 2 pixels x C1 / 4 channels per wave
@@ -1825,15 +1908,18 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 
     // identity rows of every output slice, requested first: they arrive while phase A runs (16 B per lane, pixel tile and slice)
     uint4 rpre[NT][TMB] = {};
-    if constexpr (KD == 0) {
+    auto load_identity = [&]() {
+        if constexpr (KD == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < TMB; ++j) {
-                const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
-                if (m < p.M) rpre[nt][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
-            }
-    }
+                for (int j = 0; j < TMB; ++j) {
+                    const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
+                    if (m < p.M) rpre[nt][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
+                }
+        }
+    };
+    load_identity();
 
     int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
     const int HoWo = p.Ho * p.Wo;
@@ -1917,6 +2003,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     stage(0, 0);
     if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
+    lap(0);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 2 < nk;
@@ -1947,6 +2034,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
     }
+    lap(1);
     stage_w3(0);
     stage_w1(0);
     if constexpr (KD > 0) stage_xd();
@@ -1980,6 +2068,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         const float4 b30 = *reinterpret_cast<const float4*>(q.b3 + nb), b31 = *reinterpret_cast<const float4*>(q.b3 + nb + 4);
         wait_vmcnt<0>();                                   // this slice's weights (both matrices) have landed (and the bias, the identity rows)
         __syncthreads();                                   // ... for every wave; parked tile complete; the previous reduction has left the slice block
+        lap(2);
         f32x4 acc2[TN2][TMB];
 #pragma unroll
         for (int i = 0; i < TN2; ++i)
@@ -2009,6 +2098,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
                     for (int j = 0; j < TMB; ++j) Mma<T>::run(acc2[i][j], wb[i], xa[j]);
             }
         }
+        lap(3);
         // register epilogue of the slice: bias + identity + ReLU, one rounding, 16 bytes per lane to y and into the slice block
         const float bias8[8] = {b30.x, b30.y, b30.z, b30.w, b31.x, b31.y, b31.z, b31.w};
 #pragma unroll
@@ -2032,6 +2122,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             const int ch = (wn2 * 32 + coff) >> 3;
             *reinterpret_cast<uint4*>(smem + YS_OFF + r * 128 + ((ch ^ (r & 7)) << 4)) = o;
         }
+        lap(4);
         __syncthreads();                                   // slice block complete; every wave is done with the expansion weights
         if (nt + 1 < NT) { stage_w3(nt + 1); stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
         {
@@ -2057,6 +2148,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
                     for (int j = 0; j < TMB; ++j) Mma<T>::run(acc3[i][j], wb[i], xa[j]);
             }
         }
+        lap(5);
     }
     // the reduction's own epilogue (bias + ReLU), in registers as well
     T* const op = reinterpret_cast<T*>(qq.o1);
@@ -2073,6 +2165,16 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e] + bias8[e]);
             const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
             if (m < p.M) *reinterpret_cast<uint4*>(op + (size_t)m * qq.ldo + nb) = pack_chunk<T>(v);
+        }
+    }
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(5);
+        if (lane == 0) {
+            unsigned long long* slot = g_igemm_prof[((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) & (kProfSlots - 1)];
+            for (int i = 0; i < 6; ++i) atomicAdd(&slot[i], pt[i]);
+            atomicAdd(&slot[6], 1ull);
+            atomicAdd(&slot[7], (unsigned long long)nk);
         }
     }
 }
@@ -2452,6 +2554,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.stride_w = g.stride_w > 0 ? g.stride_w : g.stride;
     d.M = g.M; d.N = g.N; d.K = g.K; d.Kp = g.Kp ? g.Kp : g.K;
     d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32; d.res_f32 = g.res_f32;
+    static const bool image_epi = getenv("HCM_IGEMM_IMAGE") != nullptr;
+    d.image_epi = image_epi ? 1 : 0;
     const int CH = dt_chunk(dt);
     d.cin_shift = 0;
     d.kw_rcp = (65536 + g.KW - 1) / g.KW;
@@ -2659,6 +2763,9 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128>)
                     : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128>);
         }
+#ifdef HCM_DEV_KNOBS
+        if (!image && prof_on() && dt == DT_F16 && b.C1 == 64 && b.CN == 64) f1 = reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true>);
+#endif
         hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e1 != hipSuccess) return e1;
         void* a1[] = {&qq};

@@ -8,7 +8,7 @@ from robo_vln_amd import synth
 from robo_vln_amd.cma import CMAEngine
 L = int(sys.argv[sys.argv.index("--L") + 1]) if "--L" in sys.argv else 80
 cfg = CMAConfig(instr_len=L).validate(); B = 64
-eng = CMAEngine(cfg, synth.make_cma_weights(cfg, 0), max_batch=B, precision="bf16", graph="--no-graph" not in sys.argv)
+eng = CMAEngine(cfg, synth.make_cma_weights(cfg, 0), max_batch=B, precision="fp16", graph="--no-graph" not in sys.argv)
 obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_observations(cfg, B, rgb_uint8=True).items()}
 hid = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
 for _ in range(60): out, stop, hid = eng.forward(obs, hid, m)

@@ -19,7 +19,7 @@ def timeit(fn, n=20):
 # configs[4]: hi model, B=128, L=160, N=6
 cfg = HCMConfig(instr_len=160, vla_layers=6).validate(); B = 128
 hi_sd = synth.materialize(synth.high_level_spec(cfg), "hi", 0)
-eng = HCMEngine(cfg, hi_sd, None, max_batch=B, precision="bf16")
+eng = HCMEngine(cfg, hi_sd, None, max_batch=B, precision="fp16")
 obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, rgb_uint8=True).items()}
 h = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
 dt = timeit(lambda: eng.high_forward(dict(obs), h, m))
@@ -29,7 +29,7 @@ eng.close()
 # configs[3]: lo model with SimpleCNN encoders, B=256
 cfg = HCMConfig(depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN").validate(); B = 256
 lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", 0)
-eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="bf16")
+eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="fp16")
 obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, rgb_uint8=True).items()}
 h = torch.zeros(cfg.num_recurrent_layers, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
 st = torch.zeros(B, dtype=torch.int64, device="cuda")

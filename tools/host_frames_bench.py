@@ -18,7 +18,7 @@ ids = torch.from_numpy(o["instruction"]).cuda()
 R = cfg.num_recurrent_layers
 m = torch.ones(B, device="cuda")
 for graph in (False, True):
-    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16", graph=graph)
+    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", graph=graph)
     for side in (False, True):
         stream = torch.cuda.Stream() if side else torch.cuda.current_stream()
         for mode in ("resident", "prestage", "host_frames"):

@@ -19,14 +19,14 @@ cobs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_cma_obs
 base = None
 hist = []
 for c in range(cycles):
-    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16" if c % 2 else "fp32", graph=bool(c % 3))
+    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16" if c % 2 else "fp32", graph=bool(c % 3))
     R = cfg.num_recurrent_layers
     hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda"); m = torch.ones(B, device="cuda")
     for _ in range(4):
         rec, hh, lh = eng.act(obs, hh, lh, m)
     torch.cuda.synchronize()
     eng.close()
-    ce = CMAEngine(ccfg, csd, max_batch=B, precision="bf16", graph=bool(c % 2))
+    ce = CMAEngine(ccfg, csd, max_batch=B, precision="fp16", graph=bool(c % 2))
     h = torch.zeros(ccfg.num_recurrent_layers, B, ccfg.hidden, device="cuda")
     for _ in range(3):
         out, stop, h = ce.forward(cobs, h, m)

@@ -10,7 +10,7 @@ from robo_vln_amd.policy import HCMEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cfg = baseline_config(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 hi, lo = synth.make_weights(cfg, 0)
-eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16")
+eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16")
 o = synth.make_observations(cfg, B, 0, 0, rgb_uint8=True)
 obs = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
 R = cfg.num_recurrent_layers

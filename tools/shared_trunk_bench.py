@@ -9,7 +9,7 @@ cfg = baseline_config(1); B = 64
 hi_sd, lo_sd = synth.make_weights(cfg, seed=0)
 for k, v in hi_sd.items():
     if k.startswith(("rgb_encoder.cnn.", "depth_encoder.visual_encoder.")): lo_sd[k] = v
-eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="bf16", graph=True)
+eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True)
 obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, B, rgb_uint8=True).items()}
 hh = torch.zeros(2, B, 512, device="cuda"); lh = torch.zeros(2, B, 512, device="cuda"); m = torch.ones(B, device="cuda")
 for reuse in (False, True):

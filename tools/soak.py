@@ -13,7 +13,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cfg = HCMConfig(rgb_hw=128, depth_hw=128, bert_layers=2).validate()
 hi, lo = synth.make_weights(cfg, seed=0)
-eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16", max_instr_len=256, graph=True)
+eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", max_instr_len=256, graph=True)
 rng = np.random.default_rng(0)
 obs0 = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=0, rgb_uint8=True).items()}
 R = cfg.num_recurrent_layers

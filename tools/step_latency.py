@@ -9,7 +9,7 @@ cfg = HCMConfig().validate()
 hi, lo = synth.make_weights(cfg, seed=0)
 for B in (1, 4):
     for graph in (False, True):
-        eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16", graph=graph)
+        eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", graph=graph)
         H, Lw = Seq2Seq_HighLevel_CMA(eng), Seq2Seq_LowLevel(eng)
         obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=0).items()}
         R = cfg.num_recurrent_layers

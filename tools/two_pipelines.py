@@ -14,7 +14,7 @@ R = cfg.num_recurrent_layers
 
 
 def make(b):
-    eng = HCMEngine(cfg, hi, lo, max_batch=b, precision="bf16", graph=True)
+    eng = HCMEngine(cfg, hi, lo, max_batch=b, precision="fp16", graph=True)
     o = synth.make_observations(cfg, b, 0, 0, rgb_uint8=True)
     obs = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
     st = {"hh": torch.zeros(R, b, cfg.hidden, device="cuda"), "lh": torch.zeros(R, b, cfg.hidden, device="cuda"), "m": torch.ones(b, device="cuda")}

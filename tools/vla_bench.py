@@ -9,7 +9,7 @@ from robo_vln_amd.config import baseline_config
 from robo_vln_amd.policy import HCMEngine
 cfg = baseline_config(1); B = 64
 hi, lo = synth.make_weights(cfg, 0)
-eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="bf16", graph=True)
+eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", graph=True)
 o = synth.make_observations(cfg, B, 0, 0, rgb_uint8=True)
 obs = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
 R = cfg.num_recurrent_layers
