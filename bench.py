@@ -75,6 +75,36 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=8):
                       f"with {torch.get_num_threads()} threads"}
 
 
+def cpu_baseline_protocol(cfg, hi_sd, lo_sd):
+    """BASELINE.md section 3's protocol (--cpu-batches: minutes of CPU work, NOT part of the default run): batches 4, 16 and 64, best of 5
+    timed steps each."""
+    import numpy as np
+    import torch
+    from oracle import hcm_oracle
+    from robo_vln_amd import synth
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
+    R = cfg.num_recurrent_layers
+    out = {}
+    for batch in (4, 16, 64):
+        hh = torch.zeros(R, batch, cfg.hidden); lh = torch.zeros(R, batch, cfg.hidden)
+        obs = synth.make_observations(cfg, batch, step=0, seed=0)
+        mask = np.zeros(batch, np.float32)
+        _, hh, lh = ora.act(obs, hh, lh, mask)
+        mask[:] = 1
+        best = None
+        for _ in range(5):
+            t0 = time.time()
+            _, hh, lh = ora.act(obs, hh, lh, mask)
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        out[f"batch_{batch}"] = {"value": round(batch / best, 3), "unit": "env-steps/s", "ms_per_step": round(best * 1e3, 1)}
+    out["cores"] = ncores
+    out["protocol"] = "best of 5 act() steps per batch size (BASELINE.md section 3), CPU oracle, fp32"
+    return out
+
+
 def _time_op(run, n=60, warm=30):
     """HIP events on torch's current stream, which is the stream the operator entry points are handed."""
     import torch
@@ -288,6 +318,8 @@ def main():
     ap.add_argument("--reuse-instruction", action="store_true",
                     help="NOT the headline configuration: steps after the first skip BERT (instructions unchanged; hcm_act_ex flag)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batches", action="store_true", help="additionally time the CPU oracle at batch 4, 16 and 64, best of 5 steps each "
+                                                               "(BASELINE.md section 3's protocol; minutes of CPU work, not in the default run)")
     ap.add_argument("--h2d", action="store_true", help="include the per-step host->device staging of uint8 RGB + f32 depth "
                     "(pinned buffers) in the timed region: the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--h2d-prestage", action="store_true", help="with --h2d: copy the frames in front of the step on the caller's stream instead of "
@@ -470,10 +502,16 @@ def main():
             out["overlapped_all_gather"] = overlapped
         if args.config == 3:
             gb = alg_bytes / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(gb / ms, 4), "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": round(gb / ms / PEAK_HBM_TBPS, 4),
+            # BASELINE.json calls this configuration memory-bound; at 16-bit MFMA rates it is not (0.25 GFLOP and 0.46 MB per sample = 540 FLOP/B,
+            # above the 312 FLOP/B ridge): the line is judged against the MATRIX peak, the HBM view rides along as a sub-key
+            gflop3 = 0.2422 * B                                   # conv0 + conv1 + conv2 + FC + one cross-modal layer per sample
+            tf = gflop3 / ms                                      # GFLOP / ms = TFLOP/s
+            out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                                "traffic": (tr or {}).get("step_GB"), "traffic_unit": "GB per step (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_cfg3.json)" if tr else None,
-                               "basis": f"{gb * 1e3:.1f} MB algorithmic bytes per step (depth f32 in + (B,80,768) instruction tensor in + (B,80,256) out + "
-                               "weights once, SURVEY 8d) / step time; the step is the whole probe (all its launches)"}
+                               "basis": f"{gflop3:.1f} algorithmic GFLOP per step / step time; the step is the whole probe (all its launches)",
+                               "hbm_view": {"achieved_TBps": round(gb / ms, 4), "peak_TBps": PEAK_HBM_TBPS, "frac": round(gb / ms / PEAK_HBM_TBPS, 4),
+                                            "basis": f"{gb * 1e3:.1f} MB algorithmic bytes per step (depth f32 in + (B,80,768) instruction tensor in + (B,80,256) out + "
+                                                     "weights once, SURVEY 8d)"}}
         else:
             gf = GFLOP[args.config]
             achieved = value * gf / 1e3                           # TFLOP/s, algorithmic
@@ -514,6 +552,8 @@ def main():
             out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
         if not args.no_cpu_baseline and world == 1 and args.config == 1:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, *weights)
+            if args.cpu_batches:
+                out["cpu_baseline"]["batches"] = cpu_baseline_protocol(cfg, *weights)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if hasattr(eng, "close"):

@@ -94,7 +94,9 @@ typedef struct hcm_config {
     int32_t reserved[8];                /* [0..3]: storage-type override (hcm_dtype + 1, 0 = default) for the depth trunk /
                                            BERT / cross-modal block / RGB trunk; see DESIGN.md section 5.
                                            [4]: keep the f32 host copies of the weights after hcm_finalize so that hcm_calibrate can
-                                           re-build a sub-network (release them with hcm_release_host_weights) */
+                                           re-build a sub-network (release them with hcm_release_host_weights)
+                                           [5]: 1 = do not share a trunk between the two models when their trunk weights are bit-identical
+                                           (the default runs it once per step and feeds both heads: same values, half the work) */
 } hcm_config;
 
 /* Replaces model construction, hierarchical_trainer.py:315-328 (Seq2Seq_HighLevel_CMA.__init__

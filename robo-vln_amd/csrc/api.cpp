@@ -502,7 +502,7 @@ int hcm_finalize(hcm_handle h) {
         // tile + staging variant (igemm.hip); steady-state calls then never synchronise the host
         // (opt-in: HCM_TUNE=1.  Isolated per-kernel timings rank variants differently from the concurrent multi-stream
         //  schedule, where the built-in heuristic measured faster end to end)
-        const char* nt = getenv("HCM_TUNE");
+        const char* nt = dev_env("HCM_TUNE");
         if (nt && atoi(nt) && h->kind == 0) {
             const hcm_config& c = h->cfg;
             const size_t B = c.max_batch, R = c.rnn_type == HCM_LSTM ? 2 : 1;
@@ -940,7 +940,7 @@ int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias,
                            void* stream) {
     const int dt = op_dt(dtype);
     if (!scratch || dt == DT_F32 || H % 4 || H < 8) return HCM_ERR_ARG;
-    static const bool no_direct = getenv("HCM_NO_DEPTH_CONV0") != nullptr;       // A/B aid: the convert + implicit-GEMM route
+    static const bool no_direct = dev_env("HCM_NO_DEPTH_CONV0") != nullptr;       // A/B aid: the convert + implicit-GEMM route
     if (!no_direct && depth_conv8x8s4_ok(dt, H, act)) return op_rc(launch_depth_conv8x8s4(depth, w, bias, y, dt, B, H, act, (hipStream_t)stream));
     int rc = op_rc(launch_convert_from_f32(depth, scratch, dt, (size_t)B * H * H, (hipStream_t)stream));
     if (rc != HCM_OK) return rc;

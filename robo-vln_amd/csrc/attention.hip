@@ -272,7 +272,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<f16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_once.done();
     }
-    static const char* valu = getenv("HCM_ATT_VALU");
+    static const char* valu = dev_env("HCM_ATT_VALU");
     if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 512 && !(valu && atoi(valu))) {
         const int Lkp = (Lk + 31) / 32 * 32;
         const size_t lds2 = (size_t)Lkp * 128 + (size_t)64 * (Lkp + 4) * 2;          // 131.6 KB at Lk = 512

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(T* __restrict__ x, const 
 }
 
 static long gn_slab_limit() {
-    static const long v = getenv("HCM_GN_SLAB") ? atol(getenv("HCM_GN_SLAB")) : 32768;
+    static const long v = dev_env("HCM_GN_SLAB") ? atol(dev_env("HCM_GN_SLAB")) : 32768;
     return v;
 }
 
@@ -509,7 +509,7 @@ hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const 
     if (C % CH || C % G) return hipErrorInvalidValue;
     const int Cg = C / G;
     if (cg_true < 0 || cg_true > Cg) return hipErrorInvalidValue;
-    static const int two_pass = getenv("HCM_GN_TWO") ? atoi(getenv("HCM_GN_TWO")) : 1;
+    static const int two_pass = dev_env("HCM_GN_TWO") ? atoi(dev_env("HCM_GN_TWO")) : 1;
     const int P = gn_partials(HW);
     const int cprw = C / CH;
     if (two_pass && !cg_true && stats && P > 0 && !(cprw & (cprw - 1)) && cprw <= 128 && C <= 512 && G <= 256 && HW % P == 0 &&
@@ -1084,7 +1084,7 @@ hipError_t launch_instr_lstm_scan(const float* pre0, const float* pre1, const fl
     LstmScanArgs a;
     a.pre[0] = pre0; a.pre[1] = pre1; a.wt[0] = wt0; a.wt[1] = wt1;
     // samples per workgroup: the fewest that keep the launch within one workgroup per CU
-    static const char* fsb = getenv("HCM_LSTM_SB");
+    static const char* fsb = dev_env("HCM_LSTM_SB");
     // (SB = 1 is not built: slower at B = 64 -- 128 workgroups take the CUs from the trunks running beside the scan -- and its
     // instantiation showed run-to-run differences of ~3e-5 whose cause was not found; SB = 2 / 4 / 8 are bitwise reproducible, tested)
     int SB = 2;

@@ -66,7 +66,7 @@ struct Fwd {
     // epilogue (igemm.hip), else conv + the stand-alone GroupNorm kernels
     void conv_gn(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, const NormW& n, int G, bool relu, int Ho,
                  int Wo, int cg_true = 0) {
-        static const bool no_fuse = getenv("HCM_NO_GN_FUSE") != nullptr;
+        static const bool no_fuse = dev_env("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
         const float eps = 1e-5f * w.fold * w.fold;          // range-folded conv (ConvW::fold): GroupNorm((fold * x), eps * fold^2) == GroupNorm(x, eps)
         if (cg_true) {
@@ -86,7 +86,7 @@ struct Fwd {
         } else {
             // large maps: the statistics come out of the conv's epilogue (column sums of the f32 tile image per 64-row block and
             // group), so GroupNorm is one launch over the map instead of two
-            static const bool no_cs = getenv("HCM_NO_GN_EPISTATS") != nullptr;
+            static const bool no_cs = dev_env("HCM_NO_GN_EPISTATS") != nullptr;
             if (!no_cs && !w.bias && groupnorm_apply_ok(w.dt, hw, C, G) && w.Cout % cg == 0) {
                 float* stats = alloc_f(gn_stats_floats(in.B, hw, G));
                 conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo, nullptr, 0, stats, cg, hw, G);
@@ -124,7 +124,7 @@ struct Fwd {
         const int wd = wdt < 0 ? w.dt : wdt;
         const int CHw = wd == DT_F32 ? 4 : 8;
         int S = 1;
-        static const bool no_split = getenv("HCM_NO_SPLITK") != nullptr;
+        static const bool no_split = dev_env("HCM_NO_SPLITK") != nullptr;
         if (!no_split && !res && M <= 256 && w.K >= 2048) {
             const long blocks = (long)((M + 63) / 64) * ((w.N + 31) / 32);
             while (S < 16 && blocks * S < 256 && w.K % (2 * S * 64) == 0 && w.K / (2 * S) >= 256) S *= 2;
@@ -205,16 +205,16 @@ struct Fwd {
         for (auto& p : slot) p = alloc_t(max_elems);
         // 7x7/2 stem: implicit GEMM gathering straight from the raw frame (permute, /255, dtype conversion fused)
         // f32 RGB frames take the row-run fast gather; uint8 frames and the 1-channel depth stem the element-wise one
-        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        static const bool no_pack = dev_env("HCM_NO_STEM_PACK") != nullptr;
         const bool packed = !t.gn && !no_pack && t.conv1_packed.w != nullptr && st.Cin == 3 && !(st.W & 1) && !(st.H & 1) &&
                             (st.x_dt == DT_F32 || st.x_dt == DT_U8);
         const bool fast = !t.gn && st.x_dt == DT_F32 && t.conv1_rowrun.w != nullptr;
         // packed RGB stem: the horizontal half of the 3x3/2 max-pool rides in the conv's epilogue (the 128-channel pair map is written at
         // half width), a vertical-only pool follows; exact.  Not while taps are captured: `_conv1` is the full-width map.
-        static const bool no_hpool = getenv("HCM_NO_STEM_HPOOL") != nullptr;
+        static const bool no_hpool = dev_env("HCM_NO_STEM_HPOOL") != nullptr;
         const bool hpool = packed && !no_hpool && !ctx->taps_on && Wo >= 2 && Wo <= 128 && !(Wo & (Wo - 1)) && (c1 % 64) == 0;
         // GroupNorm statistics of the packed depth stem from its conv's epilogue (see conv_gn)
-        static const bool no_cs_stem = getenv("HCM_NO_GN_EPISTATS") != nullptr;
+        static const bool no_cs_stem = dev_env("HCM_NO_GN_EPISTATS") != nullptr;
         float* stem_stats = nullptr;
         if (t.gn && st.x_dt == -2 && !no_cs_stem && groupnorm_apply_ok(t.conv1_packed.dt, Ho * Wo, c1, G) && c1 % (c1 / G) == 0)
             stem_stats = alloc_f(gn_stats_floats(B, Ho * Wo, G));
@@ -264,15 +264,15 @@ struct Fwd {
             else conv(b.c1, x, sa, 1, 0, nullptr, ACT_RELU, x.H, x.W);
             // BN-folded trunks, 64 / 128 mid channels (layer1, layer2), 16-bit storage: 3x3 conv + 1x1 expansion + identity in ONE
             // launch, the mid tensor stays in LDS (igemm.hip: bneck23_kernel; bit-identical to the two launches)
-            static const bool no_tail = getenv("HCM_NO_BNECK_FUSE") != nullptr;
+            static const bool no_tail = dev_env("HCM_NO_BNECK_FUSE") != nullptr;
             if (!t.gn && !no_tail && (b.c2.dt == DT_BF16 || b.c2.dt == DT_F16) && (b.c2.Cout == 64 || b.c2.Cout == 128) && b.c2.KH == 3 &&
                 b.c2.Cin == b.c2.Cout && b.c2.Kp == 9 * b.c2.Cin && b.c3.Cout == 4 * b.c2.Cout && b.c3.Kp == b.c2.Cout && b.c2.bias && b.c3.bias &&
                 b.c3.groups == b.c2.groups) {
                 const void* idt = x.p;
-                static const bool no_next = getenv("HCM_NO_BNECK_NEXT") != nullptr;
-                static const bool no_dsfold = getenv("HCM_NO_BNECK_DSFOLD") != nullptr;
+                static const bool no_next = dev_env("HCM_NO_BNECK_NEXT") != nullptr;
+                static const bool no_dsfold = dev_env("HCM_NO_BNECK_DSFOLD") != nullptr;
                 const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
-                static const int next_only = getenv("HCM_BNECK_NEXT_ONLY") ? atoi(getenv("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
+                static const int next_only = dev_env("HCM_BNECK_NEXT_ONLY") ? atoi(dev_env("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
                 const bool next = nb && !no_next && (!next_only || next_only == b.c2.Cout) && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
                                   nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
                                   ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
@@ -363,7 +363,7 @@ struct Fwd {
     Act depth_trunk_(const TrunkW& t, const float* depth, int B, const std::string& tapname) {
         const int H = ctx->cfg.depth_h / 2, W = ctx->cfg.depth_w / 2;
         const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        static const bool no_pack = dev_env("HCM_NO_STEM_PACK") != nullptr;
         if (t.conv1_packed.w && !no_pack && !(W & 1) && !(H & 1)) {
             // 16-bit trunks: avg_pool2d(2) writes straight into the zero-bordered frame of the packed stem
             void* pk = alloc_t((size_t)B * (H + 6) * (W + 8) + 64);
@@ -381,13 +381,13 @@ struct Fwd {
         const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
         const int w1 = (W - 8) / 4 + 1, w2 = (w1 - 4) / 2 + 1, w3 = (w2 - 3) / 1 + 1;
         void* y0 = alloc_t((size_t)B * h1 * w1 * 32);
-        static const bool no_pack = getenv("HCM_NO_STEM_PACK") != nullptr;
+        static const bool no_pack = dev_env("HCM_NO_STEM_PACK") != nullptr;
         if (w.c0_packed.w && !no_pack && (x_dt == DT_F32 || x_dt == DT_U8) && (w.cin == 3 || x_dt == DT_F32)) {
             // 16-bit path: convert / pack the frame once ([B][H][W][cp], cp = 4 for RGB, 1 for depth); a kernel row of an output
             // pixel is then one contiguous run of 8 pixels and the conv an ordinary LDS-DMA implicit GEMM over "virtual
             // pixels" of 4 real ones (the stride): KH = 8, KW = 1, Cin = 8*cp, pixel stride 4*cp elements
             const int cp = w.cin == 3 ? 4 : 1;
-            static const bool no_direct = getenv("HCM_NO_DEPTH_CONV0") != nullptr;
+            static const bool no_direct = dev_env("HCM_NO_DEPTH_CONV0") != nullptr;
             const bool direct = cp == 1 && H == W && !no_direct && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 && depth_conv8x8s4_ok(dt, H, ACT_RELU);
             void* pk = direct ? nullptr : alloc_t((size_t)B * H * W * cp + 64);
             if (direct) {
@@ -430,7 +430,7 @@ struct Fwd {
         // the stream itself four times per layer (both sums in front of the LayerNorms, both LayerNorm outputs) is what costs 6-9e-3 of the 1e-2
         // record tolerance.  Here only the GEMM operands are bf16: the projections write `sum = branch + stream` in f32, the LayerNorm
         // reads that and writes the stream in f32 beside its bf16 operand copy (HCM_BERT_BF16_STREAM=0: the all-16-bit form, for the A/B).
-        static const bool f32_stream_off = getenv("HCM_BERT_BF16_STREAM") && atoi(getenv("HCM_BERT_BF16_STREAM")) == 0;
+        static const bool f32_stream_off = dev_env("HCM_BERT_BF16_STREAM") && atoi(dev_env("HCM_BERT_BF16_STREAM")) == 0;
         const bool f32_stream = dt == DT_BF16 && !f32_stream_off && (D == 768 || D == 256 || D == 512);
         float* xf = f32_stream ? alloc_f(rmax * D) : nullptr;       // the stream
         float* sumf = f32_stream ? alloc_f(rmax * D) : nullptr;     // branch + stream, in front of a LayerNorm
@@ -812,7 +812,7 @@ struct Fwd {
         // the few visual tokens) + fc_o + residual + LayerNorm + FFN + residual + LayerNorm (+ the cross_pooler mean on the last layer) with
         // the block's activations resident in LDS (vla_fused.hip); deeper layers keep their key/value projection and the L x L attention as
         // launches of their own.  HCM_NO_VLA_FUSE=1 selects the launch-per-op form below (A/B and the toggle test).
-        static const bool no_vla_fuse = getenv("HCM_NO_VLA_FUSE") != nullptr;
+        static const bool no_vla_fuse = dev_env("HCM_NO_VLA_FUSE") != nullptr;
         const bool fused = !no_vla_fuse && vla_post_ok(dt, d, c.vla_heads, c.d_ff);
         const bool fork = ctx->concurrent && !ctx->taps_on;
         hipStream_t main_s = s;
@@ -908,7 +908,7 @@ struct Fwd {
         // state_encoder (:219) + linear head (:232)
         Heads hd;
         hd.w0 = w.head_w; hd.b0 = w.head_b; hd.out0 = logits; hd.r0 = c.num_actions; hd.ld0 = ld_logits;
-        static const bool no_pred_fuse = getenv("HCM_NO_PRED_FUSE") != nullptr;
+        static const bool no_pred_fuse = dev_env("HCM_NO_PRED_FUSE") != nullptr;
         pred_fused = false;
         if (split && lo_early && !no_pred_fuse && c.num_actions <= 64) {
             // fused act(): argmax + the low-level model's sub-task embedding lookup ride in the high-level cell kernel
@@ -1035,7 +1035,7 @@ struct Fwd {
             float* gh = alloc_f((size_t)B * 4 * Hi);
             float* hc = alloc_f((size_t)2 * B * Hi);
             for (int d = 0; d < w.dirs; ++d) linear(w.ih[d], x, B * L, ldx, pre[d], 4 * Hi, ACT_NONE, true);
-            static const bool no_scan = getenv("HCM_NO_LSTM_SCAN") != nullptr;
+            static const bool no_scan = dev_env("HCM_NO_LSTM_SCAN") != nullptr;
             if (Hi == 256 && !no_scan) {
                 // both directions, all L steps: one launch
                 if (!dry) ck(launch_instr_lstm_scan(pre[0], pre[1], w.hh_t[0], w.hh_t[1], ctx->len_buf, ins, B, L, Hi, w.dirs, C, s), "instr lstm scan");
@@ -1154,7 +1154,7 @@ struct Fwd {
         hipStream_t main_s = ctx->stream;
         hipStream_t a0 = multi ? ctx->aux[0] : main_s, a1 = multi ? ctx->aux[1] : main_s, a2 = multi ? ctx->aux[2] : main_s;
 #ifdef HCM_DEV_KNOBS
-        static const int skip = getenv("HCM_SKIP") ? atoi(getenv("HCM_SKIP")) : 0;   // profiling aid (make DEV=1 builds only): drop chains (bitmask)
+        static const int skip = dev_env("HCM_SKIP") ? atoi(dev_env("HCM_SKIP")) : 0;   // profiling aid (make DEV=1 builds only): drop chains (bitmask)
 #else
         constexpr int skip = 0;
 #endif
@@ -1198,7 +1198,7 @@ struct Fwd {
         else if (rpair) { if (!(skip & 1)) rgb_pair(rgb, rgb_dt, B, hb, lb); }
         else if (!(skip & 1)) { if (do_hi) hi_rgb(rgb, rgb_dt, B, hb); else lo_rgb(rgb, rgb_dt, B, lb); }
         // chain 1: the low-level RGB trunk
-        static const int rgb_serial = getenv("HCM_RGB_SERIAL") ? atoi(getenv("HCM_RGB_SERIAL")) : 1;
+        static const int rgb_serial = dev_env("HCM_RGB_SERIAL") ? atoi(dev_env("HCM_RGB_SERIAL")) : 1;
         on((rgb_serial || ctx->host_frames) ? main_s : a0);        // (staged frames: behind their copy)
         if (do_hi && do_lo && !rpair && !rshare && !ctx->cfg.ablate_rgb && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);

@@ -648,8 +648,8 @@ bool gemm256_applicable(const IGemm& g, int dt) {
     // worth it when the tile grid fills a good part of the chip with whole tiles: wide outputs over many rows
     const long tiles = (long)((g.M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
     // (HCM_GEMM256_MIN_TILES / HCM_GEMM256_MIN_N: A/B knobs for the in-step choice of the narrow-output layers)
-    static const int min_tiles = getenv("HCM_GEMM256_MIN_TILES") ? atoi(getenv("HCM_GEMM256_MIN_TILES")) : 96;
-    static const int min_n = getenv("HCM_GEMM256_MIN_N") ? atoi(getenv("HCM_GEMM256_MIN_N")) : 512;
+    static const int min_tiles = dev_env("HCM_GEMM256_MIN_TILES") ? atoi(dev_env("HCM_GEMM256_MIN_TILES")) : 96;
+    static const int min_n = dev_env("HCM_GEMM256_MIN_N") ? atoi(dev_env("HCM_GEMM256_MIN_N")) : 512;
     return g.N >= min_n && g.M >= 2048 && tiles >= min_tiles && g.K >= 256;
 }
 
@@ -700,7 +700,7 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
             default: return hipErrorInvalidValue;
         }
     }
-    static const bool w4_default = getenv("HCM_GEMM256_W4") != nullptr;
+    static const bool w4_default = dev_env("HCM_GEMM256_W4") != nullptr;
     if (var == 11 || (w4_default && !var)) {
         fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256w_kernel<bf16>) : reinterpret_cast<const void*>(gemm256w_kernel<f16>);
         threads = 256;

@@ -1875,6 +1875,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     constexpr int T_BYTES = KTB * BM * 128, W3_BYTES = KTB * SW * 128;
     constexpr int YS_OFF = T_BYTES + W3_BYTES, YS_BYTES = BM * 128;
     constexpr int W1_OFF = YS_OFF + YS_BYTES, W1_BYTES = CN * 128;      // two buffers
+    constexpr int BIAS_OFF = W1_OFF + 2 * W1_BYTES;                     // f32: the expansion's 4 * C1 biases, then the reduction's CN
     static_assert(A_IT >= 1 && B_IT >= 1 && TN1 >= 1 && TMB >= 1 && TN2 == 2 && TN3 % 2 == 0 && sizeof(T) == 2, "bneck231r tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1920,6 +1921,10 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         }
     };
     load_identity();
+    // both bias vectors, one element per thread: parked in LDS behind phase A, so that nothing in phase B is a global load whose wait would
+    // also wait for the output stores in front of it (vmcnt retires in order)
+    const float b3v = tid < 4 * C1 ? q.b3[tid] : 0.f;
+    const float b1v = tid < CN ? qq.b1[tid] : 0.f;
 
     int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
     const int HoWo = p.Ho * p.Wo;
@@ -2037,6 +2042,11 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     lap(1);
     stage_w3(0);
     stage_w1(0);
+    {
+        float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+        if (tid < 4 * C1) sbias[tid] = b3v;
+        if (tid < CN) sbias[4 * C1 + tid] = b1v;
+    }
     if constexpr (KD > 0) stage_xd();
 #pragma unroll
     for (int i = 0; i < TN1; ++i) {
@@ -2063,12 +2073,13 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     T* const yp = reinterpret_cast<T*>(q.y);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        // the lane's 8 expansion biases of this slice: in flight over the barrier and the MFMAs
         const int nb = nt * SW + wn2 * 32 + coff;
-        const float4 b30 = *reinterpret_cast<const float4*>(q.b3 + nb), b31 = *reinterpret_cast<const float4*>(q.b3 + nb + 4);
-        wait_vmcnt<0>();                                   // this slice's weights (both matrices) have landed (and the bias, the identity rows)
+        // this slice's weights (both matrices) have landed.  They were requested BEFORE the previous slice's output stores were issued (below),
+        // so the wait leaves those TMB stores per lane in flight: a slice never waits for the write acknowledgements of the one before
+        if (nt == 0) wait_vmcnt<0>(); else wait_vmcnt<TMB>();
         __syncthreads();                                   // ... for every wave; parked tile complete; the previous reduction has left the slice block
         lap(2);
+        const float4 b30 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4), b31 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4 + 16);
         f32x4 acc2[TN2][TMB];
 #pragma unroll
         for (int i = 0; i < TN2; ++i)
@@ -2101,6 +2112,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         lap(3);
         // register epilogue of the slice: bias + identity + ReLU, one rounding, 16 bytes per lane to y and into the slice block
         const float bias8[8] = {b30.x, b30.y, b30.z, b30.w, b31.x, b31.y, b31.z, b31.w};
+        uint4 oreg[TMB];
 #pragma unroll
         for (int j = 0; j < TMB; ++j) {
             float v[8];
@@ -2117,14 +2129,20 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
             const uint4 o = pack_chunk<T>(v);
             const int r = wm2 * (BM / WM2) + j * 16 + fr;
-            const int m = m0 + r;
-            if (m < p.M) *reinterpret_cast<uint4*>(yp + (size_t)m * q.ldy3 + nb) = o;
             const int ch = (wn2 * 32 + coff) >> 3;
             *reinterpret_cast<uint4*>(smem + YS_OFF + r * 128 + ((ch ^ (r & 7)) << 4)) = o;
+            oreg[j] = o;
         }
         lap(4);
         __syncthreads();                                   // slice block complete; every wave is done with the expansion weights
         if (nt + 1 < NT) { stage_w3(nt + 1); stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
+        // ... and only now the slice's 16-byte stores to y: younger than the weight requests above, they stay in flight across the next slice's wait
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < TMB; ++j) {
+            const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
+            if (m < p.M) *reinterpret_cast<uint4*>(yp + (size_t)m * q.ldy3 + nb) = oreg[j];
+        }
         {
             const char* sa = smem + YS_OFF;
             const char* sb = smem + W1_OFF + (nt & 1) * W1_BYTES;
@@ -2155,7 +2173,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 #pragma unroll
     for (int i = 0; i < TN3; i += 2) {
         const int nb = wn2 * (CN / WN2) + i * 16 + coff;
-        const float4 b0 = *reinterpret_cast<const float4*>(qq.b1 + nb), b1 = *reinterpret_cast<const float4*>(qq.b1 + nb + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + (4 * C1 + nb) * 4), b1 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + (4 * C1 + nb) * 4 + 16);
         const float bias8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int j = 0; j < TMB; ++j) {
@@ -2189,7 +2207,7 @@ hipError_t igemm_prof_read(unsigned long long* host8, bool reset) {
     std::fill(h.begin(), h.end(), 0ull);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_prof), h.data(), h.size() * 8);
 }
-static bool prof_on() { static const bool on = getenv("HCM_IGEMM_PROF") != nullptr; return on; }
+static bool prof_on() { static const bool on = dev_env("HCM_IGEMM_PROF") != nullptr; return on; }
 
 // variant: 0 = register-staged 2-buffer, 1 = LDS-DMA 2-buffer, 2 = LDS-DMA 3-deep ring, 3 = register-staged with two
 // register sets (prefetch distance 2), 4 / 5 = variants 1 / 2 with 8 waves per workgroup, 6 / 7 = 4 / 5 with the DMA
@@ -2200,7 +2218,7 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
     int grid = tm8 * 8 * d.tilesN;
-    static const char* fmap = getenv("HCM_IGEMM_MAP");
+    static const char* fmap = dev_env("HCM_IGEMM_MAP");
     d.map = fmap ? atoi(fmap) : (((size_t)d.N * d.Kp * sizeof(T) > (2u << 20)) && d.tilesN >= 8 ? 1 : 0);
     if (d.map == 1) {
         if (d.tilesN < 8) d.map = 0;
@@ -2289,7 +2307,7 @@ static hipError_t launch_big(IGemmDev d, int ring, int ilv, hipStream_t s) {
     d.tilesN = (d.N + BN - 1) / BN;
     const int tm8 = (d.tilesM + 7) / 8;
     int grid = tm8 * 8 * d.tilesN;
-    static const char* fmap = getenv("HCM_IGEMM_MAP");
+    static const char* fmap = dev_env("HCM_IGEMM_MAP");
     d.map = fmap ? atoi(fmap) : (((size_t)d.N * d.Kp * sizeof(T) > (2u << 20)) && d.tilesN >= 8 ? 1 : 0);
     if (d.map == 1) {
         if (d.tilesN < 8) d.map = 0;
@@ -2411,7 +2429,7 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     // write-dominated expansions (small K, >= 256 output channels, big M): 64 x 256 tiles write whole 512-byte pixel rows.
     // Stand-alone (no residual, one group) layer1's 64 -> 256 goes 55 -> 45 us; in the step (hi|lo groups, residual) it
     // measured 1.5 % SLOWER end to end, so it stays opt-in.
-    static const int row_tiles = getenv("HCM_IGEMM_ROW256") ? atoi(getenv("HCM_IGEMM_ROW256")) : 0;
+    static const int row_tiles = dev_env("HCM_IGEMM_ROW256") ? atoi(dev_env("HCM_IGEMM_ROW256")) : 0;
     if (row_tiles && dt != DT_F32 && d.N >= 256 && d.N % 256 == 0 && d.K <= 256 && (long)d.M * d.groups >= 32768) return 110;
     const bool longk = d.K >= 768;
     if (d.N <= 32) { tile = 3; variant = d.K >= 2048 ? 2 : 1; }
@@ -2512,7 +2530,7 @@ struct ShapeTimePrinter {
 } g_shape_time_printer;
 }
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
-    static const bool timing = getenv("HCM_IGEMM_TIME") != nullptr;
+    static const bool timing = dev_env("HCM_IGEMM_TIME") != nullptr;
     if (!timing) return launch_igemm_impl(g, dt, s);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -2544,7 +2562,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
 #endif
     if ((g.impl & 15) == 2) return launch_gemm256(g, dt, s);
     if (g.impl == 0) {
-        static const bool no256 = getenv("HCM_NO_GEMM256") != nullptr;
+        static const bool no256 = dev_env("HCM_NO_GEMM256") != nullptr;
         if (!no256 && gemm256_applicable(g, dt)) return launch_gemm256(g, dt, s);
     }
     IGemmDev d;
@@ -2554,7 +2572,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     d.stride_w = g.stride_w > 0 ? g.stride_w : g.stride;
     d.M = g.M; d.N = g.N; d.K = g.K; d.Kp = g.Kp ? g.Kp : g.K;
     d.ldy = g.ldy ? g.ldy : g.N; d.ldr = g.ldr ? g.ldr : g.N; d.act = g.act; d.out_f32 = g.out_f32; d.res_f32 = g.res_f32;
-    static const bool image_epi = getenv("HCM_IGEMM_IMAGE") != nullptr;
+    static const bool image_epi = dev_env("HCM_IGEMM_IMAGE") != nullptr;
     d.image_epi = image_epi ? 1 : 0;
     const int CH = dt_chunk(dt);
     d.cin_shift = 0;
@@ -2638,7 +2656,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     // tuning aid: HCM_IGEMM_SHAPE_FORCE="M,N,K:choice;M,N,K:choice" forces the tile / staging choice of single GEMM shapes inside a whole step
     static const std::unordered_map<std::string, int> shape_force = [] {
         std::unordered_map<std::string, int> m;
-        const char* e = getenv("HCM_IGEMM_SHAPE_FORCE");
+        const char* e = dev_env("HCM_IGEMM_SHAPE_FORCE");
         if (e) {
             std::string v(e);
             size_t pos = 0;
@@ -2657,7 +2675,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         auto it = shape_force.find(std::to_string(d.M) + "," + std::to_string(d.N) + "," + std::to_string(d.K));
         if (it != shape_force.end()) return launch_dt(d, dt, it->second, s);
     }
-    static const char* force = getenv("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
+    static const char* force = dev_env("HCM_IGEMM_FORCE");      // debugging: variant*6 + tile
     if (force && !(narrow_stride && (atoi(force) / 6 == 0 || atoi(force) / 6 == 3))) return launch_dt(d, dt, atoi(force), s);
     const std::string key = shape_key(d, dt);
     int choice = -1;
@@ -2676,7 +2694,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
             choice = heuristic_choice(d, dt);
         }
     }
-    static const bool log_shapes = getenv("HCM_IGEMM_LOG") != nullptr;       // tuning aid: every new shape and its choice, once
+    static const bool log_shapes = dev_env("HCM_IGEMM_LOG") != nullptr;       // tuning aid: every new shape and its choice, once
     if (log_shapes) {
         static std::unordered_map<std::string, int> seen;
         std::lock_guard<std::mutex> l(g_choice_mu);
@@ -2734,9 +2752,9 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             qq.xd = (const char*)b.xd; qq.xdC = b.xdC; qq.xd_bytes = (unsigned)xdb; qq.g_xd = b.g_xd;
             const int BMd = 64;
             // register-epilogue form (bneck231r_kernel, the default) or the LDS-image form (HCM_BNECK_IMAGE=1: A/B and the toggle test); bit-identical
-            static const bool image_d = getenv("HCM_BNECK_IMAGE") != nullptr;
+            static const bool image_d = dev_env("HCM_BNECK_IMAGE") != nullptr;
             size_t ldsd = image_d ? (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BMd * 128 + (size_t)b.CN * 128
-                                  : (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (size_t)BMd * 128 + (size_t)2 * b.CN * 128;
+                                  : (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (size_t)BMd * 128 + (size_t)2 * b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
             const size_t ringd = 3 * (size_t)(BMd + b.C1) * 128;
             if (ringd > ldsd) ldsd = ringd;
             const void* fd = image_d ? (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 64, 64, 1>))
@@ -2746,9 +2764,9 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             void* ad[] = {&qq};
             return hipLaunchKernel(fd, dim3((d.M + BMd - 1) / BMd, d.groups), dim3(512), ad, ldsd, s);
         }
-        static const bool image = getenv("HCM_BNECK_IMAGE") != nullptr;
+        static const bool image = dev_env("HCM_BNECK_IMAGE") != nullptr;
         size_t lds1 = image ? (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128
-                            : (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)2 * b.CN * 128;
+                            : (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)2 * b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
         const size_t ring1 = 3 * (size_t)(BM + b.C1) * 128;
         if (ring1 > lds1) lds1 = ring1;
         const void* f1;

@@ -5,8 +5,18 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <atomic>
+#include <cstdlib>
 
 namespace hcm {
+
+// A/B, tuning and profiling knobs (HCM_NO_*, HCM_IGEMM_*, HCM_GN_*, ...) exist in `make DEV=1` builds only (libhcm_dev.so, loaded with
+// HCM_DEV_LIB=1): the shipped library reads three operational variables -- HCM_GRAPH, HCM_SERIAL, HCM_NO_CALIB -- and nothing else, so no
+// stray environment variable can change which kernel a production step runs.
+#ifdef HCM_DEV_KNOBS
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 // One-time kernel-attribute setup is PER DEVICE (hipFuncSetAttribute acts on the current device): a process-wide flag would leave the
 // second GPU of a process with the default 64 KB dynamic-LDS limit and its 130-160 KB launches failing.

@@ -470,7 +470,7 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
     }
     VlaPost q = p;
 #ifdef HCM_DEV_KNOBS
-    static const int dbg = getenv("HCM_VLA_DBG") ? atoi(getenv("HCM_VLA_DBG")) : 0;      // `make DEV=1` builds only: timing experiments (results then wrong)
+    static const int dbg = dev_env("HCM_VLA_DBG") ? atoi(dev_env("HCM_VLA_DBG")) : 0;      // `make DEV=1` builds only: timing experiments (results then wrong)
     q.dbg = dbg;
 #else
     q.dbg = 0;

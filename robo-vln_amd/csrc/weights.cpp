@@ -795,7 +795,7 @@ void prepare_high(hcm_ctx* ctx) {
     }
     // identical trunk weights in both state_dicts (the reference freezes the pretrained encoders of both models)?
     auto same_trunk = [&](const std::string& prefix) {
-        if (!c.build_low || getenv("HCM_NO_SHARE")) return false;
+        if (!c.build_low || c.reserved[5]) return false;          // hcm_config.reserved[5]: run both models' trunks even when their weights are identical
         size_t n = 0;
         for (const auto& kv : ctx->sd[HCM_HIGH]) {
             if (kv.first.compare(0, prefix.size(), prefix) != 0) continue;
@@ -807,11 +807,11 @@ void prepare_high(hcm_ctx* ctx) {
     };
     h.rgb_shared = c.rgb_encoder == HCM_ENC_RESNET && same_trunk("rgb_encoder.cnn.");
     h.depth_shared = c.depth_encoder == HCM_ENC_RESNET && same_trunk("depth_encoder.visual_encoder.");
-    if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !h.depth_shared && !(getenv("HCM_NO_DEPTH_PAIR") && atoi(getenv("HCM_NO_DEPTH_PAIR")))) {
+    if (c.build_low && c.depth_encoder == HCM_ENC_RESNET && !h.depth_shared && !(dev_env("HCM_NO_DEPTH_PAIR") && atoi(dev_env("HCM_NO_DEPTH_PAIR")))) {
         h.depth_pair = make_gn_trunk_pair(ctx, up, "depth_encoder.visual_encoder.");
         h.has_depth_pair = true;
     }
-    if (c.build_low && c.rgb_encoder == HCM_ENC_RESNET && !h.rgb_shared && !(getenv("HCM_NO_RGB_PAIR") && atoi(getenv("HCM_NO_RGB_PAIR")))) {
+    if (c.build_low && c.rgb_encoder == HCM_ENC_RESNET && !h.rgb_shared && !(dev_env("HCM_NO_RGB_PAIR") && atoi(dev_env("HCM_NO_RGB_PAIR")))) {
         h.rgb_pair = make_tv_trunk_pair(ctx, up, "rgb_encoder.cnn.");
         h.has_rgb_pair = true;
     }

@@ -27,11 +27,13 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None, max_instr_len=None, keep_host_weights=False):
+def _to_struct(cfg: HCMConfig, max_batch, precision, build_high, build_low, sub_precision=None, max_instr_len=None, keep_host_weights=False,
+               share_trunks=True):
     s = _lib.HcmConfigStruct()
     for name, p in (sub_precision or {}).items():
         s.reserved[_SUB_SLOTS[name]] = _SUB_DT[p] + 1
     s.reserved[4] = int(bool(keep_host_weights))
+    s.reserved[5] = int(not share_trunks)
     s.struct_size = C.sizeof(_lib.HcmConfigStruct)
     if precision not in _lib.PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
@@ -70,7 +72,8 @@ class HCMEngine:
     """Owns one libhcm handle (weights + workspace) on one GPU.  One engine per device per thread."""
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
-                 precision="fp16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False, guard_every=64):
+                 precision="fp16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False, guard_every=64,
+                 share_trunks=True):
         """precision (fp32 accumulation, fp32 recurrent cells / heads in every mode):
           "fp16"  fp16 storage + fp16 MFMA tiles in every sub-network, behind the range calibration of hcm_finalize (the measured 16-bit mode:
                   record error 2.6e-3 at B = 64).  A trunk that leaves the fp16 range gets an exact power-of-two range fold (`range_fold`),
@@ -79,6 +82,8 @@ class HCMEngine:
                   range-folded fp16 tiles (on bf16 that trunk alone costs 1.9e-2 of the 1e-2 record tolerance);
           "fp32"  fp32 storage + fp32 MFMA.
         `sub_precision` overrides the storage type per sub-network, e.g. {"depth": "bf16"} or {"bert": "fp16"} (keys: depth, bert, vla, rgb).
+        share_trunks: when the two models' trunk weights are bit-identical (frozen pretrained encoders in both state_dicts) the trunk runs once per
+        step and feeds both heads; False runs it per model (test aid).
         guard_every: act() polls the run-time overflow guard every this many steps without synchronising (hcm_guard_poll) and raises
         FloatingPointError once a recurrent cell has seen non-finite gate pre-activations; 0 disables.
         graph=True: act() runs on an engine-owned stream with engine-owned static I/O buffers, so that libhcm replays
@@ -108,7 +113,7 @@ class HCMEngine:
         self.has_high = high_level_state_dict is not None
         self.has_low = low_level_state_dict is not None
         with torch.cuda.device(self.device):
-            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision, self.max_instr_len, keep_host_weights)
+            st = _to_struct(cfg, max_batch, precision, self.has_high, self.has_low, sub_precision, self.max_instr_len, keep_host_weights, share_trunks)
             _lib.check(self._lib.hcm_create(C.byref(st), C.byref(self._h)))
             try:
                 # load_state_dict(strict=True) semantics (hierarchical_trainer.py:343-345)

@@ -1,6 +1,7 @@
 """Integration check of the fused launches of the RGB trunk (bottleneck tail, next block's reduction, horizontal half of the stem
 max-pool) and of the serial tail (argmax + sub-task embedding inside the high-level cell kernel): they are bit-identical rewrites, so a whole act() step with them must equal the step with every one of them switched off
-(HCM_NO_* knobs; read once per process, hence sub-processes).  The down-sample fold changes one rounding and is compared to
+(HCM_NO_* knobs of the development build libhcm_dev.so -- `make DEV=1`, HCM_DEV_LIB=1: the shipped library has no such knobs --; read once per
+process, hence sub-processes; both sides of every comparison run on the development build, whose kernels are the shipped ones).  The down-sample fold changes one rounding and is compared to
 tolerance.  Covers the slot / pointer plumbing in forward.cpp that the operator-level tests cannot see."""
 import os
 import subprocess
@@ -40,7 +41,7 @@ eng.close()
 
 
 def _run(env_extra, path):
-    env = dict(os.environ)
+    env = dict(os.environ, HCM_DEV_LIB="1")
     env.update(env_extra)
     subprocess.run([sys.executable, "-c", SCRIPT, path], check=True, env=env, cwd=ROOT, timeout=600)
     return dict(np.load(path))

@@ -205,11 +205,7 @@ def test_identical_trunk_weights_are_shared(precision):
         if k.startswith(("rgb_encoder.cnn.", "depth_encoder.visual_encoder.")):
             lo_sd[k] = v
     shared = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision)
-    os.environ["HCM_NO_SHARE"] = "1"
-    try:
-        twice = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision)
-    finally:
-        del os.environ["HCM_NO_SHARE"]
+    twice = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision=precision, share_trunks=False)
     obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, n, seed=6, rgb_uint8=True).items()}
     R = cfg.num_recurrent_layers
     hh = torch.zeros(R, n, cfg.hidden, device="cuda"); lh = torch.zeros(R, n, cfg.hidden, device="cuda")
