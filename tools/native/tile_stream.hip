@@ -27,6 +27,14 @@ extern "C" __global__ __launch_bounds__(512) void tile_stream(const uint4* __res
         y[o] = v;
     }
 }
+// lds_bytes > 0: that much dynamic LDS per workgroup, to pin the number of resident workgroups per CU (160 KB / lds_bytes)
+extern "C" int run_tile_stream_lds(const void* x, const void* res, void* y, int M, int Cin, int N, int use_res, int rows, int cols, int lds_bytes, void* stream) {
+    const int tilesM = (M + rows - 1) / rows, tilesN = N / cols;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(tile_stream, dim3(tilesM * tilesN), dim3(512), lds_bytes, (hipStream_t)stream, (const uint4*)x, (const uint4*)res, (uint4*)y, M, Cin / 8,
+                       N / 8, use_res, rows, cols / 8);
+    return (int)hipGetLastError();
+}
 extern "C" int run_tile_stream(const void* x, const void* res, void* y, int M, int Cin, int N, int use_res, int rows, int cols, void* stream) {
     const int tilesM = (M + rows - 1) / rows, tilesN = N / cols;
     hipLaunchKernelGGL(tile_stream, dim3(tilesM * tilesN), dim3(512), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)res, (uint4*)y, M, Cin / 8,
