@@ -153,7 +153,7 @@ def dominant_kernel_probe(batch, L=80):
 
 
 def hbm_kernel_probe(batch):
-    """Second, HBM-bound probe: the fused bottleneck kernel of the RGB ResNet-50 pair, `bneck231_kernel` (3x3 conv 64->64 + ReLU, 1x1
+    """Second, HBM-bound probe: the fused bottleneck kernel of the RGB ResNet-50 pair, `bneck231r_kernel` (3x3 conv 64->64 + ReLU, 1x1
     expansion 64->256 + identity + ReLU and the next block's 1x1 reduction in one launch), at its layer1 middle-block shape on the
     hi|lo pair workload (M = 2*B*4096 pixels).  Algorithmic bytes = 2 B/elem * M * (64 in + 256 identity + 256 out + 64 next)."""
     import ctypes as C
@@ -182,7 +182,7 @@ def hbm_kernel_probe(batch):
     ms = _time_op(run, 100, 100)
     M = B * H * W
     gbytes = 2.0 * M * (C1 + 2 * C3 + CN) / 1e9
-    return {"kernel": "bneck231_kernel<f16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair (M=2*B*4096)",
+    return {"kernel": "bneck231r_kernel<f16,128,64,64>: conv3x3 64->64 + conv1x1 64->256 + identity + next conv1x1 256->64 @64x64, hi|lo pair (M=2*B*4096)",
             "us_per_launch": round(ms * 1e3, 2), "bound": "hbm", "achieved_TBps": round(gbytes / ms, 3), "peak_TBps": PEAK_HBM_TBPS,
             "frac": round(gbytes / ms / PEAK_HBM_TBPS, 4)}
 
