@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hcm {
 
@@ -133,20 +134,65 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 __device__ __forceinline__ float relu_f(float v) { return __builtin_elementwise_maximum(v, 0.f); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf-GELU for the 16-bit paths: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. 4 orders of magnitude below the
-// rounding of the fp16 / bf16 value it is stored as) in 12 instructions -- one v_rcp, one v_exp, FMAs -- instead of the ~50-instruction
-// branchy libm erff: a 256 x 256 output tile is 128 GELUs per thread, which with erff cost as much as the whole K = 768 main loop of
-// BERT's FFN1 (44.8 -> 35.0 us per launch).  The fp32 path keeps the exact gelu_erf.
+// erf-GELU for the 16-bit paths: erf by Abramowitz-Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (|error| <= 3e-7
+// absolute, i.e. three orders of magnitude below the rounding of the fp16 / bf16 value it is stored as), with 1/sqrt(2) folded into the
+// coefficients (the polynomial is in |x|) and the sign handled by the identity
+//     gelu(x) = 0.5 (x + |x| erf(|x| / sqrt 2)) = 0.5 (x + |x| (1 - r)),      r = p(|x|)^-16
+// -- per element one v_and (|x|), one quarter-rate v_rcp, and 6 FMAs + 4 squarings + 3 more operations that all pack two elements per
+// instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): 8.5 issue slots + the rcp, against the ~50-instruction branchy libm erff (a
+// 256 x 256 output tile is 128 GELUs per thread, which with erff cost as much as the whole K = 768 main loop of BERT's FFN1: 44.8 -> 35.0 us
+// per launch) and round 2's 7.1.26 form (v_rcp + v_exp, 11 slots + two quarter-rate instructions; stand-alone FFN1 35.5 -> 34.4 us).
+// NaN -> NaN, -inf -> NaN as torch's formula gives them; +inf -> NaN where torch keeps +inf (non-finite either way: the next LayerNorm
+// turns both into NaN, and the recurrent cells' guard counts it).  The fp32 path keeps the exact gelu_erf.
+constexpr float kGeluA1 = 0.04986734688282013f, kGeluA2 = 0.02114100567996502f, kGeluA3 = 0.0032776263542473316f,
+                kGeluA4 = 3.8003574445610866e-05f, kGeluA5 = 4.889063711743802e-05f, kGeluA6 = 5.38297490493278e-06f;
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float ax = fabsf(x);
+    float p = fmaf(ax, fmaf(ax, fmaf(ax, fmaf(ax, fmaf(ax, fmaf(ax, kGeluA6, kGeluA5), kGeluA4), kGeluA3), kGeluA2), kGeluA1), 1.0f);
+    p *= p; p *= p; p *= p; p *= p;                                   // p^16 (overflows to inf from |x| ~ 16: r = 0, erf = 1)
+    const float r = __builtin_amdgcn_rcpf(p);                         // 1 - erf(|x| / sqrt 2)
+    return 0.5f * (x + fmaf(-ax, r, ax));
 }
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_fast(x); }
 template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_erf(x); }
+// GELU of N (even) values in place: gelu_fast's operations on 2-vectors so that they come out as v_pk_*_f32 (with scalar code the compiler
+// prefers v_fmaak_f32 with the coefficient as a literal, one element per instruction), and stage by stage over all N / 2 pairs (not pair by
+// pair: a pair's chain is ~14 DEPENDENT operations and the epilogues run with two waves per SIMD).  Bit-identical to gelu_fast.
+typedef float dev_f2 __attribute__((ext_vector_type(2)));
+template <typename T, int N> __device__ __forceinline__ void gelu_vec(float (&v)[N]) {
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = gelu_erf(v[e]);
+    } else {
+        constexpr int H = N / 2;
+        dev_f2 x[H], ax[H], p[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { x[h] = (dev_f2){v[2 * h], v[2 * h + 1]}; ax[h] = __builtin_elementwise_abs(x[h]); }
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], (dev_f2)(kGeluA6), (dev_f2)(kGeluA5));
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], p[h], (dev_f2)(kGeluA4));
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], p[h], (dev_f2)(kGeluA3));
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], p[h], (dev_f2)(kGeluA2));
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], p[h], (dev_f2)(kGeluA1));
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] = __builtin_elementwise_fma(ax[h], p[h], (dev_f2)(1.0f));
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+            for (int h = 0; h < H; ++h) p[h] *= p[h];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { p[h].x = __builtin_amdgcn_rcpf(p[h].x); p[h].y = __builtin_amdgcn_rcpf(p[h].y); }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const dev_f2 g = (dev_f2)(0.5f) * (x[h] + __builtin_elementwise_fma(-ax[h], p[h], ax[h]));
+            v[2 * h] = g.x; v[2 * h + 1] = g.y;
+        }
+    }
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace hcm

@@ -340,8 +340,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+                        gelu_vec<T, 8>(v);
                     }
                     st_chunk(reinterpret_cast<T*>(p.y + ((size_t)m * p.ldy + n) * 2), v);
                 }
@@ -351,10 +350,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
         return;
     }
     // ---- epilogue: acc + bias, activation, one rounding -> 16-bit tile image in LDS -> 16-byte stores of whole rows.
-    // In two halves of the wave's rows (fragments 0-3 / 4-7, i.e. tile rows {0-63, 128-191} / {64-127, 192-255}): the stores of the first
-    // half are in flight while the second half's bias / activation / rounding arithmetic runs (FFN1's 128 GELUs per thread are ~6 us of
-    // VALU work, the tile's 128 KB of stores ~7 us of drain).
+    // In NP = 2 parts of the wave's rows (fragment rows 0-3 / 4-7, i.e. tile rows {64 q .. 64 q + 63} of both row groups): the stores of
+    // the first part are in flight while the second part's bias / activation / rounding arithmetic runs (FFN1's 128 GELUs per thread are
+    // ~6 us of VALU work, the tile's 128 KB of stores ~6 us of drain).  NP = 4 measured no better (FFN1 34.3 vs 33.6 us, no-activation
+    // shapes 0.4 us faster: inside the box-to-box noise).  The image rows of the parts are disjoint: one barrier per part.
     {
+        constexpr int NP = 2, JP = 8 / NP, RP = JP * 16;          // parts, fragment rows per part, tile rows per part and row group
         float4 b4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -364,23 +365,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
         const int chunk = tid & 31;                    // 16-byte piece of a 512-byte row
         const int n = n0 + chunk * 8;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int part = 0; part < NP; ++part) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = half * 4 + jj;
+            for (int jj = 0; jj < JP; ++jj) {
+                const int j = part * JP + jj;
+                // the fragment row's 16 values at once: eight independent GELU chains for the scheduler to interleave (a chain is ~14 dependent
+                // packed-f32 operations; taken four values at a time, with the activation switch inside, the epilogue was latency-bound)
+                float v[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v[4] = {acc[i][j][0] + b4[i].x, acc[i][j][1] + b4[i].y, acc[i][j][2] + b4[i].z, acc[i][j][3] + b4[i].w};
-                    if (p.act == ACT_RELU) {
+                    v[i * 4 + 0] = acc[i][j][0] + b4[i].x; v[i * 4 + 1] = acc[i][j][1] + b4[i].y;
+                    v[i * 4 + 2] = acc[i][j][2] + b4[i].z; v[i * 4 + 3] = acc[i][j][3] + b4[i].w;
+                }
+                if (p.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-                    } else if (p.act == ACT_GELU) {
+                    for (int e = 0; e < 16; ++e) v[e] = relu_f(v[e]);
+                } else if (p.act == ACT_GELU) {
+                    gelu_vec<T, 16>(v);
+                }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
-                    }
+                for (int i = 0; i < 4; ++i) {
                     T o4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                    for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[i * 4 + e]);
                     const int r = wr * 128 + j * 16 + fr;
                     const int cb = (wc * 64 + i * 16 + fg * 4) * 2;
                     *reinterpret_cast<uint2*>(smem + r * G_IMG_LD + cb) = *reinterpret_cast<const uint2*>(o4);
@@ -389,9 +396,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
             __syncthreads();
             if (n < p.N) {                             // N % 8 == 0 (launcher)
 #pragma unroll
-                for (int pass = 0; pass < 8; ++pass) {
-                    const int rr = pass * 16 + (tid >> 5);                      // 0..127 over the half's rows
-                    const int r = (rr >> 6) * 128 + half * 64 + (rr & 63);
+                for (int pass = 0; pass < 2 * RP / 16; ++pass) {
+                    const int rr = pass * 16 + (tid >> 5);                      // 0 .. 2 RP - 1 over the part's rows
+                    const int r = (rr / RP) * 128 + part * RP + (rr % RP);
                     const int m = m0 + r;
                     if (m < p.M)
                         *reinterpret_cast<uint4*>(p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const uint4*>(smem + r * G_IMG_LD + chunk * 16);
@@ -578,8 +585,7 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+                        gelu_vec<T, 8>(v);
                     }
                     st_chunk(reinterpret_cast<T*>(p.y + ((size_t)m * p.ldy + n) * 2), v);
                 }
@@ -610,8 +616,7 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                     } else if (p.act == ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+                        gelu_vec<T, 4>(v);
                     }
                     T o4[4];
 #pragma unroll

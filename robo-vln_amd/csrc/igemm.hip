@@ -301,8 +301,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
         } else if (p.act == ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+            gelu_vec<T, 8>(v);
         }
         if (p.out_f32 || sizeof(T) == 4) {
             float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
@@ -542,8 +541,7 @@ __device__ __forceinline__ void igemm_epilogue_split(const IGemmDev& p, f32x4 (&
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
         } else if (p.act == ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+            gelu_vec<T, 8>(v);
         }
         if (p.out_f32 || sizeof(T) == 4) {
             float* yp = reinterpret_cast<float*>(p.y) + (size_t)m * p.ldy + n;
@@ -869,8 +867,7 @@ __device__ __forceinline__ void igemm_epilogue_regs(const IGemmDev& p, f32x4 (&a
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
             } else if (p.act == ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+                gelu_vec<T, 8>(v);
             }
             if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = pack_chunk<T>(v);
         }
