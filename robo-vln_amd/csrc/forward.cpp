@@ -90,7 +90,8 @@ struct Fwd {
             if (!no_cs && !w.bias && groupnorm_apply_ok(w.dt, hw, C, G) && w.Cout % cg == 0) {
                 float* stats = alloc_f(gn_stats_floats(in.B, hw, G));
                 conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo, nullptr, 0, stats, cg, hw, G);
-                if (!dry) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, eps, relu ? 1 : 0, s), "groupnorm apply");
+                static const bool skip_apply = dev_env("HCM_SKIP_GN_APPLY") != nullptr;
+                if (!dry && !skip_apply) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, eps, relu ? 1 : 0, s), "groupnorm apply");
                 return;
             }
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
@@ -249,7 +250,12 @@ struct Fwd {
         int xi = 1;
         int bidx = 0;
         int pre = -1;          // slot already holding THIS block's 1x1 reduction output (computed by the previous block's fused launch)
+        // (development build, timing only -- the results are then wrong: HCM_GN_STOP=<k> drops the launches of the GroupNorm trunks' blocks
+        //  k.. and of the compression conv, HCM_SKIP_GN_APPLY=1 the stand-alone normalisation passes)
+        static const int gn_stop = dev_env("HCM_GN_STOP") ? atoi(dev_env("HCM_GN_STOP")) : -1;
+        const bool dry_saved = dry;
         for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
+            if (t.gn && gn_stop >= 0 && (int)bi >= gn_stop) dry = true;
             const BottleneckW& b = t.blocks[bi];
             int fr[3], nf = 0;
             if (pre >= 0) fr[nf++] = pre;
@@ -342,6 +348,7 @@ struct Fwd {
             conv_gn(t.compress, x, slot[fr], 1, 1, nullptr, t.n_compress, t.pair ? 2 : 1, true, x.H, x.W, t.compress_true);
             x = Act{slot[fr], B, x.H, x.W, CO(t.compress)};
         }
+        dry = dry_saved;
         return x;
     }
 

@@ -1846,7 +1846,23 @@ __global__ __launch_bounds__(512, 4) void bneck231_kernel(Bneck231Dev qq) {     
 // 16 bytes twice: to y, and into the slice block in LDS that the next block's reduction reads as its MFMA operand.  Per slice that leaves TWO
 // barriers (weights landed / slice block complete); the reduction's weight slices are double-buffered so that nothing else has to be waited
 // for.  Same MFMA sequence, same f32 operations in the same order as bneck231_kernel: bit-identical to it and to the stand-alone launches.
-template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false>
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// NWB > 0: HALO phase A.  A lone workgroup's phase profile (B = 8: one tile per CU, every byte out of L2 / the Infinity Cache) says what a
+// pixel tile's 12 us are: 3 us until the first barrier and 0.43 us per K iteration of the 3x3 conv for 8 MFMAs (0.05 us) -- the iteration
+// waits for its 24 KB tap tile, requested two iterations earlier through a 3-deep ring, and an L2 -> LDS request takes ~0.85 us to land: a
+// latency chain, L / 2 per tap, that no amount of HBM bandwidth shortens (the launch takes the same 21-23 us per round of resident
+// workgroups whether its maps stream from HBM or sit in the Infinity Cache).  Here the tile's input rows are staged ONCE, with their
+// one-pixel halo (a tile is whole image rows: (R + 2) x (W + 2) pixels, zero-filled outside the image by the buffer range check), the nine
+// taps read shifted windows of that block, and only the 8 KB weight tile of a tap still streams -- through an NWB-deep ring whose first
+// NWB - 1 tiles are requested with the halo block, so that all nine are in flight within the first four iterations.  The identity rows are
+// requested right BEHIND the last weight tile instead of first: vmcnt retires in order, so with them in front every wait of phase A also
+// waited for the tile's 64 KB of identity (an earlier halo form with a 4-deep ring and the identity in front measured no gain for exactly
+// that reason).  MFMA sequence and f32 operations unchanged: bit-identical to the NWB = 0 form.  Needs stride 1, C1 = 64, a tile of whole rows
+// of one image, W a multiple of 16 (launch_bneck23 checks; else NWB = 0).
+template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false, int NWB = 0>
 __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     // phase timing (HCM_IGEMM_PROF=1 builds, read through hcm_debug_igemm_prof): per-wave cycle totals [0] prologue up to the first barrier,
     // [1] phase A K loop, [2] park + top-of-slice waits and barriers, [3] expansion MFMAs, [4] register epilogues, [5] slice-block barrier +
@@ -1857,8 +1873,10 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         if constexpr (PROF) { const unsigned long long t = prof_now(); pt[slot] += t - t_prev; t_prev = t; }
     };
     BneckDev& q = qq.t;
-    constexpr int NW = 8, WMc = 2, WNc = 4, CH = 8, BK = 64, SW = 64;
-    constexpr int TM = BM / WMc / 16;              // phase A: BM / 2 pixels x C1 / 4 channels per wave
+    // phase A wave grid: 2 (pixels) x 4 (channels); the halo form with its 64 mid channels takes 4 x 2 -- 32 pixels x 32 channels per wave, four
+    // fragment reads per four MFMAs instead of five: the K loop there is bound by the LDS read rate (80 KB of fragments per tap and tile)
+    constexpr int NW = 8, WMc = NWB > 0 ? 4 : 2, WNc = NWB > 0 ? 2 : 4, CH = 8, BK = 64, SW = 64;
+    constexpr int TM = BM / WMc / 16;              // phase A: BM / WMc pixels x C1 / WNc channels per wave
     constexpr int TN1 = C1 / WNc / 16;
     constexpr int WM2 = 4, WN2 = 2;                // phase B: BM / 4 pixels x 32 channels (of a slice) or CN / 2 channels (reduction) per wave
     constexpr int TMB = BM / WM2 / 16;
@@ -1917,7 +1935,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
                 }
         }
     };
-    load_identity();
+    if constexpr (NWB == 0) load_identity();
     // both bias vectors, one element per thread: parked in LDS behind phase A, so that nothing in phase B is a global load whose wait would
     // also wait for the output stores in front of it (vmcnt retires in order)
     const float b3v = tid < 4 * C1 ? q.b3[tid] : 0.f;
@@ -2002,6 +2020,84 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         for (int j = 0; j < TM; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (p.K + BK - 1) / BK;
     constexpr int LPT = A_IT + B_IT;
+    if constexpr (NWB > 0) {
+        static_assert(KT1 == 1 && NWB >= 2, "halo phase A: 64 mid channels");
+        constexpr int NK = 9, D = NWB - 1, NID = KD == 0 ? NT * TMB : 0;
+        constexpr int ND0 = D < NK ? D : NK;                 // weight tiles requested with the halo block
+        constexpr int ID_AT = NK - 1 - D;                    // the iteration that requests the last weight tile (< 0: all went out up front)
+        // halo geometry: the tile is R whole rows of one image's W-wide map; halo rows hy = 0 .. R + 1 <-> input rows oy0 - 1 + hy, columns
+        // hx = 0 .. W + 1 <-> input columns hx - 1; HRP (a multiple of 8) LDS rows of 128 B
+        const int Wm = p.W, Wp = Wm + 2, R = BM / Wm, HR = (R + 2) * Wp, HRP = (HR + 7) & ~7;
+        const int img = m0 / HoWo, oy0 = (m0 - img * HoWo) / Wm, pix0 = img * p.H * p.W;
+        const unsigned WR_OFF = (unsigned)(HRP * 128);
+        {
+            const int n_instr = HRP / 8;
+            for (int i = wave; i < n_instr; i += NW) {
+                const int hr = i * 8 + rin;
+                const int hy = hr / Wp, hx = hr - hy * Wp;
+                const int iy = oy0 - 1 + hy, ix = hx - 1;
+                const bool ok = (hr < HR) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = (unsigned)((pix0 + iy * p.W + ix) * p.xC + c * CH) * 2u;
+                dma16(__builtin_amdgcn_readfirstlane(lds_base + i * 1024), ok ? off : 0xFFFFFFFFu, rx);
+            }
+        }
+        auto stage_w = [&](int kt, int slot) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = (wave + NW * i) * 8 + rin;
+                const unsigned off = (unsigned)(n * p.Kp + kt * BK + c * CH) * 2u;
+                dma16(__builtin_amdgcn_readfirstlane(lds_base + WR_OFF + slot * (C1 * 128) + (wave + NW * i) * 1024), off, rw);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < ND0; ++t) stage_w(t, t);
+        if constexpr (ID_AT < 0) load_identity();
+        wait_vmcnt<(ND0 - 1) * B_IT + (ID_AT < 0 ? NID : 0)>();      // the halo block and weight tile 0 have landed
+        __builtin_amdgcn_s_barrier();
+        lap(0);
+        int hr0[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * (BM / WMc) + j * 16 + fr;
+            const int ry = r / Wm;
+            hr0[j] = ry * Wp + (r - ry * Wm);
+        }
+        static_for<0, NK>([&](auto KT) {
+            constexpr int kt = decltype(KT)::value;
+            if constexpr (kt + D < NK) stage_w(kt + D, (kt + D) % NWB);      // into the slot tile kt - 1 was read from (every wave has left it)
+            if constexpr (kt == ID_AT) load_identity();                      // behind the last operand request
+            constexpr int kh = kt / 3, kw = kt - kh * 3;
+            const int dhr = kh * Wp + kw;
+            const char* sa = smem;
+            const char* sb = smem + WR_OFF + (kt % NWB) * (C1 * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xa[TM], wb[TN1];
+                const int chunk = ks * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int hr = hr0[j] + dhr;
+                    xa[j] = *reinterpret_cast<const uint4*>(sa + hr * 128 + ((chunk ^ (hr & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN1; ++i) {
+                    const int r = wn * (C1 / WNc) + i * 16 + fr;
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
+            }
+            if constexpr (kt + 1 < NK) {
+                // weight tile kt + 1 must have landed; what was requested after it (younger tiles, the identity rows) stays in flight
+                constexpr int last = kt + D < NK - 1 ? kt + D : NK - 1;
+                wait_vmcnt<(last - (kt + 1)) * B_IT + (kt >= ID_AT ? NID : 0)>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        });
+    } else {
     stage(0, 0);
     if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
@@ -2035,6 +2131,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
+    }
     }
     lap(1);
     stage_w3(0);
@@ -2703,6 +2800,8 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
 }
 
 
+constexpr int kHaloRing = 5, kHaloRingD = 5;       // weight-tile ring depth of the halo phase A (128-pixel tiles / the 64-pixel tile of the folded down-sample block)
+
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
     if ((b.C1 != 64 && b.C1 != 128) || (!b.res && !b.xd) || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
@@ -2756,6 +2855,17 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             if (ringd > ldsd) ldsd = ringd;
             const void* fd = image_d ? (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231_kernel<f16, 64, 64, 64, 1>))
                                      : (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 64, 64, 1>));
+            // halo phase A (see bneck231r_kernel): a tile of whole rows of one image
+            static const bool no_halo_d = dev_env("HCM_NO_BNECK_HALO") != nullptr;
+            if (!image_d && !no_halo_d && b.stride == 1 && d.W % 16 == 0 && BMd % d.W == 0 && (d.Ho * d.Wo) % BMd == 0) {
+                const size_t halo = (size_t)((((BMd / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRingD * 64 * 128;
+                if (halo <= 80 * 1024) {
+                    ldsd = (size_t)2 * BMd * 128 + (size_t)2 * 64 * 128 + (size_t)BMd * 128 + (size_t)2 * b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
+                    if (halo > ldsd) ldsd = halo;
+                    fd = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 64, 64, 1, false, kHaloRingD>)
+                                       : reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 64, 64, 1, false, kHaloRingD>);
+                }
+            }
             hipError_t ed = hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (ed != hipSuccess) return ed;
             void* ad[] = {&qq};
@@ -2778,9 +2888,26 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128>)
                     : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128>);
         }
+        static const bool no_halo = dev_env("HCM_NO_BNECK_HALO") != nullptr;
+        bool halo_on = false;
+        if (!image && !no_halo && b.C1 == 64 && b.stride == 1 && d.W % 16 == 0 && BM % d.W == 0 && (d.Ho * d.Wo) % BM == 0) {
+            const size_t halo = (size_t)((((BM / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 64 * 128;
+            if (halo <= 80 * 1024) {
+                halo_on = true;
+                // (the 3-deep ring of whole tap tiles is not used by this form: the phase-B regions or the halo block + weight ring decide)
+                lds1 = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)2 * b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
+                if (halo > lds1) lds1 = halo;
+                if (dt == DT_BF16) f1 = b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 64, 0, false, kHaloRing>)
+                                                   : reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 128, 0, false, kHaloRing>);
+                else f1 = b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, false, kHaloRing>)
+                                     : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128, 0, false, kHaloRing>);
+            }
+        }
 #ifdef HCM_DEV_KNOBS
-        if (!image && prof_on() && dt == DT_F16 && b.C1 == 64 && b.CN == 64) f1 = reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true>);
+        if (!image && prof_on() && dt == DT_F16 && b.C1 == 64 && b.CN == 64)
+            f1 = halo_on ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true, kHaloRing>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true>);
 #endif
+        (void)halo_on;
         hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e1 != hipSuccess) return e1;
         void* a1[] = {&qq};

@@ -1,13 +1,5 @@
-mkdir -p gpurun_out/r3i
-export HCM_DEV_LIB=1
-for i in 1 2; do
- for v in none low high; do
-  if [ $v = none ]; then unset HCM_AUX_PRIO; else export HCM_AUX_PRIO=$v; fi
-  python bench.py --no-cpu-baseline --sustain 0 --steps 100 --no-kernel-probe 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'])"
-  HCM_GRAPH=0 python bench.py --no-cpu-baseline --sustain 0 --steps 100 --no-kernel-probe 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v nograph', d['value'], d['ms_per_step'])"
- done
-done
-unset HCM_AUX_PRIO; unset HCM_DEV_LIB
+python -m pytest tests/test_fusion_toggles_gpu.py -q -x 2>&1 | tail -2
+python -m pytest tests/test_parity_gpu.py -q -x -k "cfg1 or cfg0 or batch64" 2>&1 | tail -2
 cp robo-vln_amd/libhcm.so /tmp/new.so
 for i in 1 2; do
   cp robo-vln_amd/libhcm_prev.so robo-vln_amd/libhcm.so; python bench.py --no-cpu-baseline --sustain 0 --steps 100 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('prev', d['value'], d['ms_per_step'], d['roofline']['frac'])"
