@@ -1930,12 +1930,13 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < TMB; ++j) {
-                    const int m = m0 + wm2 * (BM / WM2) + j * 16 + fr;
-                    if (m < p.M) rpre[nt][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
+                    // (rows past M read row M - 1 and are never stored: the loads are unconditional so that every wave has exactly NT * TMB of
+                    //  them in its queue -- the counted waits of phase A rely on it)
+                    const int m = min(m0 + wm2 * (BM / WM2) + j * 16 + fr, p.M - 1);
+                    rpre[nt][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
                 }
         }
     };
-    if constexpr (NWB == 0) load_identity();
     // both bias vectors, one element per thread: parked in LDS behind phase A, so that nothing in phase B is a global load whose wait would
     // also wait for the output stores in front of it (vmcnt retires in order)
     const float b3v = tid < 4 * C1 ? q.b3[tid] : 0.f;
@@ -2098,14 +2099,20 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             __builtin_amdgcn_s_barrier();
         });
     } else {
+    // the 3-deep ring of whole tap tiles.  The identity rows are requested right behind the LAST tile request (iteration nk - 3): in front,
+    // every wait of the loop would also wait for them (vmcnt retires in order) -- the first tile then comes up a whole identity fetch late
+    constexpr int NID = KD == 0 ? NT * TMB : 0;
     stage(0, 0);
-    if (nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    if (nk > 1) { stage(1, 1); if (nk == 2) load_identity(); }
+    else load_identity();
+    if (nk > 2) wait_vmcnt<LPT>(); else if (nk == 2) wait_vmcnt<LPT + NID>(); else wait_vmcnt<NID>();
     __builtin_amdgcn_s_barrier();
     lap(0);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 2 < nk;
         if (more) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        if (kt + 3 == nk) load_identity();
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -2127,7 +2134,9 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
         }
-        if (more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        // tile kt + 1 has landed; younger: tile kt + 2 (if any) and, from iteration nk - 3 on, the identity rows
+        if (more) { if (kt + 3 == nk) wait_vmcnt<LPT + NID>(); else wait_vmcnt<LPT>(); }
+        else if (kt + 1 < nk) wait_vmcnt<NID>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
@@ -2906,6 +2915,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
 #ifdef HCM_DEV_KNOBS
         if (!image && prof_on() && dt == DT_F16 && b.C1 == 64 && b.CN == 64)
             f1 = halo_on ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true, kHaloRing>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true>);
+        if (!image && prof_on() && dt == DT_F16 && b.C1 == 128 && b.CN == 128) f1 = reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128, 0, true>);
 #endif
         (void)halo_on;
         hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -1,5 +1,6 @@
-python -m pytest tests/test_fusion_toggles_gpu.py -q -x 2>&1 | tail -2
-python -m pytest tests/test_parity_gpu.py -q -x -k "cfg1 or cfg0 or batch64" 2>&1 | tail -2
+python -m pytest tests/test_ops_gpu.py -q -k "bottleneck or bneck" 2>&1 | tail -2
+python -m pytest tests/test_fusion_toggles_gpu.py -q -x -k "rgb_trunk" 2>&1 | tail -2
+python tools/bneck_bench.py 2>/dev/null | grep "fused incl"
 cp robo-vln_amd/libhcm.so /tmp/new.so
 for i in 1 2; do
   cp robo-vln_amd/libhcm_prev.so robo-vln_amd/libhcm.so; python bench.py --no-cpu-baseline --sustain 0 --steps 100 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('prev', d['value'], d['ms_per_step'], d['roofline']['frac'])"

@@ -8,7 +8,8 @@ from robo_vln_amd import _lib
 assert os.environ.get("HCM_IGEMM_PROF") and os.environ.get("HCM_DEV_LIB"), "set HCM_DEV_LIB=1 HCM_IGEMM_PROF=1"
 lib = _lib.lib()
 B, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 64)
-C1, CN, tdt = 64, 64, torch.float16
+C1 = int(sys.argv[3]) if len(sys.argv) > 3 else 64          # 64 (layer1 shape, @64) or 128 (layer2 shape, @32)
+CN, tdt = C1, torch.float16
 P = lambda t: t.data_ptr()
 x = torch.randn(B, H, H, C1, device="cuda").to(tdt)
 w2 = (torch.randn(C1, 3, 3, C1, device="cuda") * 0.05).to(tdt); b2 = torch.randn(C1, device="cuda")
