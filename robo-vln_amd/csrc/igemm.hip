@@ -1862,7 +1862,10 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // waited for the tile's 64 KB of identity (an earlier halo form with a 4-deep ring and the identity in front measured no gain for exactly
 // that reason).  MFMA sequence and f32 operations unchanged: bit-identical to the NWB = 0 form.  Needs stride 1, C1 = 64, a tile of whole rows
 // of one image, W a multiple of 16 (launch_bneck23 checks; else NWB = 0).
-template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false, int NWB = 0>
+// W1B = 1: ONE buffer for the reduction's weight slice instead of two (the 128-pixel tile of the folded-down-sample block needs the 8 KB: its
+// parked tile is two K blocks deep).  The slice is then requested behind the top-of-slice barrier -- every wave has left the previous
+// reduction -- and waited for at the slice-block barrier, a whole expansion + epilogue later.
+template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false, int NWB = 0, int W1B = 2>
 __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     // phase timing (HCM_IGEMM_PROF=1 builds, read through hcm_debug_igemm_prof): per-wave cycle totals [0] prologue up to the first barrier,
     // [1] phase A K loop, [2] park + top-of-slice waits and barriers, [3] expansion MFMAs, [4] register epilogues, [5] slice-block barrier +
@@ -1890,7 +1893,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     constexpr int T_BYTES = KTB * BM * 128, W3_BYTES = KTB * SW * 128;
     constexpr int YS_OFF = T_BYTES + W3_BYTES, YS_BYTES = BM * 128;
     constexpr int W1_OFF = YS_OFF + YS_BYTES, W1_BYTES = CN * 128;      // two buffers
-    constexpr int BIAS_OFF = W1_OFF + 2 * W1_BYTES;                     // f32: the expansion's 4 * C1 biases, then the reduction's CN
+    constexpr int BIAS_OFF = W1_OFF + W1B * W1_BYTES;                   // f32: the expansion's 4 * C1 biases, then the reduction's CN
     static_assert(A_IT >= 1 && B_IT >= 1 && TN1 >= 1 && TMB >= 1 && TN2 == 2 && TN3 % 2 == 0 && sizeof(T) == 2, "bneck231r tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2009,7 +2012,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         for (int i = 0; i < CN / 8 / NW; ++i) {
             const int n = (wave + NW * i) * 8 + rin;
             const unsigned off = (unsigned)(n * (4 * C1) + nt * SW + c * CH) * 2u;
-            dma16(lds_base + W1_OFF + (nt & 1) * W1_BYTES + (wave + NW * i) * 1024, off, rw1);
+            dma16(lds_base + W1_OFF + (nt % W1B) * W1_BYTES + (wave + NW * i) * 1024, off, rw1);
         }
     };
 
@@ -2181,6 +2184,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         // so the wait leaves those TMB stores per lane in flight: a slice never waits for the write acknowledgements of the one before
         if (nt == 0) wait_vmcnt<0>(); else wait_vmcnt<TMB>();
         __syncthreads();                                   // ... for every wave; parked tile complete; the previous reduction has left the slice block
+        if constexpr (W1B == 1) { if (nt > 0) stage_w1(nt); }
         lap(2);
         const float4 b30 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4), b31 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4 + 16);
         f32x4 acc2[TN2][TMB];
@@ -2237,8 +2241,9 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             oreg[j] = o;
         }
         lap(4);
+        if constexpr (W1B == 1) wait_vmcnt<0>();           // this slice's reduction weights (requested at the top of the slice; the stores in front of them are a slice old)
         __syncthreads();                                   // slice block complete; every wave is done with the expansion weights
-        if (nt + 1 < NT) { stage_w3(nt + 1); stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
+        if (nt + 1 < NT) { stage_w3(nt + 1); if constexpr (W1B == 2) stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
         // ... and only now the slice's 16-byte stores to y: younger than the weight requests above, they stay in flight across the next slice's wait
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -2248,7 +2253,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         }
         {
             const char* sa = smem + YS_OFF;
-            const char* sb = smem + W1_OFF + (nt & 1) * W1_BYTES;
+            const char* sb = smem + W1_OFF + (nt % W1B) * W1_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 xa[TMB], wb[TN3];
@@ -2866,6 +2871,21 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
                                      : (dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 64, 64, 1>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 64, 64, 1>));
             // halo phase A (see bneck231r_kernel): a tile of whole rows of one image
             static const bool no_halo_d = dev_env("HCM_NO_BNECK_HALO") != nullptr;
+            // 128-pixel tiles (one buffer for the reduction's weight slice, halo phase A) where the map allows: per-tile fixed costs halve
+            static const bool no_big_d = dev_env("HCM_NO_BNECK_DS128") != nullptr;
+            if (!image_d && !no_halo_d && !no_big_d && b.stride == 1 && d.W % 16 == 0 && 128 % d.W == 0 && (d.Ho * d.Wo) % 128 == 0) {
+                const size_t halo = (size_t)((((128 / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 64 * 128;
+                size_t lds = (size_t)2 * 128 * 128 + (size_t)2 * 64 * 128 + (size_t)128 * 128 + (size_t)b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
+                if (halo > lds) lds = halo;
+                if (lds <= 80 * 1024) {
+                    const void* fb = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 64, 1, false, kHaloRing, 1>)
+                                                   : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 1, false, kHaloRing, 1>);
+                    hipError_t eb = hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (eb != hipSuccess) return eb;
+                    void* ab[] = {&qq};
+                    return hipLaunchKernel(fb, dim3((d.M + 127) / 128, d.groups), dim3(512), ab, lds, s);
+                }
+            }
             if (!image_d && !no_halo_d && b.stride == 1 && d.W % 16 == 0 && BMd % d.W == 0 && (d.Ho * d.Wo) % BMd == 0) {
                 const size_t halo = (size_t)((((BMd / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRingD * 64 * 128;
                 if (halo <= 80 * 1024) {

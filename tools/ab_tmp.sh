@@ -1,8 +1,4 @@
-python -m pytest tests/test_ops_gpu.py -q -k "bottleneck or bneck" 2>&1 | tail -2
+python -m pytest tests/test_ops_gpu.py -q -k "bottleneck or bneck or fold or down" 2>&1 | tail -2
 python -m pytest tests/test_fusion_toggles_gpu.py -q -x -k "rgb_trunk" 2>&1 | tail -2
-python tools/bneck_bench.py 2>/dev/null | grep "fused incl"
-cp robo-vln_amd/libhcm.so /tmp/new.so
-for i in 1 2; do
-  cp robo-vln_amd/libhcm_prev.so robo-vln_amd/libhcm.so; python bench.py --no-cpu-baseline --sustain 0 --steps 100 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('prev', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-  cp /tmp/new.so robo-vln_amd/libhcm.so; python bench.py --no-cpu-baseline --sustain 0 --steps 100 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('new', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-done
+bash tools/profile_bench.sh r3d 1 ktonly > /dev/null 2>&1
+grep "bneck" gpurun_out/prof_r3d_cfg1/r3d_kernel_trace_bench.md | cut -c1-140
