@@ -1878,7 +1878,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     BneckDev& q = qq.t;
     // phase A wave grid: 2 (pixels) x 4 (channels); the halo form with its 64 mid channels takes 4 x 2 -- 32 pixels x 32 channels per wave, four
     // fragment reads per four MFMAs instead of five: the K loop there is bound by the LDS read rate (80 KB of fragments per tap and tile)
-    constexpr int NW = 8, WMc = NWB > 0 ? 4 : 2, WNc = NWB > 0 ? 2 : 4, CH = 8, BK = 64, SW = 64;
+    constexpr int NW = 8, WMc = (NWB > 0 && C1 == 64) ? 4 : 2, WNc = (NWB > 0 && C1 == 64) ? 2 : 4, CH = 8, BK = 64, SW = 64;
     constexpr int TM = BM / WMc / 16;              // phase A: BM / WMc pixels x C1 / WNc channels per wave
     constexpr int TN1 = C1 / WNc / 16;
     constexpr int WM2 = 4, WN2 = 2;                // phase B: BM / 4 pixels x 32 channels (of a slice) or CN / 2 channels (reduction) per wave
@@ -2025,40 +2025,45 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     const int nk = (p.K + BK - 1) / BK;
     constexpr int LPT = A_IT + B_IT;
     if constexpr (NWB > 0) {
-        static_assert(KT1 == 1 && NWB >= 2, "halo phase A: 64 mid channels");
-        constexpr int NK = 9, D = NWB - 1, NID = KD == 0 ? NT * TMB : 0;
-        constexpr int ND0 = D < NK ? D : NK;                 // weight tiles requested with the halo block
-        constexpr int ID_AT = NK - 1 - D;                    // the iteration that requests the last weight tile (< 0: all went out up front)
+        // weight UNITS of 8 KB: a whole tap (64 output rows x 64 k, 128-byte rows) with 64 mid channels; with 128 mid channels a quarter tap
+        // (128 output rows x 32 k, 64-BYTE rows: one MFMA K step) -- 16 KB tiles would leave room for a 2-deep ring only beside the 35 KB halo block
+        constexpr int UK = C1 == 64 ? 64 : 32;               // k per unit
+        constexpr int UPT = C1 / UK;                         // units per tap: 1 / 4
+        constexpr int NK = 9 * UPT, D = NWB - 1, NID = KD == 0 ? NT * TMB : 0;
+        static_assert(NWB >= 2 && (C1 == 64 || C1 == 128) && C1 * UK * 2 == 8192, "halo phase A: 8 KB weight units");
+        constexpr int ND0 = D < NK ? D : NK;                 // weight units requested with the halo block
+        constexpr int ID_AT = NK - 1 - D;                    // the iteration that requests the last weight unit (< 0: all went out up front)
         // halo geometry: the tile is R whole rows of one image's W-wide map; halo rows hy = 0 .. R + 1 <-> input rows oy0 - 1 + hy, columns
-        // hx = 0 .. W + 1 <-> input columns hx - 1; HRP (a multiple of 8) LDS rows of 128 B
+        // hx = 0 .. W + 1 <-> input columns hx - 1; HRP (a multiple of 8) LDS rows of 128 B per 64-channel block
         const int Wm = p.W, Wp = Wm + 2, R = BM / Wm, HR = (R + 2) * Wp, HRP = (HR + 7) & ~7;
         const int img = m0 / HoWo, oy0 = (m0 - img * HoWo) / Wm, pix0 = img * p.H * p.W;
-        const unsigned WR_OFF = (unsigned)(HRP * 128);
+        const unsigned WR_OFF = (unsigned)(KT1 * HRP * 128);
         {
-            const int n_instr = HRP / 8;
+            const int n_instr = KT1 * HRP / 8;
             for (int i = wave; i < n_instr; i += NW) {
-                const int hr = i * 8 + rin;
+                const int L = i * 8 + rin;
+                const int blk = L / HRP, hr = L - blk * HRP;
                 const int hy = hr / Wp, hx = hr - hy * Wp;
                 const int iy = oy0 - 1 + hy, ix = hx - 1;
                 const bool ok = (hr < HR) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                const unsigned off = (unsigned)((pix0 + iy * p.W + ix) * p.xC + c * CH) * 2u;
+                const unsigned off = (unsigned)((pix0 + iy * p.W + ix) * p.xC + blk * BK + c * CH) * 2u;
                 dma16(__builtin_amdgcn_readfirstlane(lds_base + i * 1024), ok ? off : 0xFFFFFFFFu, rx);
             }
         }
-        auto stage_w = [&](int kt, int slot) {
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int n = (wave + NW * i) * 8 + rin;
-                const unsigned off = (unsigned)(n * p.Kp + kt * BK + c * CH) * 2u;
-                dma16(__builtin_amdgcn_readfirstlane(lds_base + WR_OFF + slot * (C1 * 128) + (wave + NW * i) * 1024), off, rw);
+        // 64-byte weight rows: 16-byte position = chunk ^ g(row quad), g = (0, 3, 2, 1) -- with ds_read_b128's lane groups (lanes {0-3, 12-15} of one
+        // K group with lanes {4-11} of the next) the 16 lanes of a group then hit 16 distinct 16-byte slots of the 256-byte bank window
+        auto stage_w = [&](int u, int slot) {
+            if constexpr (C1 == 64) {
+                const int n = wave * 8 + rin;
+                const unsigned off = (unsigned)(n * p.Kp + u * BK + c * CH) * 2u;
+                dma16(__builtin_amdgcn_readfirstlane(lds_base + WR_OFF + slot * 8192 + wave * 1024), off, rw);
+            } else {
+                const int row = lane >> 2, n = wave * 16 + row;
+                const int src = (lane & 3) ^ ((4 - (row >> 2)) & 3);
+                const unsigned off = (unsigned)(n * p.Kp + u * UK + src * CH) * 2u;
+                dma16(__builtin_amdgcn_readfirstlane(lds_base + WR_OFF + slot * 8192 + wave * 1024), off, rw);
             }
         };
-#pragma unroll
-        for (int t = 0; t < ND0; ++t) stage_w(t, t);
-        if constexpr (ID_AT < 0) load_identity();
-        wait_vmcnt<(ND0 - 1) * B_IT + (ID_AT < 0 ? NID : 0)>();      // the halo block and weight tile 0 have landed
-        __builtin_amdgcn_s_barrier();
-        lap(0);
         int hr0[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -2066,16 +2071,35 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             const int ry = r / Wm;
             hr0[j] = ry * Wp + (r - ry * Wm);
         }
-        static_for<0, NK>([&](auto KT) {
-            constexpr int kt = decltype(KT)::value;
-            if constexpr (kt + D < NK) stage_w(kt + D, (kt + D) % NWB);      // into the slot tile kt - 1 was read from (every wave has left it)
-            if constexpr (kt == ID_AT) load_identity();                      // behind the last operand request
-            constexpr int kh = kt / 3, kw = kt - kh * 3;
+        auto unit_mma = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            constexpr int tap = u / UPT, kh = tap / 3, kw = tap - kh * 3;
             const int dhr = kh * Wp + kw;
-            const char* sa = smem;
-            const char* sb = smem + WR_OFF + (kt % NWB) * (C1 * 128);
+            const char* sb = smem + WR_OFF + (u % NWB) * 8192;
+            if constexpr (C1 == 64) {
+                const char* sa = smem;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 xa[TM], wb[TN1];
+                    const int chunk = ks * 4 + fg;
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const int hr = hr0[j] + dhr;
+                        xa[j] = *reinterpret_cast<const uint4*>(sa + hr * 128 + ((chunk ^ (hr & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TN1; ++i) {
+                        const int r = wn * (C1 / WNc) + i * 16 + fr;
+                        wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TN1; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
+                }
+            } else {
+                constexpr int blk = (u % UPT) / 2, ks = u % 2;       // 64-channel block of the halo rows, 32-k half inside it
+                const char* sa = smem + blk * (HRP * 128);
                 uint4 xa[TM], wb[TN1];
                 const int chunk = ks * 4 + fg;
 #pragma unroll
@@ -2086,17 +2110,29 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 #pragma unroll
                 for (int i = 0; i < TN1; ++i) {
                     const int r = wn * (C1 / WNc) + i * 16 + fr;
-                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+                    wb[i] = *reinterpret_cast<const uint4*>(sb + r * 64 + ((fg ^ ((4 - (r >> 2)) & 3)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < TN1; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) Mma<T>::run(acc1[i][j], wb[i], xa[j]);
             }
-            if constexpr (kt + 1 < NK) {
-                // weight tile kt + 1 must have landed; what was requested after it (younger tiles, the identity rows) stays in flight
-                constexpr int last = kt + D < NK - 1 ? kt + D : NK - 1;
-                wait_vmcnt<(last - (kt + 1)) * B_IT + (kt >= ID_AT ? NID : 0)>();
+        };
+#pragma unroll
+        for (int t = 0; t < ND0; ++t) stage_w(t, t);
+        if constexpr (ID_AT < 0) load_identity();
+        wait_vmcnt<(ND0 - 1) + (ID_AT < 0 ? NID : 0)>();      // the halo block and weight unit 0 have landed
+        __builtin_amdgcn_s_barrier();
+        lap(0);
+        static_for<0, NK>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if constexpr (u + D < NK) stage_w(u + D, (u + D) % NWB);        // into the slot unit u - 1 was read from (every wave has left it)
+            if constexpr (u == ID_AT) load_identity();                      // behind the last operand request
+            unit_mma(U);
+            if constexpr (u + 1 < NK) {
+                // weight unit u + 1 must have landed; what was requested after it (younger units, the identity rows) stays in flight
+                constexpr int last = u + D < NK - 1 ? u + D : NK - 1;
+                wait_vmcnt<(last - (u + 1)) + (u >= ID_AT ? NID : 0)>();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -2919,23 +2955,26 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
         }
         static const bool no_halo = dev_env("HCM_NO_BNECK_HALO") != nullptr;
         bool halo_on = false;
-        if (!image && !no_halo && b.C1 == 64 && b.stride == 1 && d.W % 16 == 0 && BM % d.W == 0 && (d.Ho * d.Wo) % BM == 0) {
-            const size_t halo = (size_t)((((BM / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 64 * 128;
+        if (!image && !no_halo && b.stride == 1 && d.W % 16 == 0 && BM % d.W == 0 && (d.Ho * d.Wo) % BM == 0) {
+            const size_t halo = (size_t)KT1 * ((((BM / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 8192;
             if (halo <= 80 * 1024) {
                 halo_on = true;
                 // (the 3-deep ring of whole tap tiles is not used by this form: the phase-B regions or the halo block + weight ring decide)
                 lds1 = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)2 * b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
                 if (halo > lds1) lds1 = halo;
-                if (dt == DT_BF16) f1 = b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 64, 0, false, kHaloRing>)
+                if (dt == DT_BF16) f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 64, 128, 128, 0, false, kHaloRing>)
+                                      : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 64, 0, false, kHaloRing>)
                                                    : reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 64, 128, 0, false, kHaloRing>);
-                else f1 = b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, false, kHaloRing>)
+                else f1 = b.C1 == 128 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128, 0, false, kHaloRing>)
+                        : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, false, kHaloRing>)
                                      : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128, 0, false, kHaloRing>);
             }
         }
 #ifdef HCM_DEV_KNOBS
         if (!image && prof_on() && dt == DT_F16 && b.C1 == 64 && b.CN == 64)
             f1 = halo_on ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true, kHaloRing>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64, 0, true>);
-        if (!image && prof_on() && dt == DT_F16 && b.C1 == 128 && b.CN == 128) f1 = reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128, 0, true>);
+        if (!image && prof_on() && dt == DT_F16 && b.C1 == 128 && b.CN == 128)
+            f1 = halo_on ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128, 0, true, kHaloRing>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 64, 128, 128, 0, true>);
 #endif
         (void)halo_on;
         hipError_t e1 = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -361,7 +361,9 @@ def test_bottleneck_tail_fused(prec, cfg):
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 1, 64), (3, 17, 15, 64, 1, 64), (2, 16, 16, 128, 2, 128), (1, 24, 20, 128, 1, 128), (2, 16, 16, 64, 1, 128),
-                                 (5, 9, 11, 64, 2, 64), (2, 64, 64, 64, 1, 64)])
+                                 (5, 9, 11, 64, 2, 64), (2, 64, 64, 64, 1, 64),
+                                 # halo phase A (tiles of whole image rows): 128 mid channels on 32- and 16-wide maps, 64 mid channels with a 128-wide reduction
+                                 (2, 32, 32, 128, 1, 128), (3, 16, 16, 128, 1, 128), (2, 64, 64, 64, 1, 128), (1, 32, 32, 64, 1, 64)])
 def test_bottleneck_tail_next_fused(prec, cfg):
     """Bottleneck tail + the next block's 1x1 reduction in one launch: both outputs BIT-identical to the three stand-alone convs."""
     lib, L = _lib()
