@@ -939,7 +939,23 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     static_assert(A_IT >= 1 && B_IT >= 1 && TN >= 1, "tile too small for this wave count");
     constexpr int LPT = A_IT + B_IT;       // DMA instructions per wave per K tile
     constexpr int TILE_BYTES = (BM + BN) * 128;
-    static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+    static_assert(NBUF >= 2 && NBUF <= 6, "ring depth");
+    // NBUF > 3 (the DEEP ring): for launches whose whole grid fits the chip one workgroup per CU -- the depth trunk's 8 x 8 and 4 x 4 maps,
+    // every conv at small batch -- LDS is free, and the K loop is a latency chain: an iteration waits for the tile requested NBUF - 1
+    // iterations earlier, and an L2 -> LDS request takes ~0.85 us to land, so the iteration costs L / (NBUF - 1) until it reaches its own
+    // ~0.15 us of fragment reads + MFMAs.  Waits stay counted: (NBUF - 2) tiles in flight across the barrier in the steady state.
+    auto wait_tiles = [&](int n) {          // at most n whole tiles (n * LPT requests) of this wave still in flight
+        if constexpr (NBUF <= 3) { if (n >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
+        else {
+            switch (n) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<LPT>(); break;
+                case 2: wait_vmcnt<2 * LPT>(); break;
+                case 3: wait_vmcnt<3 * LPT>(); break;
+                default: wait_vmcnt<4 * LPT>(); break;
+            }
+        }
+    };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.groups > 1) {
@@ -1062,7 +1078,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
     }
     // prologue: NBUF-1 tiles in flight; tile 0 must have landed (for every wave) before the first fragment read
     stage(0, 0);
-    if (NBUF == 3 && nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    if constexpr (NBUF <= 3) {
+        if (NBUF == 3 && nk > 1) { stage(1, 1); wait_vmcnt<LPT>(); } else { wait_vmcnt<0>(); }
+    } else {
+        int staged = 1;
+#pragma unroll
+        for (int t = 1; t < NBUF - 1; ++t)
+            if (t < nk) { stage(t, t); ++staged; }
+        wait_tiles(staged - 1);
+    }
     __builtin_amdgcn_s_barrier();
     lap(0);
 
@@ -1247,7 +1271,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
                     if (q >= pc) piece(q, sa2, sb2, k, kh, kw, ci);
             }
             lap(2);
-            if (NBUF == 3 && live) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            // tile kt + 1 must have landed; younger: tiles kt + 2 .. min(kt + NBUF - 1, nk - 1)
+            if constexpr (NBUF <= 3) { if (NBUF == 3 && live) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
+            else { if (live) wait_vmcnt<(NBUF - 2) * LPT>(); else wait_tiles(nk - 2 - kt > 0 ? nk - 2 - kt : 0); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             lap(3);
             __builtin_amdgcn_s_barrier();
@@ -1287,7 +1313,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         // tile kt+1 must be complete before the next iteration reads it; with the 3-deep ring the tile requested in this
         // iteration may stay in flight across the barrier
         lap(2);
-        if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        if constexpr (NBUF <= 3) { if (NBUF == 3 && more) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
+        else { if (more) wait_vmcnt<(NBUF - 2) * LPT>(); else wait_tiles(nk - 2 - kt > 0 ? nk - 2 - kt : 0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lap(3);
         __builtin_amdgcn_s_barrier();
@@ -2371,6 +2398,27 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
     size_t lds = ((variant == 2 || variant == 5 || variant >= 7) ? 3 : 2) * (size_t)(BM + BN) * 128;
     const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024 + (d.cs_part ? 64 * 8 * 2 * 4 : 0);    // f32 output-tile image of the epilogue (+ fused-GroupNorm statistics, + column-sum slices)
     if (lds_c > lds) lds = lds_c;
+    if (variant == 9 || variant == 10) {
+        // the DEEP ring (igemm_dma_kernel, NBUF > 3): 6 tiles (variant 9; as many as 160 KB hold) or 4 (variant 10), one workgroup per CU
+        constexpr int TB = (BM + BN) * 128;
+        constexpr int ND6 = 6 * TB <= 160 * 1024 ? 6 : (5 * TB <= 160 * 1024 ? 5 : 4);
+        const int nb = variant == 9 ? ND6 : 4;
+        lds = (size_t)nb * TB;
+        if (lds_c > lds) lds = lds_c;
+        const void* fn;
+        int threads;
+        if constexpr (BN >= 64 && sizeof(T) == 2) {
+            fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6, 8, 2, false, 1>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4, 8, 2, false, 1>);
+            threads = 512;
+        } else {
+            fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4>);
+            threads = 256;
+        }
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        void* args[] = {&d};
+        return hipLaunchKernel(fn, dim3(grid, d.groups), dim3(threads), args, lds, s);
+    }
     static DeviceOnce attr_once;                            // one flag per template instantiation
     if (attr_once.need()) {
         const void* fns[4] = {reinterpret_cast<const void*>(igemm_kernel<T, BM, BN>),
@@ -2591,6 +2639,12 @@ static int heuristic_choice(const IGemmDev& d, int dt) {
     else if (b128 >= 192 && d.K >= 2048 && sizeof_dt(dt) == 2) { tile = 0; variant = 7; }
     else if (b64128 >= 128) { tile = 5; variant = longk ? (sizeof_dt(dt) == 2 ? 7 : 5) : 4; }   // long K: interleaved DMA issue
     else { tile = b64 >= 256 ? 2 : 3; variant = d.K >= 2048 ? 2 : 1; }
+    // launches whose whole grid fits the chip one workgroup per CU, with a K loop worth pipelining: the deep ring (LDS is free there)
+    static const int deep = dev_env("HCM_IGEMM_DEEP") ? atoi(dev_env("HCM_IGEMM_DEEP")) : 9;     // (development build: 0 off, 9 six tiles, 10 four)
+    if (deep && variant != 0 && variant != 3) {
+        const long blocks = cdiv(d.M, kTiles[tile][0]) * cdiv(d.N, kTiles[tile][1]) * d.groups;
+        if (blocks <= 256 && d.K >= 256 && !d.hpool) return deep * 6 + tile;
+    }
     return variant * 6 + tile;
 }
 
