@@ -2824,6 +2824,10 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         if (g.x_src_dt >= 0 || d.gn_hw <= 0 || 64 % d.gn_hw || d.M % d.gn_hw || d.gn_cg % 8 || 128 % d.gn_cg || d.N % d.gn_cg || d.bias ||
             d.out_f32 || !d.gn_beta)
             return hipErrorInvalidValue;
+        // (16-bit, the whole grid one workgroup per CU: the deep ring -- see igemm_dma_kernel, NBUF > 3)
+        static const int deep_gn = dev_env("HCM_IGEMM_DEEP") ? atoi(dev_env("HCM_IGEMM_DEEP")) : 9;
+        const long blocks_gn = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.groups;
+        if (deep_gn && dt != DT_F32 && blocks_gn <= 256 && d.K >= 256) return launch_dt(d, dt, deep_gn * 6 + 5, s);
         return launch_dt(d, dt, ((d.K >= 768 && dt != DT_F32) ? 7 : 4) * 6 + 5, s);
     }
     if (g.hpool) {
