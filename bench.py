@@ -380,8 +380,15 @@ def main():
     # the collective is enqueued by the LIBRARY behind the graph replay (hcm_act_gather, one ncclAllGather on the step's stream) unless
     # --torch-gather asks for the torch.distributed call per step of rounds 1-2 (A/B)
     lib_gather = use_dist and args.config == 1 and not args.torch_gather
+    gather_note = None
     if lib_gather:
-        eng.comm_init()
+        try:
+            eng.comm_init()             # raises on EVERY rank or on none (policy.py: status byte with the id, MIN-reduce of the init result)
+        except RuntimeError as e:       # the library's own communicator is an optimisation: fall back to the torch.distributed collective
+            lib_gather = False
+            gather_note = f"hcm_comm_init failed ({e}); torch.distributed.all_gather_into_tensor per step instead"
+            if rank == 0:
+                print("bench.py: " + gather_note, file=sys.stderr)
 
     def step(mask=None, overlap=False):
         if use_dist and overlap and len(pending) >= 2:
@@ -495,7 +502,7 @@ def main():
         }
         if use_dist:
             out["config"]["all_gather"] = ("ncclAllGather enqueued by libhcm on the step's stream behind the hipGraph replay (hcm_act_gather)" if lib_gather
-                                           else "torch.distributed.all_gather_into_tensor per step (--torch-gather)")
+                                           else gather_note or "torch.distributed.all_gather_into_tensor per step (--torch-gather)")
         if sustained:
             out["sustained"] = sustained
         if overlapped:

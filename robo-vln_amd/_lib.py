@@ -114,6 +114,11 @@ def lib():
     return _lib
 
 
+def last_error(handle=None):
+    msg = lib().hcm_last_error(handle)
+    return msg.decode() if msg else ""
+
+
 def check(rc, handle=None):
     if rc == 0:
         return

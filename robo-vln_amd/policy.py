@@ -191,16 +191,25 @@ class HCMEngine:
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         ident = (C.c_char * 128)()
+        ok = 1
         if rank == 0:
-            _lib.check(self._lib.hcm_comm_unique_id(ident))
-        t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+            ok = 1 if self._lib.hcm_comm_unique_id(ident) == 0 else 0
+        # 128 id bytes + one status byte: a rank-0 failure (no librccl to dlopen) reaches every rank as an exception, not as a hang in the broadcast
+        t = torch.tensor(list(bytes(ident)) + [ok], dtype=torch.uint8)
         on_dev = dist.get_backend(group) == "nccl"
         if on_dev:
             t = t.to(self.device)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         raw = bytes(t.cpu().numpy().tobytes())
+        if raw[128] != 1:
+            raise RuntimeError("hcm_comm_unique_id failed on rank 0 (librccl not loadable?)")
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.hcm_comm_init(self._h, C.c_char_p(raw), rank, world), self._h)
+            rc = self._lib.hcm_comm_init(self._h, C.c_char_p(raw[:128]), rank, world)
+        # every rank learns whether ALL ranks have a communicator (a rank that failed would otherwise leave the others in their first collective)
+        flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            raise RuntimeError("hcm_comm_init failed on at least one rank" + (": " + _lib.last_error(self._h) if rc != 0 else ""))
         self.comm_world, self.comm_rank = world, rank
         return world
 
