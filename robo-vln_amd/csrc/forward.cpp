@@ -256,6 +256,42 @@ struct Fwd {
         const bool dry_saved = dry;
         for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
             if (t.gn && gn_stop >= 0 && (int)bi >= gn_stop) dry = true;
+            // GroupNorm trunk, 8 x 8 maps, 512 / 128 channels, 16 groups per trunk (the depth encoder's layer3 at 256-pixel frames): the run of
+            // identity bottlenecks behind the layer's first block is ONE launch, a workgroup per (sample, trunk) -- igemm.hip depth_l3_kernel
+            static const bool no_l3 = dev_env("HCM_NO_DEPTH_L3") != nullptr;
+            if (t.gn && !no_l3 && !ctx->taps_on && pre < 0 && x.H * x.W == 64 && x.H == 8 && t.groups == 16) {
+                auto plain = [&](const BottleneckW& q) {
+                    const bool dt16 = q.c1.dt == DT_F16 || q.c1.dt == DT_BF16;
+                    return dt16 && !q.has_ds && q.stride == 1 && q.c1.KH == 1 && q.c1.Cin == 512 && q.c1.Cout == 128 && q.c1.Kp == 512 && q.c2.KH == 3 && q.c2.KW == 3 &&
+                           q.c2.Cin == 128 && q.c2.Cout == 128 && q.c2.Kp == 1152 && q.c3.KH == 1 && q.c3.Cin == 128 && q.c3.Cout == 512 && q.c3.Kp == 128 &&
+                           !q.c1.bias && !q.c2.bias && !q.c3.bias && q.c2.dt == q.c1.dt && q.c3.dt == q.c1.dt && q.c1.groups == q.c2.groups &&
+                           q.c1.groups == q.c3.groups;
+                };
+                size_t run = 0;
+                while (bi + run < t.blocks.size() && run < 6 && plain(t.blocks[bi + run]) && t.blocks[bi + run].c1.groups == t.blocks[bi].c1.groups) ++run;
+                if (run >= 2 && x.C == t.blocks[bi].c1.groups * 512) {
+                    int fo = 0;
+                    while (fo == xi) ++fo;
+                    if (!dry) {
+                        DepthL3 q;
+                        q.x = x.p; q.y = slot[fo]; q.ld = x.C; q.B = B; q.groups = t.blocks[bi].c1.groups; q.nblocks = (int)run;
+                        for (size_t r = 0; r < run; ++r) {
+                            const BottleneckW& bb = t.blocks[bi + r];
+                            q.w1[r] = bb.c1.w; q.w2[r] = bb.c2.w; q.w3[r] = bb.c3.w;
+                            q.g1[r] = bb.n1.gamma; q.b1[r] = bb.n1.beta; q.g2[r] = bb.n2.gamma; q.b2[r] = bb.n2.beta; q.g3[r] = bb.n3.gamma; q.b3[r] = bb.n3.beta;
+                            q.eps1[r] = 1e-5f * bb.c1.fold * bb.c1.fold; q.eps2[r] = 1e-5f * bb.c2.fold * bb.c2.fold; q.eps3[r] = 1e-5f * bb.c3.fold * bb.c3.fold;
+                        }
+                        ck(launch_depth_l3(q, t.blocks[bi].c1.dt, s), "depth layer3 run");
+                        calib_check(slot[fo], t.blocks[bi].c1.dt, B * 64, x.C, x.C);
+                    }
+                    x = Act{slot[fo], B, x.H, x.W, x.C};
+                    xi = fo;
+                    bidx += (int)run;
+                    bi += run - 1;
+                    if (bidx == 13) tap(tapname + "_layer3", x.p, true, {B, x.H, x.W, x.C});
+                    continue;
+                }
+            }
             const BottleneckW& b = t.blocks[bi];
             int fr[3], nf = 0;
             if (pre >= 0) fr[nf++] = pre;

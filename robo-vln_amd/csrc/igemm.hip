@@ -3052,4 +3052,263 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     return hipLaunchKernel(fn, dim3((d.M + BM - 1) / BM, d.groups), dim3(512), args, lds, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// depth_l3_kernel: a run of identity bottlenecks of the depth GroupNorm trunk's layer3 (8 x 8 maps, 512 channels, 128 mid channels, 16 groups
+// per trunk; habitat ResNetEncoder as used at resnet_encoders.py:27-62) in ONE launch.  As separate launches every conv of these blocks is a
+// 64 x 128-tile GEMM over a few dozen workgroups whose 14 us are fixed costs (launch, first-tile latency, the fused-GroupNorm epilogue's LDS
+// image and barriers), 15 launches in a row.  Here a workgroup owns ONE sample of one trunk for the whole run: the block input (64 pixels x
+// 512 channels = 64 KB) and the two mid tensors (16 KB each) stay in LDS in the MFMA operand layout (64-channel blocks of 128-byte pixel rows,
+// XOR-swizzled), the weights come from L2 straight into registers as MFMA fragments (16 bytes per lane: 8 k of one output channel), a few K
+// steps ahead, and GroupNorm needs no LDS at all -- a wave's accumulators hold whole groups (8 channels x 64 pixels for the 128-wide convs,
+// 32 x 64 for the expansion), so the statistics are a butterfly over lanes.  3 barriers per block.  Same f32 operations as the fused epilogue
+// of igemm_dma_kernel (statistics of the f32 accumulators, (v - mean) * rstd * gamma + beta, + identity, ReLU, one rounding) in a different
+// (fixed) summation order: equal to that path to f32 round-off of the statistics, not bit for bit.
+struct DepthL3Dev {
+    const char* x; char* y; int ld, nblocks;
+    const char* w1[6]; const char* w2[6]; const char* w3[6];
+    const float* g1[6]; const float* b1[6]; const float* g2[6]; const float* b2[6]; const float* g3[6]; const float* b3[6];
+    float eps1[6], eps2[6], eps3[6];
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
+    constexpr int XO = 0, O1 = 65536, O2 = 81920;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    // ---- block input -> LDS
+    {
+        const char* src = p.x + ((size_t)b * 64 * p.ld + (size_t)g * 512) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 512 * i;
+            const int px = c >> 6, ch = c & 63;                     // 64 chunks of 8 channels per pixel
+            const uint4 v = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld + ch * 8) * 2);
+            *reinterpret_cast<uint4*>(smem + XO + (ch >> 3) * 8192 + px * 128 + (((ch & 7) ^ (px & 7)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+    // the lane's A-fragment rows: pixel r = j * 16 + fr
+    auto a_addr = [&](int base, int r, int kstep) {             // k step of 32 channels: 64-channel block kstep / 2, half kstep % 2
+        const int chunk = (kstep & 1) * 4 + fg;
+        return base + (kstep >> 1) * 8192 + r * 128 + ((chunk ^ (r & 7)) << 4);
+    };
+    // per-lane sum over the 16 lanes of its K group pair and both K groups of a pair (bits 0-4), or over the whole wave
+    auto red32 = [&](float v) {
+#pragma unroll
+        for (int o = 1; o <= 16; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    auto store4 = [&](int base, int r, int c, const float (&v)[4]) {        // 4 consecutive channels c .. c + 3 of pixel r into an operand block
+        T o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+        *reinterpret_cast<uint2*>(smem + base + (c >> 6) * 8192 + r * 128 + ((((c & 63) >> 3) ^ (r & 7)) << 4) + (c & 7) * 2) = *reinterpret_cast<const uint2*>(o4);
+    };
+    // ---- the weight stream.  Per block a wave consumes 68 PIECES of 1 KB -- its 16 output rows x 32 k (64-byte rows) of conv1's 16 K steps,
+    // conv2's 36, and conv3's 4 K steps x 4 fragments -- in a fixed order; every wave has its own R-slot ring in LDS (no barrier: producer and
+    // consumer are the same wave), filled by `buffer_load ... lds` R - 1 pieces ahead, across the conv and block boundaries, with counted waits.
+    // 64-byte rows: 16-byte position = K group ^ g(row quad), g = (0, 3, 2, 1), as in the bottleneck kernel's quarter-tap units.
+    constexpr int R = 8, PPB = 68, WR = 98304;
+    const int total = p.nblocks * PPB;
+    const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + WR + wave * (R * 1024);
+    const int drow = lane >> 2, dsrc = (lane & 3) ^ ((4 - (drow >> 2)) & 3);
+    // per-lane byte offsets of a piece inside its weight matrix, without the K step
+    const unsigned vo1 = (unsigned)((wave * 16 + drow) * 512 + dsrc * 8) * 2u, vo2 = (unsigned)((wave * 16 + drow) * 1152 + dsrc * 8) * 2u,
+                   vo3 = (unsigned)((wave * 64 + drow) * 128 + dsrc * 8) * 2u;
+    v4i_t rs1, rs2, rs3, rs1n;                                  // buffer resources of this block's three matrices and the next block's first
+    int par = 0;                                                // ring position of the block's first piece: (blk * 68) % 8
+    bool has_next = false;
+    auto load_rsrc = [&](int blk) {
+        rs1 = make_rsrc(p.w1[blk] + (size_t)g * 128 * 512 * 2, 128u * 512u * 2u);
+        rs2 = make_rsrc(p.w2[blk] + (size_t)g * 128 * 1152 * 2, 128u * 1152u * 2u);
+        rs3 = make_rsrc(p.w3[blk] + (size_t)g * 512 * 128 * 2, 512u * 128u * 2u);
+        has_next = blk + 1 < p.nblocks;
+        rs1n = make_rsrc(p.w1[has_next ? blk + 1 : blk] + (size_t)g * 128 * 512 * 2, 128u * 512u * 2u);
+        par = (blk & 1) * 4;
+    };
+    auto issue = [&](int idx) {                                 // piece idx of the current block (compile-time after unrolling); >= 68: of the next
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)(((par + idx) & (R - 1)) * 1024));
+        if (idx >= PPB) { if (has_next) dma16(dst, vo1 + (unsigned)(idx - PPB) * 64u, rs1n); }
+        else if (idx < 16) dma16(dst, vo1 + (unsigned)idx * 64u, rs1);
+        else if (idx < 52) dma16(dst, vo2 + (unsigned)(idx - 16) * 64u, rs2);
+        else dma16(dst, vo3 + (unsigned)(((idx - 52) & 3) * 16 * 128 * 2 + ((idx - 52) >> 2) * 64), rs3);
+    };
+    // the fragment of piece idx: wait for it and read it; the slot of the piece BEFORE it (whose fragment the previous MFMAs have consumed, so its
+    // read is long complete) is refilled with the piece R - 1 ahead of this one -- R - 2 pieces in flight behind the one waited for
+    auto take = [&](int idx) {
+        if (idx + R - 2 < PPB || has_next) wait_vmcnt<R - 2>(); else wait_vmcnt<0>();
+        const uint4 wb = *reinterpret_cast<const uint4*>(smem + WR + wave * (R * 1024) + ((par + idx) & (R - 1)) * 1024 + fr * 64 +
+                                                         ((fg ^ ((4 - (fr >> 2)) & 3)) << 4));
+        issue(idx + R - 1);
+        return wb;
+    };
+    load_rsrc(0);
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) issue(i);
+    for (int blk = 0; blk < p.nblocks; ++blk) {
+        if (blk > 0) load_rsrc(blk);
+        // =================== conv1: 1x1, 512 -> 128 (wave: channels wave * 16 .. + 15, all 64 pixels)
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (fragment reads one K step ahead, by hand: the asm waits / requests of take() are barriers to the compiler's own pipelining)
+        {
+            uint4 xa[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[0][j] = *reinterpret_cast<const uint4*>(smem + a_addr(XO, j * 16 + fr, 0));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 1 < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xa[(ks + 1) & 1][j] = *reinterpret_cast<const uint4*>(smem + a_addr(XO, j * 16 + fr, ks + 1));
+                }
+                const uint4 wb = take(ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(acc[j], wb, xa[ks & 1][j]);
+            }
+        }
+        auto gn128 = [&](const float* gamma, const float* beta, float eps, int dst) {
+            // groups of 8 channels: the lane's 4 channels with those of its neighbour K group (fg ^ 1), over 64 pixels
+            const int c = wave * 16 + fg * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + g * 128 + c), be = *reinterpret_cast<const float4*>(beta + g * 128 + c);
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = acc[j][e]; a += v; q += v * v; }
+            a = red32(a); q = red32(q);
+            const float inv = 1.0f / 512.0f;
+            const float mean = a * inv;
+            const float rstd = rsqrtf(relu_f(q * inv - mean * mean) + eps);
+            const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_f((acc[j][e] - mean) * rstd * gaa[e] + bea[e]);
+                store4(dst, j * 16 + fr, c, v);
+            }
+        };
+        gn128(p.g1[blk], p.b1[blk], p.eps1[blk], O1);
+        __syncthreads();
+        // =================== conv2: 3x3 (pad 1), 128 -> 128 over the 8 x 8 map: k = tap * 128 + ci
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            uint4 xa[2][4];
+            auto ld2 = [&](int step, uint4 (&dst)[4]) {            // A fragments of K step `step` = (tap, 32-channel quarter)
+                const int tap = step >> 2, kc = step & 3;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = j * 16 + fr;
+                    const int sy = (r >> 3) + dy, sx = (r & 7) + dx;
+                    const bool ok = ((unsigned)sy < 8u) & ((unsigned)sx < 8u);
+                    uint4 v = *reinterpret_cast<const uint4*>(smem + a_addr(O1, ok ? sy * 8 + sx : 0, kc));
+                    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                    dst[j] = v;
+                }
+            };
+            ld2(0, xa[0]);
+#pragma unroll
+            for (int ks = 0; ks < 36; ++ks) {
+                if (ks + 1 < 36) ld2(ks + 1, xa[(ks + 1) & 1]);
+                const uint4 wb = take(16 + ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(acc[j], wb, xa[ks & 1][j]);
+            }
+        }
+        gn128(p.g2[blk], p.b2[blk], p.eps2[blk], O2);
+        __syncthreads();
+        // =================== conv3: 1x1, 128 -> 512, GroupNorm (groups of 32 channels = fragment pairs), + identity, ReLU, in place
+        {
+            f32x4 acc3[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 xa[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const uint4*>(smem + a_addr(O2, j * 16 + fr, ks));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 wb = take(52 + ks * 4 + i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<T>::run(acc3[i][j], wb, xa[j]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                       // the wave's two groups: fragments 2 pr, 2 pr + 1
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float v = acc3[pr * 2 + ii][j][e]; a += v; q += v * v; }
+                a = wave_sum(a); q = wave_sum(q);
+                const float inv = 1.0f / 2048.0f;
+                const float mean = a * inv;
+                const float rstd = rsqrtf(relu_f(q * inv - mean * mean) + p.eps3[blk]);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = pr * 2 + ii;
+                    const int c = wave * 64 + i * 16 + fg * 4;
+                    const float4 ga = *reinterpret_cast<const float4*>(p.g3[blk] + g * 512 + c), be = *reinterpret_cast<const float4*>(p.b3[blk] + g * 512 + c);
+                    const float gaa[4] = {ga.x, ga.y, ga.z, ga.w}, bea[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = j * 16 + fr;
+                        char* xp = smem + XO + (c >> 6) * 8192 + r * 128 + ((((c & 63) >> 3) ^ (r & 7)) << 4) + (c & 7) * 2;
+                        const uint2 idt = *reinterpret_cast<const uint2*>(xp);
+                        const T* it = reinterpret_cast<const T*>(&idt);
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu_f((acc3[i][j][e] - mean) * rstd * gaa[e] + bea[e] + Tr<T>::ld(it + e));
+                        T o4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Tr<T>::st(&o4[e], v[e]);
+                        *reinterpret_cast<uint2*>(xp) = *reinterpret_cast<const uint2*>(o4);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- block output -> y
+    {
+        char* dst = p.y + ((size_t)b * 64 * p.ld + (size_t)g * 512) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 512 * i;
+            const int px = c >> 6, ch = c & 63;
+            *reinterpret_cast<uint4*>(dst + ((size_t)px * p.ld + ch * 8) * 2) =
+                *reinterpret_cast<const uint4*>(smem + XO + (ch >> 3) * 8192 + px * 128 + (((ch & 7) ^ (px & 7)) << 4));
+        }
+    }
+}
+
+hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s) {
+    if ((dt != DT_F16 && dt != DT_BF16) || d.nblocks < 1 || d.nblocks > 6 || d.B < 1 || d.groups < 1 || (d.ld % 8) || d.ld < d.groups * 512 || !d.x || !d.y)
+        return hipErrorInvalidValue;
+    DepthL3Dev q;
+    q.x = (const char*)d.x; q.y = (char*)d.y; q.ld = d.ld; q.nblocks = d.nblocks;
+    for (int i = 0; i < 6; ++i) {
+        q.w1[i] = (const char*)d.w1[i]; q.w2[i] = (const char*)d.w2[i]; q.w3[i] = (const char*)d.w3[i];
+        q.g1[i] = d.g1[i]; q.b1[i] = d.b1[i]; q.g2[i] = d.g2[i]; q.b2[i] = d.b2[i]; q.g3[i] = d.g3[i]; q.b3[i] = d.b3[i];
+        q.eps1[i] = d.eps1[i]; q.eps2[i] = d.eps2[i]; q.eps3[i] = d.eps3[i];
+    }
+    const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(depth_l3_kernel<bf16>) : reinterpret_cast<const void*>(depth_l3_kernel<f16>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    void* args[] = {&q};
+    return hipLaunchKernel(fn, dim3(d.B, d.groups), dim3(512), args, 98304 + 8 * 8 * 1024, s);
+}
+
 }  // namespace hcm

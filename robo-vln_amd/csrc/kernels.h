@@ -93,6 +93,16 @@ struct Bneck23 {
     // b3 = b3 + bds, res is unused; xd = block input [B,H,W,*] (64*KD channels at pixel stride xdC), same stride as the 3x3 conv
     const void* xd = nullptr; int xdC = 0, KD = 0; long long g_xd = 0;
 };
+// A run of up to 6 identity bottlenecks (no down-sample, stride 1) of a GroupNorm trunk on 8 x 8 maps with 512 / 128 channels and 16 groups
+// per trunk -- the depth encoder's layer3 behind its first block -- as ONE launch, a workgroup per (sample, trunk): igemm.hip depth_l3_kernel.
+struct DepthL3 {
+    const void* x = nullptr; void* y = nullptr;      // [B][64][ld] activations (block input / output of the run), trunk g at channels [g * 512, +512)
+    int ld = 0, B = 0, groups = 1, nblocks = 0;
+    const void* w1[6] = {}; const void* w2[6] = {}; const void* w3[6] = {};          // [groups][128][512], [groups][128][1152], [groups][512][128]
+    const float* g1[6] = {}; const float* b1[6] = {}; const float* g2[6] = {}; const float* b2[6] = {}; const float* g3[6] = {}; const float* b3[6] = {};
+    float eps1[6] = {}, eps2[6] = {}, eps3[6] = {};
+};
+hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s);
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 
 // While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real

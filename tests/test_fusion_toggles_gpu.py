@@ -86,3 +86,18 @@ def test_fused_cross_modal_layer_equals_the_launch_per_op_form(env):
         err = np.abs(a[k] - b[k]).max()
         print(k, err)
         assert err <= 8e-3, (k, err)      # measured: 1e-4 .. 4e-3 (three layers of bf16 LayerNorm outputs, one ulp = 4e-3 at 1.0)
+
+
+def test_depth_layer3_run_equals_the_launch_per_conv_form():
+    """depth_l3_kernel (igemm.hip): the five identity bottlenecks of the depth trunk's layer3 on its 8 x 8 map as one launch, against the fifteen
+    conv + fused-GroupNorm launches it replaces: the same MFMA products in the same k order, the GroupNorm statistics summed in a different
+    (fixed) order -> equal to f32 round-off of the statistics amplified through the fp16 chain, not bit for bit."""
+    with tempfile.TemporaryDirectory() as d:
+        env = {"HCMT_DEPTH_HW": "256", "HCMT_L": "20"}
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_DEPTH_L3="1"), os.path.join(d, "b.npz"))
+    assert np.isfinite(a["rec"]).all()
+    for k in ("rec", "hh", "lh"):
+        err = np.abs(a[k] - b[k]).max()
+        print(k, err)
+        assert err <= 2e-3, (k, err)
