@@ -3071,8 +3071,15 @@ struct DepthL3Dev {
     float eps1[6], eps2[6], eps3[6];
 };
 
-template <typename T>
+template <typename T, bool PROF = false>
 __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
+    // phase timing (HCM_IGEMM_PROF=1, development build; read through hcm_debug_igemm_prof): per-wave cycle totals [0] input staging, [1] conv1 K loop,
+    // [2] its GroupNorm + barrier, [3] conv2 K loop, [4] its GroupNorm + barrier, [5] conv3 + GroupNorm + identity + barrier + output, [6] waves
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if constexpr (PROF) t_prev = prof_now();
+    auto lap = [&](int slot) {
+        if constexpr (PROF) { const unsigned long long t = prof_now(); pt[slot] += t - t_prev; t_prev = t; }
+    };
     constexpr int XO = 0, O1 = 65536, O2 = 81920;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, g = blockIdx.y;
@@ -3149,6 +3156,7 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
     load_rsrc(0);
 #pragma unroll
     for (int i = 0; i < R - 1; ++i) issue(i);
+    lap(0);
     for (int blk = 0; blk < p.nblocks; ++blk) {
         if (blk > 0) load_rsrc(blk);
         // =================== conv1: 1x1, 512 -> 128 (wave: channels wave * 16 .. + 15, all 64 pixels)
@@ -3171,6 +3179,7 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
                 for (int j = 0; j < 4; ++j) Mma<T>::run(acc[j], wb, xa[ks & 1][j]);
             }
         }
+        lap(1);
         auto gn128 = [&](const float* gamma, const float* beta, float eps, int dst) {
             // groups of 8 channels: the lane's 4 channels with those of its neighbour K group (fg ^ 1), over 64 pixels
             const int c = wave * 16 + fg * 4;
@@ -3195,6 +3204,7 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
         };
         gn128(p.g1[blk], p.b1[blk], p.eps1[blk], O1);
         __syncthreads();
+        lap(2);
         // =================== conv2: 3x3 (pad 1), 128 -> 128 over the 8 x 8 map: k = tap * 128 + ci
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -3222,8 +3232,10 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
                 for (int j = 0; j < 4; ++j) Mma<T>::run(acc[j], wb, xa[ks & 1][j]);
             }
         }
+        lap(3);
         gn128(p.g2[blk], p.b2[blk], p.eps2[blk], O2);
         __syncthreads();
+        lap(4);
         // =================== conv3: 1x1, 128 -> 512, GroupNorm (groups of 32 channels = fragment pairs), + identity, ReLU, in place
         {
             f32x4 acc3[4][4];
@@ -3280,6 +3292,7 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
             }
         }
         __syncthreads();
+        lap(5);
     }
     // ---- block output -> y
     {
@@ -3290,6 +3303,15 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
             const int px = c >> 6, ch = c & 63;
             *reinterpret_cast<uint4*>(dst + ((size_t)px * p.ld + ch * 8) * 2) =
                 *reinterpret_cast<const uint4*>(smem + XO + (ch >> 3) * 8192 + px * 128 + (((ch & 7) ^ (px & 7)) << 4));
+        }
+    }
+    if constexpr (PROF) {
+        lap(5);
+        if (lane == 0) {
+            unsigned long long* slot = g_igemm_prof[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) & (kProfSlots - 1)];
+            for (int i = 0; i < 6; ++i) atomicAdd(&slot[i], pt[i]);
+            atomicAdd(&slot[6], 1ull);
+            atomicAdd(&slot[7], (unsigned long long)p.nblocks);
         }
     }
 }
@@ -3305,6 +3327,9 @@ hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s) {
         q.eps1[i] = d.eps1[i]; q.eps2[i] = d.eps2[i]; q.eps3[i] = d.eps3[i];
     }
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(depth_l3_kernel<bf16>) : reinterpret_cast<const void*>(depth_l3_kernel<f16>);
+#ifdef HCM_DEV_KNOBS
+    if (prof_on() && dt == DT_F16) fn = reinterpret_cast<const void*>(depth_l3_kernel<f16, true>);
+#endif
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     void* args[] = {&q};
