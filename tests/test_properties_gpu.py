@@ -48,6 +48,19 @@ def test_deterministic_bitwise(full):
     assert torch.isfinite(a[0]).all() and a[0].shape == (B, 7)
 
 
+def test_single_model_calls_equal_the_paired_step(full):
+    """high_forward / low_forward run each model's trunks alone (one trunk per launch group), act() runs them as hi|lo pairs (grouped launches,
+    the depth layer3 run with two workgroups per sample): the same per-trunk arithmetic, so the outputs agree to accumulation-order round-off."""
+    cfg, eng, obs, hh, lh, mask = full
+    rec, h2, l2 = _act(eng, obs, hh, lh, mask)
+    logits, h3 = eng.high_forward(dict(obs), hh, mask)
+    vel, stop, l3 = eng.low_forward(dict(obs), lh, mask, torch.argmax(rec[:, :4], 1))
+    torch.cuda.synchronize()
+    assert (logits - rec[:, :4]).abs().max().item() <= 1e-3
+    assert (torch.cat([vel, stop], 1) - rec[:, 4:]).abs().max().item() <= 1e-3
+    assert (h3 - h2).abs().max().item() <= 2e-3 and (l3 - l2).abs().max().item() <= 2e-3
+
+
 def test_batch_permutation_equivariance(full):
     """Every op of the path is per-sample: permuting the environments permutes the outputs, bit for bit."""
     cfg, eng, obs, hh, lh, mask = full
