@@ -1,6 +1,6 @@
 """bench.py -- policy env-steps/sec of the batched HCM act() on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config {0,1,3,4}]
+    python bench.py --gpus N --steps K --warmup W [--config {0,1,3,4}]       (N > 1: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Default workload (BASELINE.json configs[1]/[2], the configuration the metric is quoted on): per GPU 64 environments, 256x256
@@ -122,7 +122,7 @@ def _time_op(run, n=60, warm=30):
 def dominant_kernel_probe(batch, L=80):
     """The launches with the largest share of a step's kernel time are the GEMMs of the fp16 BERT encoder
     (profiles/r2b_kernel_trace_bench.md): 12 launches each of QKV (768 -> 2304) and FFN1 (768 -> 3072, GELU) on the 256 x 256-tile
-    8-phase kernel `gemm256_kernel`, and of attention-output (768 -> 768) and FFN2 (3072 -> 768) on `igemm_dma_kernel` (at B = 64 their
+    kernel `gemm256f_kernel` (one barrier per K tile; round 4), and of attention-output (768 -> 768) and FFN2 (3072 -> 768) on `igemm_dma_kernel` (at B = 64 their
     output is too narrow for 256-wide tiles), over M = batch * L token rows.  Each is timed live here through the library's operator
     entry point (same kernel, same tile choice as inside the step) and priced against the dense 16-bit MFMA peak: algorithmic FLOPs
     per launch = 2*M*N*K.  The FFN1 launch is the single most expensive one and is the `roofline` of the JSON line."""
@@ -212,31 +212,95 @@ def dtype_string(args, eng):
 
 
 # ------------------------------------------------------------------------------------------------------------ workloads
-def build_act_workload(args, cfg_idx, rank, world, local_rank):
+STUB = os.environ.get("HCM_BENCH_STUB", "0") not in ("", "0")     # tests/test_bench_cpu.py only: no GPU, no libhcm, gloo -- exercises the launch plumbing
+
+
+def _device(local_rank):
+    import torch
+    return torch.device("cpu") if STUB else torch.device("cuda", local_rank)
+
+
+def _sync():
+    import torch
+    if not STUB:
+        torch.cuda.synchronize()
+
+
+class _StubEngine:
+    """NOT a measurement path: a deterministic stand-in for HCMEngine so that the exact multi-rank command line of the driver
+    (`python bench.py --gpus N ...`: self-spawn, rendezvous, rank-tagged gather, weak + strong legs, one rank-0 JSON line) can be run on a
+    CPU-only host under gloo.  Selected by HCM_BENCH_STUB=1 only; the result line says so in `data` and `metric`."""
+    fp16_fallback = ()
+    range_fold = ()
+
+    def __init__(self, cfg, rank, dev):
+        self.cfg, self.rank, self.dev, self.tick = cfg, rank, dev, 0
+
+    def comm_init(self):
+        raise RuntimeError("stub engine has no RCCL communicator")
+
+    def act(self, obs, hh, lh, m, reuse_instruction=False, host_frames=False, gather=False):
+        import torch
+        B = obs["rgb"].shape[0]
+        self.tick += 1
+        base = obs["depth"].reshape(B, -1)[:, :7].float() + obs["rgb"].reshape(B, -1)[:, :7].float() / 255.0
+        return base + 0.001 * self.rank + 1e-6 * self.tick, hh, lh
+
+    def query(self, what):
+        return 0
+
+    def close(self):
+        pass
+
+
+def build_act_workload(args, cfg_idx, rank, world, local_rank, strong_batch=0):
     import torch
     from robo_vln_amd import synth
     from robo_vln_amd.config import baseline_config
-    from robo_vln_amd.policy import HCMEngine
+    if not STUB:
+        from robo_vln_amd.policy import HCMEngine
     cfg = baseline_config(cfg_idx)
     B = args.batch or BATCH[cfg_idx]
     if args.total_batch:                                      # strong scaling: the environments of ONE rollout split over the ranks
         if args.total_batch % world:
             raise SystemExit("--total-batch must be a multiple of the number of ranks")
         B = args.total_batch // world
-    hi_sd, lo_sd = synth.make_weights(cfg, seed=0)            # full replica per rank
+    if STUB:
+        B = int(os.environ.get("HCM_BENCH_STUB_BATCH", "4"))  # the plumbing test keeps its frames small; the command line stays the driver's
+        strong_batch = min(strong_batch, 2 * B)
+    hi_sd, lo_sd = (None, None) if STUB else synth.make_weights(cfg, seed=0)            # full replica per rank (SURVEY 8e)
     hi_only = cfg_idx == 4
-    eng = HCMEngine(cfg, hi_sd, None if hi_only else lo_sd, max_batch=B, precision=args.precision, graph=not args.no_graph and not hi_only)
+    dev = _device(local_rank)
+    if STUB:
+        eng = _StubEngine(cfg, rank, dev)                     # CPU plumbing test of the multi-rank command line only (tests/test_bench_cpu.py)
+    else:
+        eng = HCMEngine(cfg, hi_sd, None if hi_only else lo_sd, max_batch=max(B, strong_batch), precision=args.precision,
+                        graph=not args.no_graph and not hi_only)
+    steppers = {}
+
+    def make_step(Bx, stager_ok=False):
+        """A stepping closure over two resident observation sets at batch Bx (the engine is sized for the largest leg)."""
+        if Bx not in steppers:
+            steppers[Bx] = _act_stepper(args, cfg, eng, Bx, rank, local_rank, hi_only, dev, stager_ok)
+        return steppers[Bx]
+    step = make_step(B, stager_ok=True)
+    return cfg, B, eng, step, (hi_sd, lo_sd), make_step
+
+
+def _act_stepper(args, cfg, eng, B, rank, local_rank, hi_only, dev, stager_ok):
+    import torch
+    from robo_vln_amd import synth
     # two observation sets resident in HBM, used alternately (distinct frames per rank, same shapes)
     sets = []
     for k in range(2):
         o = synth.make_observations(cfg, B, step=2 * rank + k, seed=0, rgb_uint8=True)
-        sets.append({"rgb": torch.from_numpy(o["rgb"]).cuda(), "depth": torch.from_numpy(o["depth"]).cuda(),
-                     "instruction": torch.from_numpy(o["instruction"]).cuda()})
+        sets.append({"rgb": torch.from_numpy(o["rgb"]).to(dev), "depth": torch.from_numpy(o["depth"]).to(dev),
+                     "instruction": torch.from_numpy(o["instruction"]).to(dev)})
     R = cfg.num_recurrent_layers
-    state = {"hh": torch.zeros(R, B, cfg.hidden, device="cuda"), "lh": torch.zeros(R, B, cfg.hidden, device="cuda"), "tick": 0}
-    mask1 = torch.ones(B, device="cuda")
+    state = {"hh": torch.zeros(R, B, cfg.hidden, device=dev), "lh": torch.zeros(R, B, cfg.hidden, device=dev), "tick": 0}
+    mask1 = torch.ones(B, device=dev)
     stager = None
-    if args.h2d:
+    if args.h2d and stager_ok:
         from robo_vln_amd.obs import ObsStager
         stager = ObsStager(B, cfg.rgb_hw, cfg.depth_hw, cfg.instr_len, device=torch.device("cuda", local_rank))
         stager.host["rgb"].copy_(sets[0]["rgb"].cpu())
@@ -265,7 +329,7 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank):
                                               reuse_instruction=args.reuse_instruction and mask is None and state["tick"] > 3,
                                               host_frames=host_frames, gather=gather)
         return r
-    return cfg, B, eng, step, (hi_sd, lo_sd)
+    return step
 
 
 def build_probe_workload(args):
@@ -299,6 +363,23 @@ def build_probe_workload(args):
     return cfg, B, probe, step, alg_bytes, prec
 
 
+def _respawn(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: become the launcher -- re-execute this script under
+    torch.distributed.run with one rank per GPU on 127.0.0.1 and pass its exit code (and rank 0's ONE JSON line on stdout) through."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,10 +390,14 @@ def main():
     ap.add_argument("--prewarm", type=int, default=40, help="untimed clock-ramp steps before the W warm-up steps (0 for profiler runs)")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the additional sustained measurement reported as `sustained` (0 = skip)")
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the BASELINE size of the config)")
-    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: total environments, split evenly over the ranks (BASELINE configs[2]: 512); "
-                                                               "default 0 = weak scaling at --batch per GPU")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling as the PRIMARY value: total environments, split evenly over the ranks; "
+                                                               "default 0 = weak scaling at --batch per GPU (N > 1 then adds a `strong` leg at --strong-total)")
+    ap.add_argument("--strong-total", type=int, default=512, help="N > 1: total environments of the additional strong-scaling leg reported as `strong` "
+                                                                  "(BASELINE configs[2]: 512; 0 = skip)")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"],
                     help="fp16 = the measured 16-bit mode (range-calibrated fp16 tiles); bf16 = bf16 tiles in BERT / RGB trunks / cross-modal block")
+    ap.add_argument("--bf16-leg", type=float, default=2.0, help="N = 1, configs[1], --precision fp16: seconds of an additional run of the SAME workload on a "
+                                                                 "`precision=\"bf16\"` engine, reported as `bf16_mode` (0 = skip)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: the per-step all-gather through torch.distributed instead of the library's own "
                                                                 "RCCL call behind the step (A/B of rounds 1-2 vs round 3)")
     ap.add_argument("--reuse-instruction", action="store_true",
@@ -326,6 +411,10 @@ def main():
                     "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        if args.config != 1:
+            raise SystemExit("--config 0/3/4 are single-GPU roofline lines; the multi-GPU workload is configs[1]/[2]")
+        _respawn(args)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its communicator
     # is created): keep the real stdout aside for the result line and point file descriptor 1 at stderr for everything else.
     sys.stdout.flush()
@@ -348,35 +437,44 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): use `python bench.py --gpus N` (spawns its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if world > 1 and args.config != 1:
         raise SystemExit("--config 0/3/4 are single-GPU roofline lines; the multi-GPU workload is configs[1]/[2]")
-    torch.cuda.set_device(local_rank)
+    dev = _device(local_rank)
+    if not STUB:
+        torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run (any N)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if STUB:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     alg_bytes = None
+    make_step = None
+    # N > 1 weak-scaling runs also time a strong-scaling leg (the same rollout of --strong-total environments split over the ranks; at N = 8 with the
+    # default 512 that is the weak leg's 64 per GPU again = BASELINE configs[2])
+    strong_B = 0
+    if world > 1 and args.config == 1 and not args.total_batch and args.strong_total:
+        if args.strong_total % world:
+            raise SystemExit("--strong-total must be a multiple of the number of ranks")
+        strong_B = args.strong_total // world
     if args.config == 3:
         cfg, B, eng, raw_step, alg_bytes, prec3 = build_probe_workload(args)
         weights = None
     else:
-        cfg, B, eng, raw_step, weights = build_act_workload(args, args.config, rank, world, local_rank)
-    global_B = B * world
-    lo_e, hi_e = shard_range(global_B, world, rank)     # this rank's contiguous block of environments e -> rank e // B
-    rec = torch.empty(B, 7, device="cuda")
-    all_rec = torch.empty(global_B, 7, device="cuda") if use_dist else rec
-    last = {}
+        cfg, B, eng, raw_step, weights, make_step = build_act_workload(args, args.config, rank, world, local_rank, strong_batch=strong_B)
+        if STUB and strong_B:
+            strong_B = min(strong_B, 2 * B)
 
     # N>1: the all-gather of step i can either sit on the critical path (what a rollout needs: the environments cannot produce
     # observation i+1 before they have record i) or be overlapped with the compute of step i+1 on a communication stream (an upper
     # bound that only a pipelined simulator could use).  `value` is the former; the latter is reported as an extra key.
-    comm = torch.cuda.Stream() if use_dist else None
-    pending = []
+    comm = torch.cuda.Stream() if use_dist and not STUB else None
     # the collective is enqueued by the LIBRARY behind the graph replay (hcm_act_gather, one ncclAllGather on the step's stream) unless
     # --torch-gather asks for the torch.distributed call per step of rounds 1-2 (A/B)
     lib_gather = use_dist and args.config == 1 and not args.torch_gather
@@ -390,103 +488,144 @@ def main():
             if rank == 0:
                 print("bench.py: " + gather_note, file=sys.stderr)
 
-    def step(mask=None, overlap=False):
-        if use_dist and overlap and len(pending) >= 2:
-            torch.cuda.current_stream().wait_event(pending.pop(0))
-        if lib_gather and not overlap:
-            full = raw_step(mask, gather=True)          # ONE RCCL all-gather of the (B,7) records per step, in stream order, issued by libhcm
-            last["full"] = full
-            last["r"] = full[lo_e:hi_e]
-            return
-        r = raw_step(mask)
-        last["r"] = r
-        last["full"] = all_rec
-        if not use_dist:
-            return
-        if not overlap:
-            gather_records(r, all_rec)                  # ONE RCCL all-gather of the (B,7) records per step, in stream order
-            return
-        ready = torch.cuda.Event()
-        ready.record()
-        comm.wait_event(ready)
-        with torch.cuda.stream(comm):
-            gather_records(r, all_rec)
-            done = torch.cuda.Event()
-            done.record(comm)
-        pending.append(done)
+    def run_leg(B, raw_step, steps, sustain=0.0, with_overlap=False):
+        """One measured leg at B environments per rank: rank-tagged gather check, untimed warm-up, K timed steps between barriers (MAX over ranks),
+        validation of what the step returned.  -> dict(dt, host_us, ranks_seen, sustained, overlapped)"""
+        global_B = B * world
+        lo_e, hi_e = shard_range(global_B, world, rank)     # this rank's contiguous block of environments e -> rank e // B
+        all_rec = torch.empty(global_B, 7, device=dev) if use_dist else None
+        last = {}
+        pending = []
 
-    def timed(n, overlap=False):
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step(overlap=overlap)
-        last["host_s"] = (time.perf_counter() - t0) / n          # host time to ENQUEUE a step (no synchronisation inside)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        def step(mask=None, overlap=False):
+            if use_dist and overlap and len(pending) >= 2:
+                torch.cuda.current_stream().wait_event(pending.pop(0))
+            if lib_gather and not overlap:
+                full = raw_step(mask, gather=True)          # ONE RCCL all-gather of the (B,7) records per step, in stream order, issued by libhcm
+                last["full"] = full
+                last["r"] = full[lo_e:hi_e]
+                return
+            r = raw_step(mask)
+            last["r"] = r
+            last["full"] = all_rec
+            if not use_dist:
+                return
+            if not overlap:
+                gather_records(r, all_rec)                  # ONE all-gather of the (B,7) records per step, in stream order
+                return
+            ready = torch.cuda.Event()
+            ready.record()
+            comm.wait_event(ready)
+            with torch.cuda.stream(comm):
+                gather_records(r, all_rec)
+                done = torch.cuda.Event()
+                done.record(comm)
+            pending.append(done)
 
-    if use_dist:
-        # prove that the collective moves every rank's rows to every rank: rank-tagged records, checked on all ranks
-        tag = (torch.arange(B * 7, device="cuda", dtype=torch.float32).reshape(B, 7) + 1000.0 * rank)
-        gather_records(tag, all_rec)
-        torch.cuda.synchronize()
-        want = torch.cat([torch.arange(B * 7, dtype=torch.float32).reshape(B, 7) + 1000.0 * r for r in range(world)]).cuda()
-        assert torch.equal(all_rec, want), f"rank {rank}: all-gather did not deliver every rank's rows in rank order"
+        def timed(n, overlap=False):
+            if use_dist:
+                dist.barrier()
+            _sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step(overlap=overlap)
+            last["host_s"] = (time.perf_counter() - t0) / n          # host time to ENQUEUE a step (no synchronisation inside)
+            _sync()
+            if use_dist:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
 
-    # two untimed steps before the W warm-up steps: the library runs a new (batch, pointer set) eagerly once and captures its
-    # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is (x2: two observation sets)
-    zero = torch.zeros(B, device="cuda")
-    step(zero)
-    for _ in range(5):
-        step()
-    for _ in range(args.prewarm):                      # ~0.25 s of untimed steps so that the clocks have ramped (a fixed
-        step()                                         # count: every rank must issue the same number of all-gathers)
-    for _ in range(args.warmup):
-        step()
-    dt = timed(args.steps)
-    host_us = last["host_s"] * 1e6
-    # what the step returned is checked, not only timed: finite, and (N>1) this rank's rows of the gathered records are its own
-    r = last["r"]
-    assert torch.isfinite(r.float()).all(), "non-finite outputs"
-    if use_dist:
-        full = last["full"]
-        assert full.shape == (global_B, 7) and torch.equal(full[lo_e:hi_e], r), "gathered records do not contain this rank's rows"
-        chk = full.double().sum().reshape(1)
-        lo_c, hi_c = chk.clone(), chk.clone()
-        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
-        assert float(lo_c) == float(hi_c), "ranks disagree on the gathered records"
-
-    sustained = None
-    if args.sustain > 0:
-        n_s = max(args.steps, int(args.sustain / (dt / args.steps)) + 1)
+        ranks_seen = [0]
         if use_dist:
-            t = torch.tensor([n_s], device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            n_s = int(t.item())
-        dts = timed(n_s)
-        sustained = {"seconds": round(dts, 3), "steps": n_s, "value": round(global_B * n_s / dts, 2), "ms_per_step": round(dts / n_s * 1e3, 3)}
-    overlapped = None
-    if use_dist:
-        for _ in range(4):
-            step(overlap=True)
-        dto = timed(args.steps, overlap=True)
-        torch.cuda.current_stream().wait_stream(comm)
-        overlapped = {"value": round(global_B * args.steps / dto, 2), "ms_per_step": round(dto / args.steps * 1e3, 3),
-                      "note": "all-gather of step i on a communication stream, overlapping the compute of step i+1 (needs a pipelined simulator)"}
+            # prove that the collective moves every rank's rows to every rank: rank-tagged records, checked on all ranks
+            tag = (torch.arange(B * 7, device=dev, dtype=torch.float32).reshape(B, 7) + 1000.0 * rank)
+            gather_records(tag, all_rec)
+            _sync()
+            want = torch.cat([torch.arange(B * 7, dtype=torch.float32).reshape(B, 7) + 1000.0 * r for r in range(world)]).to(dev)
+            assert torch.equal(all_rec, want), f"rank {rank}: all-gather did not deliver every rank's rows in rank order"
+            ranks_seen = sorted({int(v) for v in (all_rec[::B, 0] // 1000.0).tolist()})
+            assert ranks_seen == list(range(world)), ranks_seen
+
+        # two untimed steps before the W warm-up steps: the library runs a new (batch, pointer set) eagerly once and captures its
+        # hipGraph on the second call -- neither belongs in anybody's timed region, whatever W is (x2: two observation sets)
+        zero = torch.zeros(B, device=dev)
+        step(zero)
+        for _ in range(5):
+            step()
+        for _ in range(args.prewarm):                      # ~0.25 s of untimed steps so that the clocks have ramped (a fixed
+            step()                                         # count: every rank must issue the same number of all-gathers)
+        for _ in range(args.warmup):
+            step()
+        dt = timed(steps)
+        res = {"B": B, "global_B": global_B, "dt": dt, "steps": steps, "host_us": last["host_s"] * 1e6, "ranks_seen": ranks_seen,
+               "sustained": None, "overlapped": None}
+        # what the step returned is checked, not only timed: finite, and (N>1) this rank's rows of the gathered records are its own
+        r = last["r"]
+        assert torch.isfinite(r.float()).all(), "non-finite outputs"
+        if use_dist:
+            full = last["full"]
+            assert full.shape == (global_B, 7) and torch.equal(full[lo_e:hi_e], r), "gathered records do not contain this rank's rows"
+            chk = full.double().sum().reshape(1)
+            lo_c, hi_c = chk.clone(), chk.clone()
+            dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+            assert float(lo_c) == float(hi_c), "ranks disagree on the gathered records"
+        if sustain > 0:
+            n_s = max(steps, int(sustain / (dt / steps)) + 1)
+            if use_dist:
+                t = torch.tensor([n_s], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                n_s = int(t.item())
+            dts = timed(n_s)
+            res["sustained"] = {"seconds": round(dts, 3), "steps": n_s, "value": round(global_B * n_s / dts, 2), "ms_per_step": round(dts / n_s * 1e3, 3)}
+        if with_overlap and comm is not None:
+            for _ in range(4):
+                step(overlap=True)
+            dto = timed(steps, overlap=True)
+            torch.cuda.current_stream().wait_stream(comm)
+            res["overlapped"] = {"value": round(global_B * steps / dto, 2), "ms_per_step": round(dto / steps * 1e3, 3),
+                                 "note": "all-gather of step i on a communication stream, overlapping the compute of step i+1 (needs a pipelined simulator)"}
+        return res
+
+    leg = run_leg(B, raw_step, args.steps, sustain=args.sustain, with_overlap=use_dist)
+    global_B, dt, host_us = leg["global_B"], leg["dt"], leg["host_us"]
+    sustained, overlapped = leg["sustained"], leg["overlapped"]
+    strong = None
+    if strong_B and make_step is not None:
+        if strong_B == B:
+            strong = {"total_batch": global_B, "per_gpu_batch": B, "value": round(global_B * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                      "note": "identical to the weak leg at this N (total / N = the weak per-GPU batch): the same timed region"}
+        else:
+            sl = run_leg(strong_B, make_step(strong_B), args.steps)
+            strong = {"total_batch": sl["global_B"], "per_gpu_batch": strong_B, "value": round(sl["global_B"] * args.steps / sl["dt"], 2),
+                      "ms_per_step": round(sl["dt"] / args.steps * 1e3, 3), "host_us_per_step": round(sl["host_us"], 1), "ranks_seen": sl["ranks_seen"]}
+    # the "bf16" mode of the SAME workload on a second engine (N = 1 default run only): driver-visible throughput of the mode whose parity
+    # tests/test_parity_gpu.py asserts at 1e-2
+    bf16_mode = None
+    if (world == 1 and args.config == 1 and args.precision == "fp16" and args.bf16_leg > 0 and not STUB and not args.h2d and not args.reuse_instruction
+            and not args.batch and not args.total_batch):
+        try:
+            import copy
+            a2 = copy.copy(args)
+            a2.precision = "bf16"
+            _, B2, eng2, step2, _, _ = build_act_workload(a2, 1, rank, world, local_rank)
+            n2 = max(10, int(args.bf16_leg / (dt / args.steps)))
+            l2 = run_leg(B2, step2, n2)
+            bf16_mode = {"value": round(l2["global_B"] * n2 / l2["dt"], 2), "ms_per_step": round(l2["dt"] / n2 * 1e3, 3), "steps": n2,
+                         "dtype": dtype_string(a2, eng2), "note": "same workload, same timed-region protocol, on an engine built with precision=\"bf16\""}
+            eng2.close()
+        except Exception as e:           # never lose the headline number to the extra leg
+            bf16_mode = {"error": str(e)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = global_B * args.steps / dt
-        tr = pmc_traffic(args.config) if B == BATCH[args.config] and not args.total_batch else None
+        tr = pmc_traffic(args.config) if B == BATCH[args.config] and not args.total_batch and not STUB else None
         out = {
             "metric": "policy env-steps/sec (batched act()) at 256x256 RGB-D, 80-tok instr" if args.config == 1 else
                       f"policy env-steps/sec, BASELINE.json configs[{args.config}]",
@@ -500,13 +639,22 @@ def main():
                                        if world > 1 else "single GPU")},
             "host_us_per_step": round(host_us, 1),
         }
+        if STUB:
+            out["metric"] = "STUB ENGINE -- launch-plumbing test on CPU, not a measurement"
+            out["data"] = "HCM_BENCH_STUB=1: stand-in engine, gloo, no GPU"
         if use_dist:
+            out["ranks_seen"] = leg["ranks_seen"]
             out["config"]["all_gather"] = ("ncclAllGather enqueued by libhcm on the step's stream behind the hipGraph replay (hcm_act_gather)" if lib_gather
                                            else gather_note or "torch.distributed.all_gather_into_tensor per step (--torch-gather)")
+            out["weak"] = {"per_gpu_batch": B, "global_batch": global_B, "value": round(value, 2), "ms_per_step": round(ms, 3)} if not args.total_batch else None
+        if strong:
+            out["strong"] = strong
         if sustained:
             out["sustained"] = sustained
         if overlapped:
             out["overlapped_all_gather"] = overlapped
+        if bf16_mode:
+            out["bf16_mode"] = bf16_mode
         if args.config == 3:
             gb = alg_bytes / 1e9
             # BASELINE.json calls this configuration memory-bound; at 16-bit MFMA rates it is not (0.25 GFLOP and 0.46 MB per sample = 540 FLOP/B,
@@ -536,17 +684,17 @@ def main():
                 whole["basis"] = "cached-instruction variant: 36.9 - 13.83 (BERT) GFLOP per env-step x env-steps/s"
             roof = dict(whole)
             roof["scope"] = "whole step"
-            if args.precision != "fp32" and not args.no_kernel_probe and args.config in (1, 4):
+            if args.precision != "fp32" and not args.no_kernel_probe and args.config in (1, 4) and not STUB:
                 try:
                     L = cfg.instr_len
                     dk = dominant_kernel_probe(B, L)
                     top = dk["ffn1"]
                     k_tr = (tr or {}).get("dominant_kernel_GB_per_launch")
-                    # the JSON line's `roofline` is the DOMINANT KERNEL (gemm256_kernel on the BERT FFN1 shape), live HIP-event timing;
+                    # the JSON line's `roofline` is the DOMINANT KERNEL (gemm256f_kernel on the BERT FFN1 shape), live HIP-event timing;
                     # the whole-step view and the HBM-bound probe ride along as labelled sub-objects
                     roof = {"bound": "mfma", "achieved": top["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_peak"],
                             "traffic": k_tr, "traffic_unit": "GB per launch, averaged over this kernel's launches of the step (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic*.json)" if k_tr else None,
-                            "scope": "dominant kernel: gemm256_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
+                            "scope": "dominant kernel: gemm256f_kernel<f16> on BERT FFN1 (" + top["shape"] + f", GELU epilogue), {top['us_per_launch']} us per launch, "
                                      f"{top['gflop_per_launch']} algorithmic GFLOP per launch, 12 launches per step",
                             "bert_gemms": dk, "whole_step": whole}
                     roof["hbm_probe"] = hbm_kernel_probe(B)
@@ -557,7 +705,7 @@ def main():
             out["config"]["hipgraph"] = {"enabled": not args.no_graph, "inputs": "read in place from two alternating device buffer sets"}
         if hasattr(eng, "query"):
             out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
-        if not args.no_cpu_baseline and world == 1 and args.config == 1:          # reported on rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and args.config == 1 and not STUB:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, *weights)
             if args.cpu_batches:
                 out["cpu_baseline"]["batches"] = cpu_baseline_protocol(cfg, *weights)

@@ -190,6 +190,9 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
 /* Companion of HCM_ACT_REUSE_INSTRUCTION for batched rollouts in which a few environments start a new episode: recomputes
  * the cached instruction stream of the n listed environments (HOST array of indices into the batch) from ids (B,L) (device),
  * leaving the other environments' cached tensors untouched.  Needs a previous hcm_act / hcm_act_ex step at this batch size. */
+int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
+                            const int32_t* env_indices, int n, void* stream);
+
 /* ---- multi-GPU: environment-sharded replicas, ONE collective per step (no reference counterpart: the reference evaluates one
  * environment in one process, hierarchical_trainer.py:1088-1107).  One process per GPU, every rank a full weight replica stepping its own
  * B_local environments; the (B_local, 7) action records are all-gathered over RCCL / xGMI into the (world * B_local, 7) record of the whole batch,
@@ -197,15 +200,18 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
  * no Python call per step, no host synchronisation.  RCCL is resolved with dlopen when first asked for.
  *   hcm_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank through any side channel (torch.distributed broadcast, a file, MPI)
  *   hcm_comm_init        every rank, collectively: creates the handle's communicator (blocks until all `world` ranks have called)
- *   hcm_act_gather       hcm_act_ex + ncclAllGather(record -> gathered) on `stream`; B must be the same on every rank */
+ *   hcm_act_gather       hcm_act_ex + ncclAllGather(record -> gathered) on `stream`; B must be the same on every rank.  A rank whose own step
+ *                        fails (bad argument, workspace, launch error) STILL takes part in the collective, with an all-NaN record, and returns
+ *                        its error afterwards -- the private communicator has no watchdog, so a rank that simply returned would leave the
+ *                        others blocked in ncclAllGather; they see NaN rows for that rank's environments instead
+ *   hcm_comm_abort       ncclCommAbort of the handle's communicator (a rank that is going to stop stepping: an exception outside the library,
+ *                        shutdown after a peer's NaN record); the handle can create a new one with hcm_comm_init afterwards */
 int hcm_comm_unique_id(void* out128);
 int hcm_comm_init(hcm_handle h, const void* unique_id128, int rank, int world);
+int hcm_comm_abort(hcm_handle h);
 int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
                    int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                    int flags, float* gathered, void* stream);
-
-int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const int32_t* lengths, int B, int L,
-                            const int32_t* env_indices, int n, void* stream);
 
 /* fp16 range safety (no reference counterpart: the reference is fp32).  Sub-networks that store fp16 (all four in HCM_F16 mode, the depth
  * trunks in HCM_BF16 mode) have a range that ends at 65504.  hcm_finalize runs one forward on a synthetic batch with range hooks on every GEMM
@@ -284,6 +290,13 @@ int hcm_debug_get_tap(hcm_handle h, const char* name, float* host_out, int64_t c
  * HCM_IGEMM_PROF=1 (which selects instrumented builds of the 8-wave bf16 kernels).  out8: prologue, DMA issue,
  * fragment reads + MFMA issue, DMA wait, barrier, epilogue (cycles summed over waves), waves, K iterations. */
 int hcm_debug_igemm_prof(uint64_t* out8, int reset);
+/* Development aid: phase cycle totals of the profiled builds of the 256 x 256 GEMM kernels (`make DEV=1` library,
+ * hcm_op_linear_impl variants 13-15): out1024 = [16 workgroups][8 waves][8 counters], see csrc/gemm256.hip. */
+int hcm_debug_gemm256_prof(uint64_t* out1024, int reset);
+/* Development aid (`make DEV=1` library created under HCM_MARKS=1; otherwise returns 0): wall-clock stamps (100 MHz ticks) that one-lane marker
+ * kernels wrote at named points of the last step's chains -- how the three encoder chains really interleave inside a hipGraph-replayed step, which
+ * a kernel trace cannot show (rocprofv3 serialises the streams).  Returns the number of marks; names = '\n'-joined, in slot order. */
+int hcm_debug_marks(hcm_handle h, uint64_t* out256, char* names, int names_cap);
 
 /* Stand-alone operator entry points used by the kernel-level parity tests (device pointers, f32 or bf16
  * per `dtype`; layouts NHWC / row-major); implemented at the end of robo-vln_amd/csrc/api.cpp. */

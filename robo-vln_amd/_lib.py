@@ -62,6 +62,7 @@ EXPORTS = {
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hcm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "hcm_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hcm_comm_abort": (C.c_int, [C.c_void_p]),
     "hcm_act_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hcm_refresh_instruction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
@@ -74,6 +75,8 @@ EXPORTS = {
     "hcm_debug_enable_taps": (C.c_int, [C.c_void_p, C.c_int]),
     "hcm_debug_get_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hcm_debug_igemm_prof": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "hcm_debug_gemm256_prof": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "hcm_debug_marks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_int]),
     "hcm_op_conv2d": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 11 + [C.c_void_p]),
     "hcm_op_bottleneck_tail": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]),
     "hcm_op_bottleneck_tail_next": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 7 + [C.c_void_p]),

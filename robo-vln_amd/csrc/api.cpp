@@ -386,7 +386,24 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
         // the cross-modal block's verdict was formed on the unfolded features: judge it again behind the folded trunk
         if ((rebuild & 8) && !h->calib_bad[0] && !h->calib_bad[1]) rebuild &= ~8;
     }
+    // A chain of range folds that has not converged after kFoldPasses passes (each pass repairs only the FIRST non-finite position of the depth
+    // trunk; a fold can also bottom out) stops here: the trunk(s) still asking for a fold move to bf16 tiles -- always safe -- with their folds
+    // cleared, and the passes that remain only measure.  Without this the last re-build was applied but never measured and the handle reported
+    // success with stale ranges (round-3 advisor).
+    constexpr int kFoldPasses = 12, kMaxPasses = 16;
+    if (pass >= kFoldPasses && refold) {
+        if (refold & 2) rebuild |= 2;
+        if (refold & 4) rebuild |= 4;
+        refold = 0;
+    }
+    // a trunk that leaves fp16 does not need (and no longer reports) a range fold
+    if (rebuild & 2) { for (int pos = 0; pos < hcm_ctx::kDepthPos; ++pos) h->depth_fold[pos] = 1.f; h->range_fold &= ~2; }
+    if (rebuild & 4) { h->rgb_fold = 1.f; h->range_fold &= ~4; }
     if (!rebuild && !refold) return HCM_OK;
+    if (pass >= kMaxPasses)
+        return fail(h, HCM_ERR_STATE, "fp16 range calibration did not converge within " + std::to_string(kMaxPasses) + " passes (max |x| " +
+                    std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) + " depth / " + std::to_string(h->calib_max[2]) +
+                    " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal): create the engine with precision bf16");
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
                     " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
@@ -431,7 +448,7 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     // once more on the re-built engine: what was downstream of the overflow is measured on clean inputs now (the reported ranges are
     // those of the engine as it runs).  A sub-network moves to bf16 at most once; folds converge in a pass or two per position (one blind step
     // and one re-centring for a position that went non-finite), the pass limit bounds a pathological chain of them.
-    return pass < 16 ? calibrate_run(h, rgb, rgb_dt, depth, ids, ids_dt, B, L, stream, pass + 1) : HCM_OK;
+    return calibrate_run(h, rgb, rgb_dt, depth, ids, ids_dt, B, L, stream, pass + 1);       // bounded by kMaxPasses above: the last pass only measures
 }
 // deterministic synthetic calibration batch for hcm_finalize: frames of mid-range noise, ids spread over the vocabulary
 static int calibrate_synthetic(hcm_ctx* h) {
@@ -491,6 +508,10 @@ int hcm_finalize(hcm_handle h) {
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;
+        if (dev_env("HCM_MARKS")) {          // development build only: wall-clock stamps inside the step (hcm_debug_marks)
+            if (hipMalloc((void**)&h->marks_dev, 256 * 8) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
+            (void)hipMemset(h->marks_dev, 0, 256 * 8);
+        }
         if (hipMalloc((void**)&h->calib_buf, hcm_ctx::kCalibWords * 4) != hipSuccess) return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
         if (hipMemset(h->calib_buf, 0, hcm_ctx::kCalibWords * 4) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipMemset failed");       // words 0-7: calibration, 12: step guard, 16..: conv positions
         // fp16 range check on a synthetic batch; a real batch can follow through hcm_calibrate (reserved[4]: keep the host weights for it)
@@ -817,6 +838,7 @@ void hcm_destroy(hcm_handle h) {
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->pred_buf) (void)hipFree(h->pred_buf);
     if (h->calib_buf) (void)hipFree(h->calib_buf);
+    if (h->marks_dev) (void)hipFree(h->marks_dev);
     if (h->stage_rgb) (void)hipFree(h->stage_rgb);
     if (h->stage_depth) (void)hipFree(h->stage_depth);
     if (h->len_buf) (void)hipFree(h->len_buf);
@@ -843,6 +865,26 @@ int hcm_debug_igemm_prof(uint64_t* out8, int reset) {
     unsigned long long v[8];
     if (hcm::igemm_prof_read(v, reset != 0) != hipSuccess) return HCM_ERR_HIP;
     for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    return HCM_OK;
+}
+
+int hcm_debug_marks(hcm_handle h, uint64_t* out256, char* names, int names_cap) {
+    REQUIRE(h && out256 && names && names_cap > 0, HCM_ERR_ARG, "null argument");
+    names[0] = 0;
+    if (!h->marks_dev) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(h, HCM_ERR_HIP, "hipDeviceSynchronize failed");
+    if (hipMemcpy(out256, h->marks_dev, 256 * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, HCM_ERR_HIP, "marks copy failed");
+    std::string all;
+    for (const std::string& n : h->mark_names) { all += n; all += '\n'; }
+    REQUIRE((int)all.size() < names_cap, HCM_ERR_ARG, "names buffer too small");
+    std::memcpy(names, all.c_str(), all.size() + 1);
+    return (int)h->mark_names.size();
+}
+
+int hcm_debug_gemm256_prof(uint64_t* out1024, int reset) {
+    if (!out1024) return HCM_ERR_ARG;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    if (hcm::gemm256_prof_read(reinterpret_cast<unsigned long long*>(out1024), reset != 0) != hipSuccess) return HCM_ERR_HIP;
     return HCM_OK;
 }
 

@@ -6,6 +6,7 @@
 // No reference counterpart: the reference evaluates one environment in one process (hierarchical_trainer.py:1088-1107).
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "model.h"
@@ -22,27 +23,34 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommAbort)(Comm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    if (r.lib || !r.err.empty()) return r;
+void rccl_load(Rccl& r) {
     // the copy the process already maps (a torch process: torch/lib/librccl.so) wins by SONAME; otherwise ROCm's
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
-    if (!r.lib) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return r; }
+    if (!r.lib) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
     r.GetUniqueId = (int (*)(UniqueId*))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(Comm*, int, UniqueId, int))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (int (*)(Comm))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (int (*)(const void*, void*, size_t, int, Comm, hipStream_t))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.CommAbort = (int (*)(Comm))dlsym(r.lib, "ncclCommAbort");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { r.err = "librccl lacks an expected symbol"; r.lib = nullptr; }
+}
+
+// resolved once per process, also when two handles on two threads ask for their communicators at the same moment
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
     return r;
 }
 
@@ -96,17 +104,36 @@ int hcm_comm_init(hcm_handle h, const void* unique_id128, int rank, int world) {
     return HCM_OK;
 }
 
+int hcm_comm_abort(hcm_handle h) {
+    if (!h) return HCM_ERR_ARG;
+    if (!h->comm) return HCM_OK;
+    Rccl& r = rccl();
+    // ncclCommAbort frees the communicator and fails outstanding / future operations on it on THIS rank; peers blocked in a collective with
+    // this rank are released by their own abort (or by this process exiting)
+    if (r.CommAbort) (void)r.CommAbort((Comm)h->comm); else if (r.CommDestroy) (void)r.CommDestroy((Comm)h->comm);
+    h->comm = nullptr;
+    h->comm_world = 0;
+    h->comm_rank = 0;
+    return HCM_OK;
+}
+
 int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
                    int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                    int flags, float* gathered, void* stream) {
     if (!h) return HCM_ERR_ARG;
     if (!h->comm) return fail(h, HCM_ERR_STATE, "hcm_act_gather: no communicator (hcm_comm_init)");
     if (!gathered) return fail(h, HCM_ERR_ARG, "hcm_act_gather: null gather buffer");
+    if (!record || B < 1) return fail(h, HCM_ERR_ARG, "hcm_act_gather: bad record buffer / batch");
     const int rc = hcm_act_ex(h, rgb, rgb_dtype, depth, ids, ids_dtype, lengths, B, L, hi_h_in, lo_h_in, mask, record, hi_h_out, lo_h_out, flags, stream);
-    if (rc != HCM_OK) return rc;
+    const std::string step_err = rc != HCM_OK ? h->err : std::string();
+    // A rank whose own step failed STILL takes part in the collective -- with a poisoned (all-NaN) record -- and reports its error afterwards:
+    // the other ranks are already inside (or about to enter) ncclAllGather for this step, and the private communicator has no watchdog that
+    // would release them (round-3 advisor).  They see NaN rows for this rank's environments; hcm_comm_abort tears the communicator down.
+    if (rc != HCM_OK) (void)hipMemsetAsync(record, 0xFF, (size_t)B * 7 * sizeof(float), (hipStream_t)stream);
     // stream order makes the record complete before the collective reads it; every rank contributes B rows of 7 floats
     Rccl& r = rccl();
     const int nrc = r.AllGather(record, gathered, (size_t)B * 7, kNcclFloat32, (Comm)h->comm, (hipStream_t)stream);
+    if (rc != HCM_OK) return fail(h, rc, step_err + " [this rank still contributed a NaN record to the step's all-gather]");
     if (nrc != kNcclSuccess) return fail(h, HCM_ERR_HIP, nccl_msg(r, "ncclAllGather", nrc));
     return HCM_OK;
 }

@@ -1209,4 +1209,14 @@ hipError_t launch_convert(const void* x, int dt_in, void* y, int dt_out, size_t 
     return hipGetLastError();
 }
 
+
+// Development aid (make DEV=1, HCM_MARKS=1): a one-lane kernel that stores the constant 100 MHz wall clock -- placed by forward.cpp between the
+// launches of a chain, it records WHEN that chain reached that point of the (hipGraph-replayed, multi-stream) step.  rocprofv3's kernel trace
+// serialises the streams (kernels in flight: 1 for 91 % of a traced step), so it cannot show how the three chains really interleave.
+__global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+hipError_t launch_mark(unsigned long long* slot, hipStream_t s) {
+    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, s, slot);
+    return hipGetLastError();
+}
+
 }  // namespace hcm

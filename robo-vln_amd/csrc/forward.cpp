@@ -247,6 +247,7 @@ struct Fwd {
             if (!dry) ck(launch_vpool3s2(slot[0], slot[1], dt, B, Ho, Wo / 2, c1, s), "maxpool (vertical half)");
         } else if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
         Act x{slot[1], B, Hp, Wp, c1};
+        mark(tapname + ".stem_end");
         int xi = 1;
         int bidx = 0;
         int pre = -1;          // slot already holding THIS block's 1x1 reduction output (computed by the previous block's fused launch)
@@ -288,7 +289,7 @@ struct Fwd {
                     xi = fo;
                     bidx += (int)run;
                     bi += run - 1;
-                    if (bidx == 13) tap(tapname + "_layer3", x.p, true, {B, x.H, x.W, x.C});
+                    if (bidx == 13) { tap(tapname + "_layer3", x.p, true, {B, x.H, x.W, x.C}); mark(tapname + ".layer3_end"); }
                     continue;
                 }
             }
@@ -307,17 +308,20 @@ struct Fwd {
             // BN-folded trunks, 64 / 128 mid channels (layer1, layer2), 16-bit storage: 3x3 conv + 1x1 expansion + identity in ONE
             // launch, the mid tensor stays in LDS (igemm.hip: bneck23_kernel; bit-identical to the two launches)
             static const bool no_tail = dev_env("HCM_NO_BNECK_FUSE") != nullptr;
-            if (!t.gn && !no_tail && (b.c2.dt == DT_BF16 || b.c2.dt == DT_F16) && (b.c2.Cout == 64 || b.c2.Cout == 128) && b.c2.KH == 3 &&
+            static const bool no_next = dev_env("HCM_NO_BNECK_NEXT") != nullptr;
+            static const bool no_256 = dev_env("HCM_NO_BNECK256") != nullptr;        // layer3 (256 mid channels) as a launch per conv (A/B, toggle test)
+            const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
+            static const int next_only = dev_env("HCM_BNECK_NEXT_ONLY") ? atoi(dev_env("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
+            const bool next = nb && !no_next && (!next_only || next_only == b.c2.Cout) && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
+                              nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
+                              ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128 || nb->c1.Cout == 256)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
+            // (256 mid channels -- layer3: only the "tail + next block's reduction" form exists, so the layer's last block stays a launch per conv)
+            const bool c1_ok = b.c2.Cout == 64 || b.c2.Cout == 128 || (b.c2.Cout == 256 && next && !no_256);
+            if (!t.gn && !no_tail && (b.c2.dt == DT_BF16 || b.c2.dt == DT_F16) && c1_ok && b.c2.KH == 3 &&
                 b.c2.Cin == b.c2.Cout && b.c2.Kp == 9 * b.c2.Cin && b.c3.Cout == 4 * b.c2.Cout && b.c3.Kp == b.c2.Cout && b.c2.bias && b.c3.bias &&
                 b.c3.groups == b.c2.groups) {
                 const void* idt = x.p;
-                static const bool no_next = dev_env("HCM_NO_BNECK_NEXT") != nullptr;
                 static const bool no_dsfold = dev_env("HCM_NO_BNECK_DSFOLD") != nullptr;
-                const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
-                static const int next_only = dev_env("HCM_BNECK_NEXT_ONLY") ? atoi(dev_env("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
-                const bool next = nb && !no_next && (!next_only || next_only == b.c2.Cout) && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
-                                  nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
-                                  ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
                 // layer1's first block: its 1x1 down-sample conv (64 -> 256, same stride) rides in the expansion GEMM as 64 more K columns
                 // ([W3 | Wds], bias b3 + bds): no down-sample launch, no identity tensor.  One rounding instead of two on that path, so
                 // not bit-identical to the separate launches (closer to the fp32 oracle)
@@ -355,8 +359,10 @@ struct Fwd {
                 x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
                 xi = fr[2];
                 ++bidx;
-                if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16)
+                if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16) {
                     tap(tapname + "_layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4), x.p, true, {B, x.H, x.W, x.C});
+                    mark(tapname + ".layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4) + "_end");
+                }
                 continue;
             }
             Act o2{sb, B, Ho2, Wo2, CO(b.c2)};
@@ -376,8 +382,10 @@ struct Fwd {
             x = Act{sc, B, Ho2, Wo2, CO(b.c3)};
             xi = fr[2];
             ++bidx;
-            if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16)
+            if (bidx == 3 || bidx == 7 || bidx == 13 || bidx == 16) {
                 tap(tapname + "_layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4), x.p, true, {B, x.H, x.W, x.C});
+                mark(tapname + ".layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4) + "_end");
+            }
         }
         if (t.gn) {
             int fr = (xi + 1) & 3;
@@ -486,7 +494,9 @@ struct Fwd {
             ck(launch_igemm(g, lw.dt, s), "bert linear (f32 stream)");
         };
         int li = 0;
+        mark("bert.embed");
         for (const BertLayerW& l : w.layers) {
+            if (li) mark("bert.layer" + std::to_string(li));
             linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
             if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
                                           L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
@@ -836,7 +846,9 @@ struct Fwd {
         bert(ctx->hi.bert, ids, ids_dt, B, hb.emb, ctx->cur_lens);
         calib_slot = -1;
         tap("hi.bert", hb.emb, true, {B, ctx->cur_L, ctx->cfg.bert_hidden});
+        mark("bert.end");
         hi_ins_pre(B, hb);
+        mark("bert.ins_pre_end");
     }
     // Visual_Ling_Attn x2 (the cross-modal part), poolers, state encoder, head (:200-232)
     void hi_tail(int B, HiBufs& hb, const float* h_in, const float* mask, float* logits, int ld_logits, float* h_out) {
@@ -1184,6 +1196,14 @@ struct Fwd {
         }
     }
     void on(hipStream_t st) { s = st; }
+    // development aid: stamp the wall clock at this point of the current chain (no-op unless hcm_create saw HCM_MARKS=1 in a DEV build)
+    void mark(const std::string& name) {
+        if (!ctx->marks_dev || dry) return;
+        size_t i = 0;
+        for (; i < ctx->mark_names.size(); ++i) if (ctx->mark_names[i] == name) break;
+        if (i == ctx->mark_names.size()) { if (i >= 256) return; ctx->mark_names.push_back(name); }
+        ck(launch_mark(ctx->marks_dev + i, s), "mark");
+    }
 
     void step(bool do_hi, bool do_lo, const void* rgb, int rgb_dt, const float* depth, const void* ids, int ids_dt, int B,
               const float* hi_h_in, const float* lo_h_in, const float* mask, const int64_t* subtask,
@@ -1216,11 +1236,13 @@ struct Fwd {
         // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
         // chain 3: BERT
         on(a2);
+        mark("bert.start");
         // (the workspace layout is identical from step to step, so hb.I / hb.Q of the previous step are still in place when the
         //  caller declares the instructions unchanged)
         if (do_hi && !(skip & 8) && !(ctx->reuse_instruction && !dry)) hi_bert(ids, ids_dt, B, hb);
         // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
         on(a1);
+        mark("depth.start");
         const bool dshare = do_hi && do_lo && ctx->hi.depth_shared && !ctx->lo.depth_simple;
         const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;
         if (ctx->cfg.ablate_depth) {
@@ -1232,8 +1254,10 @@ struct Fwd {
         } else if (do_hi && !(skip & 4)) hi_depth(depth, B, hb);
         on(a1);
         if (do_lo && !pair && !dshare && !ctx->cfg.ablate_depth && !(skip & 4)) lo_depth(depth, B, lb);
+        mark("depth.end");
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
+        mark("rgb.start");
         const bool rshare = do_hi && do_lo && ctx->hi.rgb_shared && !ctx->lo.rgb_simple;
         const bool rpair = do_hi && do_lo && ctx->hi.has_rgb_pair && !ctx->lo.rgb_simple;
         if (ctx->cfg.ablate_rgb) { if (!(skip & 1)) ablated_encoder(0, B, do_hi ? &hb : nullptr, do_lo ? &lb : nullptr); }
@@ -1245,7 +1269,9 @@ struct Fwd {
         on((rgb_serial || ctx->host_frames) ? main_s : a0);        // (staged frames: behind their copy)
         if (do_hi && do_lo && !rpair && !rshare && !ctx->cfg.ablate_rgb && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
+        mark("rgb.end");
         if (multi) fork_join_end(4);
+        mark("tail.start");
         if (do_hi && do_lo && T == 1) { lo_early = &lb; lo_h_in_early = lo_h_in; }
         if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);
         const int64_t* st_ids = subtask;
@@ -1255,6 +1281,7 @@ struct Fwd {
             st_ids = ctx->pred_buf;
         }
         if (do_lo) lo_tail(B, lb, lo_h_in, mask, st_ids, vel, ld_vel, stop, ld_stop, lo_h_out);
+        mark("tail.end");
     }
 };
 

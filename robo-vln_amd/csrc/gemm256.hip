@@ -89,212 +89,10 @@ __device__ __forceinline__ void g_quad(g_f32x4 (&acc)[4][8], const uint4 (&wf)[2
             for (int j = 0; j < 4; ++j) GMma<T>::run(acc[NQ * 2 + i][MQ * 4 + j], wf[ks][i], xf[ks][j]);
 }
 
-// SCHED: how the 8 DMA pieces a wave requests per K tile are spread over the four phases (0: 2/2/2/2; 1: 0/3/1/4 -- the pieces go where
-// the phase has few fragment reads: 12/4/8/0).  DBG (timing experiments only, results are then wrong): 1 no DMA in the loop, 2 no fragment
-// reads after the first tile, 4 no MFMAs.
-template <typename T, int SCHED = 0, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // ---- tile of this block: XCD (blockIdx % 8) owns a rectangle of the tile grid
-    int tile_m, tile_n;
-    {
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
-        const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
-        const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
-        const int nn = n_hi - n_lo;
-        if (nn <= 0 || local >= (m_hi - m_lo) * nn) return;
-        tile_m = m_lo + local / nn;
-        tile_n = n_lo + local % nn;
-    }
-    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;          // wave (wr, wc): tokens [wr*128, +128) x channels [wc*64, +64)
-    const int rin = lane >> 3;                        // row inside an 8-row DMA piece
-    const int csrc = (lane & 7) ^ rin;                // source chunk this lane fetches (swizzle on the source side)
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
-    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
-
-    // DMA pieces of this wave: per half-tile h (X-h: token rows {h*64..+64} of both row groups; W-h: channel rows {h*32..+32} of all
-    // four column groups) pieces q = 2*wave + i, i = 0, 1.  Out-of-range rows present an offset beyond num_records: hardware zero fill.
-    unsigned xsrc[2][2], wsrc[2][2], xdst[2][2], wdst[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = 2 * wave + i;
-            const int xrow = (q >> 3) * 128 + h * 64 + (q & 7) * 8;
-            const int wrow = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
-            const int m = m0 + xrow + rin, n = n0 + wrow + rin;
-            xsrc[h][i] = m < p.M ? (unsigned)(m * p.ldx + csrc * 8) * 2u : 0x80000000u;
-            wsrc[h][i] = n < p.N ? (unsigned)(n * p.ldw + csrc * 8) * 2u : 0x80000000u;
-            xdst[h][i] = lds_base + (unsigned)xrow * 128u;
-            wdst[h][i] = lds_base + G_WOFF + (unsigned)wrow * 128u;
-        }
-    auto dma_x = [&](int h, unsigned buf, unsigned kbyte) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) g_dma16(xdst[h][i] + buf, xsrc[h][i] + kbyte, rx);
-    };
-    auto dma_w = [&](int h, unsigned buf, unsigned kbyte) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) g_dma16(wdst[h][i] + buf, wsrc[h][i] + kbyte, rw);
-    };
-    // piece q of a K tile in request order: X-h0[0,1], W-h0[0,1], W-h1[0,1], X-h1[0,1] (the order the next tile's phases need them)
-    auto piece = [&](int q, unsigned buf, unsigned kbyte) {
-        const int i = q & 1;
-        if (q < 2) g_dma16(xdst[0][i] + buf, xsrc[0][i] + kbyte, rx);
-        else if (q < 4) g_dma16(wdst[0][i] + buf, wsrc[0][i] + kbyte, rw);
-        else if (q < 6) g_dma16(wdst[1][i] + buf, wsrc[1][i] + kbyte, rw);
-        else g_dma16(xdst[1][i] + buf, xsrc[1][i] + kbyte, rx);
-    };
-
-    g_f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / 64;
-    // prologue: the whole first K tile
-    dma_x(0, 0, 0); dma_w(0, 0, 0); dma_w(1, 0, 0); dma_x(1, 0, 0);
-    g_wait_vmcnt<0>();
-    G_BAR();
-    if (wr == 1) G_BAR();                              // stagger the second row group by one barrier interval
-
-    const int fr = lane & 15, fg = lane >> 4;
-    uint4 xf[2][4], wf0[2][2], wf1[2][2];
-    auto rd_x = [&](int mq, unsigned buf) {
-        const char* sx = smem + buf;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wr * 128 + mq * 64 + j * 16 + fr;
-                xf[ks][j] = *reinterpret_cast<const uint4*>(sx + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
-            }
-    };
-    auto rd_w = [&](uint4 (&wf)[2][2], int nq, unsigned buf) {
-        const char* sw = smem + buf + G_WOFF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wc * 64 + nq * 32 + i * 16 + fr;
-                wf[ks][i] = *reinterpret_cast<const uint4*>(sw + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
-            }
-    };
-
-    // K tile t lives in buffer t & 1; tile t+1 is requested into the other buffer while t is consumed (that buffer's last reader,
-    // the second row group's phase 3 of tile t-1, finished two barrier intervals before the first request)
-    // SCHED 2: the two DMA pieces of a phase are issued from INSIDE its MFMA cluster (after the 4th and the 12th MFMA), where an LDS-DMA
-    // instruction costs ~60 cycles of issue instead of 100-185 in a phase that is also reading fragments (MI355X_MICROARCH.md, cycle table)
-    auto mma_phase_dma = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2], auto LIVE, int q0, unsigned buf, unsigned kbyte) {
-        constexpr int nq = decltype(NQ)::value, mq = decltype(MQ)::value;
-        constexpr bool live = decltype(LIVE)::value;
-        G_BAR();
-        __builtin_amdgcn_s_setprio(1);
-        int cnt = 0;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    GMma<T>::run(acc[nq * 2 + i][mq * 4 + j], wf[ks][i], xf[ks][j]);
-                    ++cnt;
-                    if (live && (cnt == 4 || cnt == 12)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        piece(q0 + (cnt == 12), buf, kbyte);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-        __builtin_amdgcn_s_setprio(0);
-        G_BAR();
-    };
-    auto mma_phase = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2]) {
-        G_BAR();
-        if constexpr (!(DBG & 4)) {
-            __builtin_amdgcn_s_setprio(1);
-            g_quad<T, decltype(NQ)::value, decltype(MQ)::value>(acc, wf, xf);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        G_BAR();
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    auto tile_body = [&](int t, auto LIVE) {
-        constexpr bool live = decltype(LIVE)::value && !(DBG & 1);
-        const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
-        const unsigned kb = (unsigned)(t + 1) * 128u;
-        const bool rd = !(DBG & 2) || t == 0;
-        if constexpr (SCHED == 0) {
-            // ---- phase 1: channels 0-31 x tokens 0-63 of the wave's block
-            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
-            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); }
-            mma_phase(I0{}, I0{}, wf0);
-            // ---- phase 2: channels 32-63 x tokens 0-63
-            if (rd) rd_w(wf1, 1, cur);
-            if (live) { piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<4>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of THIS tile has landed
-            mma_phase(I1{}, I0{}, wf1);
-            // ---- phase 3: channels 32-63 x tokens 64-127
-            if (rd) rd_x(1, cur);
-            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); }
-            mma_phase(I1{}, I1{}, wf1);
-            // ---- phase 4: channels 0-31 x tokens 64-127 (both fragment sets are in registers)
-            if (live) { piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<2>(); }     // X-h0, W-h0, W-h1 of the next tile have landed
-            mma_phase(I0{}, I1{}, wf0);
-        } else if constexpr (SCHED == 3) {
-            // early requests, late waits: the whole next tile is requested in phases 1 and 2 (4 + 4 pieces) and every wait sits one phase
-            // before the first read of what it waits for -- every piece has >= 3 phases (~0.8 us) between request and first use, where
-            // SCHED 0 gives W-h1 one phase (~0.28 us: less than an L2 hit's latency under load).
-            //   before phase 2 reads W-h1 of THIS tile (pieces 4, 5; requested in phase 2 of the previous tile): younger = 6, 7 + 0-3 of the next
-            //   before phase 3 reads X-h1 of THIS tile (6, 7): younger = 0-7 of the next tile
-            //   before the next phase 1 reads X-h0 / W-h0 of the next tile (0-3): younger = 4-7 of the next tile
-            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
-            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<6>(); } else { g_wait_vmcnt<2>(); }
-            mma_phase(I0{}, I0{}, wf0);
-            if (rd) rd_w(wf1, 1, cur);
-            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<8>(); } else { g_wait_vmcnt<0>(); }
-            mma_phase(I1{}, I0{}, wf1);
-            if (rd) rd_x(1, cur);
-            mma_phase(I1{}, I1{}, wf1);
-            if (live) g_wait_vmcnt<4>();
-            mma_phase(I0{}, I1{}, wf0);
-        } else if constexpr (SCHED == 2) {
-            using LV = std::integral_constant<bool, live>;
-            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
-            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (its X-h1 may be in flight)
-            mma_phase_dma(I0{}, I0{}, wf0, LV{}, 0, nxt, kb);
-            if (rd) rd_w(wf1, 1, cur);
-            if (live) g_wait_vmcnt<2>(); else g_wait_vmcnt<0>();                          // X-h1 of this tile
-            mma_phase_dma(I1{}, I0{}, wf1, LV{}, 2, nxt, kb);
-            if (rd) rd_x(1, cur);
-            mma_phase_dma(I1{}, I1{}, wf1, LV{}, 4, nxt, kb);
-            if (live) g_wait_vmcnt<2>();                                                  // X-h0, W-h0 of the next tile
-            mma_phase_dma(I0{}, I1{}, wf0, LV{}, 6, nxt, kb);
-        } else {
-            // pieces where the fragment reads are few: 0 / 3 / 1 / 4
-            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
-            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (X-h1 may be in flight)
-            mma_phase(I0{}, I0{}, wf0);
-            if (rd) rd_w(wf1, 1, cur);
-            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); g_wait_vmcnt<3>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of this tile
-            mma_phase(I1{}, I0{}, wf1);
-            if (rd) rd_x(1, cur);
-            if (live) piece(3, nxt, kb);
-            mma_phase(I1{}, I1{}, wf1);
-            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<4>(); }   // X-h0, W-h0 of the next tile
-            mma_phase(I0{}, I1{}, wf0);
-        }
-    };
-    int t = 0;
-    for (; t + 1 < nk; ++t) tile_body(t, std::true_type{});
-    tile_body(t, std::false_type{});
-    if (wr == 0) G_BAR();                              // re-align the two row groups: every fragment read is done
-
+// Epilogue shared by the 8-wave kernels (gemm256_kernel, gemm256f_kernel): wave (wr, wc) holds tokens [wr*128, +128) x channels [wc*64, +64) of the tile,
+// acc[i][j] = channel fragment i x token fragment j, a lane holds 4 consecutive channels of one token.
+template <typename T>
+__device__ __forceinline__ void g_epilogue(const G256Dev& p, g_f32x4 (&acc)[4][8], char* smem, int m0, int n0, int tid, int wr, int wc, int fr, int fg) {
     if (p.res) {
         // ---- residual epilogue: y = act(acc + bias + res), one rounding -- the order of f32 operations of igemm_epilogue.  The accumulators
         // go through an f32 LDS image of HALF the tile at a time (128 rows x 256 channels, rows padded to 1040 B); in the row pass every
@@ -406,6 +204,432 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Phase timing of the 8-wave K loops (`make DEV=1` builds: hcm_op_linear_impl variants 13-15; read back through hcm_debug_gemm256_prof).
+// Per wave of workgroup 0..kG256ProfWgs-1, cycle totals over the K tiles of one launch (s_memtime ticks = shader cycles):
+//   gemm256_kernel  (8-phase): [0] load segment incl. the wait at barrier 1 (phase start -> released + fragments arrived), [1] MFMA issue,
+//                              [2] wait at barrier 2, [3] (PROF 2 only) the part of [0] that is the barrier-1 wait, [4] prologue, [5] epilogue
+//   gemm256f_kernel (free)   : [0] first half (32 MFMAs + the other K half's fragment reads), [1] lgkmcnt + vmcnt waits, [2] the barrier,
+//                              [3] second half (32 MFMAs + 8 DMA requests + the next tile's fragment reads), [4] prologue, [5] epilogue
+//   [6] K tiles, [7] launches
+constexpr int kG256ProfWgs = 16;
+__device__ unsigned long long g_g256_prof[kG256ProfWgs][8][8];
+__device__ __forceinline__ unsigned long long g_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// SCHED: how the 8 DMA pieces a wave requests per K tile are spread over the four phases (0: 2/2/2/2; 1: 0/3/1/4 -- the pieces go where
+// the phase has few fragment reads: 12/4/8/0).  DBG (timing experiments only, results are then wrong): 1 no DMA in the loop, 2 no fragment
+// reads after the first tile, 4 no MFMAs.
+template <typename T, int SCHED = 0, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PROF = (DBG & 16) ? 2 : (DBG & 8) ? 1 : 0;      // phase timing (see g_g256_prof)
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if constexpr (PROF) t_prev = g_now();
+    auto lap = [&](int slot) {
+        if constexpr (PROF) { const unsigned long long t = g_now(); pt[slot] += t - t_prev; t_prev = t; }
+    };
+    // ---- tile of this block: XCD (blockIdx % 8) owns a rectangle of the tile grid
+    int tile_m, tile_n;
+    {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
+        const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
+        const int nn = n_hi - n_lo;
+        if (nn <= 0 || local >= (m_hi - m_lo) * nn) return;
+        tile_m = m_lo + local / nn;
+        tile_n = n_lo + local % nn;
+    }
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // wave (wr, wc): tokens [wr*128, +128) x channels [wc*64, +64)
+    const int rin = lane >> 3;                        // row inside an 8-row DMA piece
+    const int csrc = (lane & 7) ^ rin;                // source chunk this lane fetches (swizzle on the source side)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
+    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
+
+    // DMA pieces of this wave: per half-tile h (X-h: token rows {h*64..+64} of both row groups; W-h: channel rows {h*32..+32} of all
+    // four column groups) pieces q = 2*wave + i, i = 0, 1.  Out-of-range rows present an offset beyond num_records: hardware zero fill.
+    unsigned xsrc[2][2], wsrc[2][2], xdst[2][2], wdst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = 2 * wave + i;
+            const int xrow = (q >> 3) * 128 + h * 64 + (q & 7) * 8;
+            const int wrow = (q >> 2) * 64 + h * 32 + (q & 3) * 8;
+            const int m = m0 + xrow + rin, n = n0 + wrow + rin;
+            xsrc[h][i] = m < p.M ? (unsigned)(m * p.ldx + csrc * 8) * 2u : 0x80000000u;
+            wsrc[h][i] = n < p.N ? (unsigned)(n * p.ldw + csrc * 8) * 2u : 0x80000000u;
+            xdst[h][i] = lds_base + (unsigned)xrow * 128u;
+            wdst[h][i] = lds_base + G_WOFF + (unsigned)wrow * 128u;
+        }
+    auto dma_x = [&](int h, unsigned buf, unsigned kbyte) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g_dma16(xdst[h][i] + buf, xsrc[h][i] + kbyte, rx);
+    };
+    auto dma_w = [&](int h, unsigned buf, unsigned kbyte) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g_dma16(wdst[h][i] + buf, wsrc[h][i] + kbyte, rw);
+    };
+    // piece q of a K tile in request order: X-h0[0,1], W-h0[0,1], W-h1[0,1], X-h1[0,1] (the order the next tile's phases need them)
+    auto piece = [&](int q, unsigned buf, unsigned kbyte) {
+        const int i = q & 1;
+        if (q < 2) g_dma16(xdst[0][i] + buf, xsrc[0][i] + kbyte, rx);
+        else if (q < 4) g_dma16(wdst[0][i] + buf, wsrc[0][i] + kbyte, rw);
+        else if (q < 6) g_dma16(wdst[1][i] + buf, wsrc[1][i] + kbyte, rw);
+        else g_dma16(xdst[1][i] + buf, xsrc[1][i] + kbyte, rx);
+    };
+
+    g_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    // prologue: the whole first K tile
+    dma_x(0, 0, 0); dma_w(0, 0, 0); dma_w(1, 0, 0); dma_x(1, 0, 0);
+    g_wait_vmcnt<0>();
+    G_BAR();
+    if (wr == 1) G_BAR();                              // stagger the second row group by one barrier interval
+    lap(4);
+
+    const int fr = lane & 15, fg = lane >> 4;
+    uint4 xf[2][4], wf0[2][2], wf1[2][2];
+    auto rd_x = [&](int mq, unsigned buf) {
+        const char* sx = smem + buf;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wr * 128 + mq * 64 + j * 16 + fr;
+                xf[ks][j] = *reinterpret_cast<const uint4*>(sx + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            }
+    };
+    auto rd_w = [&](uint4 (&wf)[2][2], int nq, unsigned buf) {
+        const char* sw = smem + buf + G_WOFF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wc * 64 + nq * 32 + i * 16 + fr;
+                wf[ks][i] = *reinterpret_cast<const uint4*>(sw + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            }
+    };
+
+    // K tile t lives in buffer t & 1; tile t+1 is requested into the other buffer while t is consumed (that buffer's last reader,
+    // the second row group's phase 3 of tile t-1, finished two barrier intervals before the first request)
+    // SCHED 2: the two DMA pieces of a phase are issued from INSIDE its MFMA cluster (after the 4th and the 12th MFMA), where an LDS-DMA
+    // instruction costs ~60 cycles of issue instead of 100-185 in a phase that is also reading fragments (MI355X_MICROARCH.md, cycle table)
+    auto mma_phase_dma = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2], auto LIVE, int q0, unsigned buf, unsigned kbyte) {
+        constexpr int nq = decltype(NQ)::value, mq = decltype(MQ)::value;
+        constexpr bool live = decltype(LIVE)::value;
+        G_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        int cnt = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    GMma<T>::run(acc[nq * 2 + i][mq * 4 + j], wf[ks][i], xf[ks][j]);
+                    ++cnt;
+                    if (live && (cnt == 4 || cnt == 12)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(q0 + (cnt == 12), buf, kbyte);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        __builtin_amdgcn_s_setprio(0);
+        G_BAR();
+    };
+    auto mma_phase = [&](auto NQ, auto MQ, const uint4 (&wf)[2][2]) {
+        if constexpr (PROF == 2) lap(0);               // (the stamp waits for the fragment reads: they complete BEFORE the barrier in this build)
+        G_BAR();
+        lap(PROF == 2 ? 3 : 0);
+        if constexpr (!(DBG & 4)) {
+            __builtin_amdgcn_s_setprio(1);
+            g_quad<T, decltype(NQ)::value, decltype(MQ)::value>(acc, wf, xf);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        lap(1);
+        G_BAR();
+        lap(2);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto tile_body = [&](int t, auto LIVE) {
+        constexpr bool live = decltype(LIVE)::value && !(DBG & 1);
+        const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
+        const unsigned kb = (unsigned)(t + 1) * 128u;
+        const bool rd = !(DBG & 2) || t == 0;
+        if constexpr (SCHED == 0) {
+            // ---- phase 1: channels 0-31 x tokens 0-63 of the wave's block
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); }
+            mma_phase(I0{}, I0{}, wf0);
+            // ---- phase 2: channels 32-63 x tokens 0-63
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<4>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of THIS tile has landed
+            mma_phase(I1{}, I0{}, wf1);
+            // ---- phase 3: channels 32-63 x tokens 64-127
+            if (rd) rd_x(1, cur);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); }
+            mma_phase(I1{}, I1{}, wf1);
+            // ---- phase 4: channels 0-31 x tokens 64-127 (both fragment sets are in registers)
+            if (live) { piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<2>(); }     // X-h0, W-h0, W-h1 of the next tile have landed
+            mma_phase(I0{}, I1{}, wf0);
+        } else if constexpr (SCHED == 3) {
+            // early requests, late waits: the whole next tile is requested in phases 1 and 2 (4 + 4 pieces) and every wait sits one phase
+            // before the first read of what it waits for -- every piece has >= 3 phases (~0.8 us) between request and first use, where
+            // SCHED 0 gives W-h1 one phase (~0.28 us: less than an L2 hit's latency under load).
+            //   before phase 2 reads W-h1 of THIS tile (pieces 4, 5; requested in phase 2 of the previous tile): younger = 6, 7 + 0-3 of the next
+            //   before phase 3 reads X-h1 of THIS tile (6, 7): younger = 0-7 of the next tile
+            //   before the next phase 1 reads X-h0 / W-h0 of the next tile (0-3): younger = 4-7 of the next tile
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); piece(3, nxt, kb); g_wait_vmcnt<6>(); } else { g_wait_vmcnt<2>(); }
+            mma_phase(I0{}, I0{}, wf0);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<8>(); } else { g_wait_vmcnt<0>(); }
+            mma_phase(I1{}, I0{}, wf1);
+            if (rd) rd_x(1, cur);
+            mma_phase(I1{}, I1{}, wf1);
+            if (live) g_wait_vmcnt<4>();
+            mma_phase(I0{}, I1{}, wf0);
+        } else if constexpr (SCHED == 2) {
+            using LV = std::integral_constant<bool, live>;
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (its X-h1 may be in flight)
+            mma_phase_dma(I0{}, I0{}, wf0, LV{}, 0, nxt, kb);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) g_wait_vmcnt<2>(); else g_wait_vmcnt<0>();                          // X-h1 of this tile
+            mma_phase_dma(I1{}, I0{}, wf1, LV{}, 2, nxt, kb);
+            if (rd) rd_x(1, cur);
+            mma_phase_dma(I1{}, I1{}, wf1, LV{}, 4, nxt, kb);
+            if (live) g_wait_vmcnt<2>();                                                  // X-h0, W-h0 of the next tile
+            mma_phase_dma(I0{}, I1{}, wf0, LV{}, 6, nxt, kb);
+        } else {
+            // pieces where the fragment reads are few: 0 / 3 / 1 / 4
+            if (rd) { rd_x(0, cur); rd_w(wf0, 0, cur); }
+            g_wait_vmcnt<2>();                                                            // W-h1 of this tile has landed (X-h1 may be in flight)
+            mma_phase(I0{}, I0{}, wf0);
+            if (rd) rd_w(wf1, 1, cur);
+            if (live) { piece(0, nxt, kb); piece(1, nxt, kb); piece(2, nxt, kb); g_wait_vmcnt<3>(); } else { g_wait_vmcnt<0>(); }   // X-h1 of this tile
+            mma_phase(I1{}, I0{}, wf1);
+            if (rd) rd_x(1, cur);
+            if (live) piece(3, nxt, kb);
+            mma_phase(I1{}, I1{}, wf1);
+            if (live) { piece(4, nxt, kb); piece(5, nxt, kb); piece(6, nxt, kb); piece(7, nxt, kb); g_wait_vmcnt<4>(); }   // X-h0, W-h0 of the next tile
+            mma_phase(I0{}, I1{}, wf0);
+        }
+    };
+    int t = 0;
+    for (; t + 1 < nk; ++t) tile_body(t, std::true_type{});
+    tile_body(t, std::false_type{});
+    if (wr == 0) G_BAR();                              // re-align the two row groups: every fragment read is done
+
+    if constexpr (PROF) t_prev = g_now();
+    g_epilogue<T>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg);
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(5);
+        if (lane == 0 && blockIdx.x < kG256ProfWgs) {
+            unsigned long long* slot = g_g256_prof[blockIdx.x][wave];
+            for (int i = 0; i < 6; ++i) atomicAdd(&slot[i], pt[i]);
+            atomicAdd(&slot[6], (unsigned long long)nk);
+            atomicAdd(&slot[7], 1ull);
+        }
+    }
+}
+
+
+// "Free-running" form of the same 256 x 256 tile, same 8 waves (2 x 4, 128 tokens x 64 channels per wave), same DMA pieces, swizzle and
+// two 64 KB K-tile buffers -- but ONE workgroup barrier per K tile instead of eight.  What round 4 measured about the 8-phase loop
+// (profiles/r4_gemm256_ktile_trace.md): a barrier interval is the 16 MFMAs of one wave group (272 cycles of the SIMD's matrix pipe) plus
+// ~60 cycles in which neither wave of the SIMD issues an MFMA -- the barrier's release, the lgkmcnt wait behind it and the first MFMA's
+// issue -- eight times per K tile: 2680 cycles for 2176 of matrix work.  Here the barriers are not used as the pacing mechanism.  A wave
+// software-pipelines itself: while the 32 MFMAs of one 32-deep K step issue (fragment set A), the 12 fragments of the next K step are read
+// into set B, one read behind each of the first 12 MFMAs, and vice versa; the two waves of a SIMD drift against each other freely, so
+// whenever one of them stalls (a DMA request costs its wave ~60 cycles of issue, a read burst its latency) the other one's MFMAs fill
+// the pipe.  The one barrier sits in the middle of the K tile: by then every wave holds the tile's last fragments in registers, so the
+// tile's buffer is free for tile t+2, and tile t+1 -- requested a whole tile earlier -- has landed (`vmcnt(0)`: the wave's 8 pieces, the
+// barrier makes it everybody's).  Same MFMA instruction, same k order per accumulator (K step 0 then K step 1 of every tile): bit-identical
+// to gemm256_kernel.
+template <typename T, int PROF = 0, int OPT = 0>
+__global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if constexpr (PROF) t_prev = g_now();
+    auto lap = [&](int slot) {
+        if constexpr (PROF) { const unsigned long long t = g_now(); pt[slot] += t - t_prev; t_prev = t; }
+    };
+    int tile_m, tile_n;
+    {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
+        const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
+        const int nn = n_hi - n_lo;
+        if (nn <= 0 || local >= (m_hi - m_lo) * nn) return;
+        tile_m = m_lo + local / nn;
+        tile_n = n_lo + local % nn;
+    }
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int rin = lane >> 3;
+    const int csrc = (lane & 7) ^ rin;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
+    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
+
+    // the wave's 8 DMA pieces per K tile: X rows {wave*32 + i*8 .. +8}, W rows likewise (i = 0..3) -- 8 rows x 128 B each
+    unsigned xsrc[4], wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + rin;
+        const int m = m0 + row, n = n0 + row;
+        xsrc[i] = m < p.M ? (unsigned)(m * p.ldx + csrc * 8) * 2u : 0x80000000u;
+        wsrc[i] = n < p.N ? (unsigned)(n * p.ldw + csrc * 8) * 2u : 0x80000000u;
+    }
+    const unsigned pdst = lds_base + (unsigned)(wave * 32) * 128u;
+    auto piece = [&](int q, unsigned buf, unsigned kbyte) {              // q = 0..7: X pieces then W pieces of this wave
+        if (q < 4) g_dma16(pdst + buf + (unsigned)q * 1024u, xsrc[q] + kbyte, rx);
+        else g_dma16(pdst + buf + G_WOFF + (unsigned)(q - 4) * 1024u, wsrc[q - 4] + kbyte, rw);
+    };
+
+    g_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment f of a register set: f < 4 weight fragment i = f (A operand), else token fragment j = f - 4 (B operand)
+    auto rd_frag = [&](uint4 (&wf)[4], uint4 (&xf)[8], int f, int ks, unsigned buf) {
+        if (f < 4) {
+            const int r = wc * 64 + f * 16 + fr;
+            wf[f] = *reinterpret_cast<const uint4*>(smem + buf + G_WOFF + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+        } else {
+            const int r = wr * 128 + (f - 4) * 16 + fr;
+            xf[f - 4] = *reinterpret_cast<const uint4*>(smem + buf + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+        }
+    };
+    uint4 wfa[4], xfa[8], wfb[4], xfb[8];
+    const int nk = p.K / 64;
+
+    // prologue: K tiles 0 and 1 requested; tile 0 landed for everybody; K step 0 of tile 0 in register set A
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piece(q, 0, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) piece(q, G_BUF, 128u);
+        g_wait_vmcnt<8>();
+    } else {
+        g_wait_vmcnt<0>();
+    }
+    G_BAR();
+#pragma unroll
+    for (int f = 0; f < 12; ++f) rd_frag(wfa, xfa, f, 0, 0);
+    lap(4);
+
+    auto tile_body = [&](int t, auto MORE1, auto MORE2) {
+        constexpr bool more1 = decltype(MORE1)::value, more2 = decltype(MORE2)::value;
+        const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
+        // ---- first half: K step 0 (set A); behind each of the first 12 MFMAs one fragment of K step 1 -> set B
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                GMma<T>::run(acc[i][j], wfa[i], xfa[j]);
+                const int m = i * 8 + j;
+                if (m < 12) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_frag(wfb, xfb, m, 1, cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        lap(0);
+        // this wave is past its last read of the tile's buffer; its pieces of tile t+1 (requested a tile ago) have landed
+        // (sched_barrier: MFMAs are register-only, so hipcc would otherwise sink them below these waits)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_wait_vmcnt<0>();
+        lap(1);
+        G_BAR();
+        lap(2);
+        // ---- second half: K step 1 (set B); the 8 requests of tile t+2 go out first, one behind every second MFMA (they need the whole
+        // next tile to land), then K step 0 of tile t+1 -> set A
+        const unsigned kb2 = (unsigned)(t + 2) * 128u;
+        if constexpr (OPT & 2) {
+            if (more2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) piece(q, cur, kb2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                GMma<T>::run(acc[i][j], wfb[i], xfb[j]);
+                const int m = i * 8 + j;
+                if (!(OPT & 2) && more2 && m < 16 && (m & 1) == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(m >> 1, cur, kb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (more1 && m >= 16 && m < 28) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_frag(wfa, xfa, m - 16, 0, nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        lap(3);
+    };
+    if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(1);      // over waves of OTHER kernels co-resident on the SIMD (a step runs three chains)
+    {
+        int t = 0;
+        for (; t + 2 < nk; ++t) tile_body(t, std::true_type{}, std::true_type{});
+        if (t + 1 < nk) { tile_body(t, std::true_type{}, std::false_type{}); ++t; }
+        tile_body(t, std::false_type{}, std::false_type{});
+    }
+    if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                                   // every wave is done with the operand buffers: the epilogue images reuse them
+    if constexpr (PROF) t_prev = g_now();
+    g_epilogue<T>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg);
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(5);
+        if (lane == 0 && blockIdx.x < kG256ProfWgs) {
+            unsigned long long* slot = g_g256_prof[blockIdx.x][wave];
+            for (int i = 0; i < 6; ++i) atomicAdd(&slot[i], pt[i]);
+            atomicAdd(&slot[6], (unsigned long long)nk);
+            atomicAdd(&slot[7], 1ull);
+        }
+    }
+}
+
+hipError_t gemm256_prof_read(unsigned long long* host, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256_prof), sizeof(unsigned long long) * kG256ProfWgs * 64);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        static unsigned long long zeros[kG256ProfWgs * 64] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_g256_prof), zeros, sizeof(zeros));
+    }
+    return e;
 }
 
 #ifdef HCM_DEV_KNOBS
@@ -682,7 +906,14 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
         }
         if (cnt < best_cnt || (cnt == best_cnt && fp < best_fp)) { best_cnt = cnt; best_fp = fp; d.gm = gm; d.gn = gn; }
     }
-    const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256_kernel<bf16>) : reinterpret_cast<const void*>(gemm256_kernel<f16>);
+    // round 4: the one-barrier-per-K-tile form (gemm256f_kernel, bit-identical to the 8-phase gemm256_kernel); its 8 DMA requests go out right behind
+    // the barrier for short K (the launch is half prologue + epilogue there, profiles/r4_gemm256_ktile_trace.md), interleaved with the MFMAs beyond.
+    // HCM_GEMM256_8PHASE=1 (development build): the 8-phase form of rounds 2-3, for the A/B.
+    static const bool eight_phase = dev_env("HCM_GEMM256_8PHASE") != nullptr;
+    const void* fn;
+    if (eight_phase) fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256_kernel<bf16>) : reinterpret_cast<const void*>(gemm256_kernel<f16>);
+    else if (g.K <= 1024) fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256f_kernel<bf16, 0, 2>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2>);
+    else fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256f_kernel<bf16, 0, 0>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 0>);
     int threads = 512;
 #ifdef HCM_DEV_KNOBS
     // `make DEV=1` builds only (libhcm_dev.so): g.impl >> 4 selects the experiment builds DESIGN.md section 7 quotes (f16): 1 = SCHED 1;
@@ -702,8 +933,24 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
             case 9: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 0>); break;
             case 10: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 3, 4>); break;
             case 11: break;                                                           // the four-wave form, selected below
+            case 12: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 0>); break;   // free-running: one barrier per K tile (bit-identical)
+            case 13: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 8>); break;  // 8-phase with phase stamps
+            case 14: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 16>); break; // ... plus a stamp in front of barrier 1
+            case 15: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 1>); break;   // free-running with phase stamps
+            case 16: fn = reinterpret_cast<const void*>(gemm256_kernel<f16, 0, 0>); break;  // the 8-phase form whatever the default is
+            case 17: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 1>); break; // free-running + static s_setprio(1) over the loop
+            case 18: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2>); break; // free-running, the 8 DMA requests right behind the barrier
+            case 19: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 3>); break; // both
+            case 20: fn = reinterpret_cast<const void*>(gemm256f_kernel<f16, 1, 2>); break; // DMA-first form with phase stamps
             default: return hipErrorInvalidValue;
         }
+    }
+    static const bool free_default = dev_env("HCM_GEMM256_FREE") != nullptr;           // in-step A/B of the free-running form
+    if (free_default && !var) {
+        const int fo = atoi(dev_env("HCM_GEMM256_FREE"));         // 1 plain, 2 + static priority, 3 DMA requests first, 4 both
+        if (dt == DT_BF16) fn = reinterpret_cast<const void*>(gemm256f_kernel<bf16, 0>);
+        else fn = fo == 2 ? reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 1>) : fo == 3 ? reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2>)
+                : fo == 4 ? reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 3>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0>);
     }
     static const bool w4_default = dev_env("HCM_GEMM256_W4") != nullptr;
     if (var == 11 || (w4_default && !var)) {

@@ -1583,6 +1583,10 @@ struct Bneck231Dev {
     // KD > 0: the block's 1x1 down-sample conv folded into the expansion GEMM (weights K-concatenated [W3 | Wds], bias b3 + bds): the
     // block input xd [B,H,W,*] (KD*64 channels at pixel stride xdC) is a second operand block, no identity tensor exists
     const char* xd; int xdC; unsigned xd_bytes; long long g_xd;
+    // xcd_tiles > 0 (two groups, 1-D grid): the hi | lo pair is split over the XCDs -- workgroup id -> XCD id & 7 (dispatch order, observed), group =
+    // XCD / 4, pixel tile = (id / 8) * 4 + XCD % 4 -- so that an XCD's L2 streams ONE group's weights (2.2 MB per group at 256 mid channels;
+    // both groups' 4.4 MB do not fit the 4 MB of an XCD's L2: 104 us per launch in the step against 83 us with one group's weights)
+    int xcd_tiles;
 };
 
 template <typename T, int BM, int C1, int CN, int KD = 0>
@@ -1893,7 +1897,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // parked tile is two K blocks deep).  The slice is then requested behind the top-of-slice barrier -- every wave has left the previous
 // reduction -- and waited for at the slice-block barrier, a whole expansion + epilogue later.
 template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false, int NWB = 0, int W1B = 2>
-__global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
+__global__ __launch_bounds__(512, C1 >= 256 ? 2 : 4) void bneck231r_kernel(Bneck231Dev qq) {
     // phase timing (HCM_IGEMM_PROF=1 builds, read through hcm_debug_igemm_prof): per-wave cycle totals [0] prologue up to the first barrier,
     // [1] phase A K loop, [2] park + top-of-slice waits and barriers, [3] expansion MFMAs, [4] register epilogues, [5] slice-block barrier +
     // reduction MFMAs + final epilogue, [6] waves, [7] K iterations
@@ -1925,8 +1929,15 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     IGemmDev& p = q.a;
+    int tile_id = blockIdx.x;
     if (p.groups > 1) {
-        const long long g = blockIdx.y;
+        long long g = blockIdx.y;
+        if (qq.xcd_tiles > 0) {
+            const int xcd = blockIdx.x & 7;
+            g = xcd >> 2;
+            tile_id = (blockIdx.x >> 3) * 4 + (xcd & 3);
+            if (tile_id >= qq.xcd_tiles) return;
+        }
         p.x += g * p.g_x * 2;
         p.w += g * p.g_w * 2;
         p.bias += g * p.g_b;
@@ -1939,7 +1950,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         qq.o1 += g * qq.g_o1 * 2;
         if (KD) qq.xd += g * qq.g_xd * 2;
     }
-    const int m0 = blockIdx.x * BM;
+    const int m0 = tile_id * BM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1953,9 +1964,20 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     // identity rows of every output slice, requested first: they arrive while phase A runs (16 B per lane, pixel tile and slice)
-    uint4 rpre[NT][TMB] = {};
+    // ID_STREAM (256 mid channels: 16 slices x TMB rows = 128 registers if held at once): the identity rows of slice nt + 1 are requested at the
+    // top of slice nt instead, behind that slice's reduction-weight request, into a two-slice register ring -- a whole slice (~1.5 us) to land
+    constexpr bool ID_STREAM = C1 >= 256 && KD == 0;
+    static_assert(!ID_STREAM || W1B == 1, "the streamed identity's wait counts assume the one-buffer reduction-weight form");
+    uint4 rpre[ID_STREAM ? 2 : NT][TMB] = {};
+    auto load_identity_slice = [&](int nt, int slot) {
+#pragma unroll
+        for (int j = 0; j < TMB; ++j) {
+            const int m = min(m0 + wm2 * (BM / WM2) + j * 16 + fr, p.M - 1);
+            rpre[slot][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * q.ldr3 + nt * SW + wn2 * 32 + coff);
+        }
+    };
     auto load_identity = [&]() {
-        if constexpr (KD == 0) {
+        if constexpr (KD == 0 && !ID_STREAM) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1970,6 +1992,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     // both bias vectors, one element per thread: parked in LDS behind phase A, so that nothing in phase B is a global load whose wait would
     // also wait for the output stores in front of it (vmcnt retires in order)
     const float b3v = tid < 4 * C1 ? q.b3[tid] : 0.f;
+    const float b3w = (4 * C1 > 512 && tid + 512 < 4 * C1) ? q.b3[tid + 512] : 0.f;      // 256 mid channels: 1024 expansion biases, two per thread
     const float b1v = tid < CN ? qq.b1[tid] : 0.f;
 
     int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
@@ -2056,7 +2079,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
         // (128 output rows x 32 k, 64-BYTE rows: one MFMA K step) -- 16 KB tiles would leave room for a 2-deep ring only beside the 35 KB halo block
         constexpr int UK = C1 == 64 ? 64 : 32;               // k per unit
         constexpr int UPT = C1 / UK;                         // units per tap: 1 / 4
-        constexpr int NK = 9 * UPT, D = NWB - 1, NID = KD == 0 ? NT * TMB : 0;
+        constexpr int NK = 9 * UPT, D = NWB - 1, NID = (KD == 0 && !ID_STREAM) ? NT * TMB : 0;
         static_assert(NWB >= 2 && (C1 == 64 || C1 == 128) && C1 * UK * 2 == 8192, "halo phase A: 8 KB weight units");
         constexpr int ND0 = D < NK ? D : NK;                 // weight units requested with the halo block
         constexpr int ID_AT = NK - 1 - D;                    // the iteration that requests the last weight unit (< 0: all went out up front)
@@ -2167,7 +2190,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     } else {
     // the 3-deep ring of whole tap tiles.  The identity rows are requested right behind the LAST tile request (iteration nk - 3): in front,
     // every wait of the loop would also wait for them (vmcnt retires in order) -- the first tile then comes up a whole identity fetch late
-    constexpr int NID = KD == 0 ? NT * TMB : 0;
+    constexpr int NID = (KD == 0 && !ID_STREAM) ? NT * TMB : 0;
     stage(0, 0);
     if (nk > 1) { stage(1, 1); if (nk == 2) load_identity(); }
     else load_identity();
@@ -2211,9 +2234,11 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
     lap(1);
     stage_w3(0);
     stage_w1(0);
+    if constexpr (ID_STREAM) load_identity_slice(0, 0);
     {
         float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
         if (tid < 4 * C1) sbias[tid] = b3v;
+        if constexpr (4 * C1 > 512) { if (tid + 512 < 4 * C1) sbias[tid + 512] = b3w; }
         if (tid < CN) sbias[4 * C1 + tid] = b1v;
     }
     if constexpr (KD > 0) stage_xd();
@@ -2240,14 +2265,28 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
 #pragma unroll
         for (int j = 0; j < TMB; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     T* const yp = reinterpret_cast<T*>(q.y);
+    // store instructions this wave issues per slice: its row groups j (16 rows each, ascending) that start below M -- wave-uniform
+    int n_st = 0;
+#pragma unroll
+    for (int j = 0; j < TMB; ++j) n_st += (m0 + wm2 * (BM / WM2) + j * 16 < p.M) ? 1 : 0;
+    n_st = __builtin_amdgcn_readfirstlane(n_st);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nb = nt * SW + wn2 * 32 + coff;
         // this slice's weights (both matrices) have landed.  They were requested BEFORE the previous slice's output stores were issued (below),
         // so the wait leaves those TMB stores per lane in flight: a slice never waits for the write acknowledgements of the one before
-        if (nt == 0) wait_vmcnt<0>(); else wait_vmcnt<TMB>();
+        // (a wave whose pixel rows lie partly or wholly past M -- the ragged last tile -- issued FEWER store instructions: a row group of 16 whose lanes are
+        //  all past M is branched around.  Its count of stores in flight is n_st, not TMB; waiting `vmcnt(TMB)` there would leave the wave's own weight
+        //  pieces in flight across the barrier, and the OTHER waves read them: a rare wrong tile, found by round 4's race screen)
+        if (nt == 0) wait_vmcnt<0>();
+        else if (n_st >= TMB) wait_vmcnt<TMB>();
+        else if (TMB > 2 && n_st == 3) wait_vmcnt<3>();
+        else if (TMB > 1 && n_st == 2) wait_vmcnt<2>();
+        else if (n_st == 1) wait_vmcnt<1>();
+        else wait_vmcnt<0>();
         __syncthreads();                                   // ... for every wave; parked tile complete; the previous reduction has left the slice block
         if constexpr (W1B == 1) { if (nt > 0) stage_w1(nt); }
+        if constexpr (ID_STREAM) { if (nt + 1 < NT) load_identity_slice(nt + 1, (nt + 1) & 1); }      // younger than this slice's reduction weights
         lap(2);
         const float4 b30 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4), b31 = *reinterpret_cast<const float4*>(smem + BIAS_OFF + nb * 4 + 16);
         f32x4 acc2[TN2][TMB];
@@ -2291,7 +2330,7 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             for (int e = 0; e < 8; ++e) v[e] += bias8[e];
             if constexpr (KD == 0) {
                 float rr[8];
-                cvt_chunk<T>(rpre[nt][j], rr);
+                cvt_chunk<T>(rpre[ID_STREAM ? (nt & 1) : nt][j], rr);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rr[e];
             }
@@ -2304,7 +2343,9 @@ __global__ __launch_bounds__(512, 4) void bneck231r_kernel(Bneck231Dev qq) {
             oreg[j] = o;
         }
         lap(4);
-        if constexpr (W1B == 1) wait_vmcnt<0>();           // this slice's reduction weights (requested at the top of the slice; the stores in front of them are a slice old)
+        // this slice's reduction weights (requested at the top of the slice; the stores in front of them are a slice old); the streamed identity rows
+        // of the next slice, requested behind them, stay in flight
+        if constexpr (W1B == 1) { if (ID_STREAM && nt + 1 < NT) wait_vmcnt<TMB>(); else wait_vmcnt<0>(); }
         __syncthreads();                                   // slice block complete; every wave is done with the expansion weights
         if (nt + 1 < NT) { stage_w3(nt + 1); if constexpr (W1B == 2) stage_w1(nt + 1); }      // (the reduction's weight slices alternate between two buffers)
         // ... and only now the slice's 16-byte stores to y: younger than the weight requests above, they stay in flight across the next slice's wait
@@ -2912,7 +2953,8 @@ constexpr int kHaloRing = 5, kHaloRingD = 5;       // weight-tile ring depth of 
 
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
-    if ((b.C1 != 64 && b.C1 != 128) || (!b.res && !b.xd) || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
+    if ((b.C1 != 64 && b.C1 != 128 && b.C1 != 256) || (!b.res && !b.xd) || !b.b2 || !b.b3 || b.stride < 1) return hipErrorInvalidValue;
+    if (b.C1 == 256 && (!b.w1 || b.CN != 256 || b.xd)) return hipErrorInvalidValue;        // 256 mid channels: only the tail + next-reduction form is built
     if (b.xd && (b.C1 != 64 || b.KD != 1 || !b.w1 || b.CN != 64 || (b.xdC % 8))) return hipErrorInvalidValue;   // the one folded-down-sample shape built
     const int C3 = 4 * b.C1;
     const int ldy = b.ldy ? b.ldy : C3, ldr = b.ldr ? b.ldr : C3, xC = b.xC ? b.xC : b.C1;
@@ -2925,7 +2967,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     d.Ho = (b.H + 2 - 3) / b.stride + 1; d.Wo = (b.W + 2 - 3) / b.stride + 1;
     d.KH = 3; d.KW = 3; d.stride = b.stride; d.stride_w = b.stride; d.pad = 1;
     d.M = b.B * d.Ho * d.Wo; d.N = b.C1; d.K = 9 * b.C1; d.Kp = 9 * b.C1;
-    d.cin_shift = b.C1 == 64 ? 6 : 7;
+    d.cin_shift = b.C1 == 64 ? 6 : b.C1 == 128 ? 7 : 8;
     d.kw_rcp = (65536 + 3 - 1) / 3;
     d.groups = b.groups > 1 ? b.groups : 1;
     d.g_x = b.g_x; d.g_w = b.g_w2; d.g_b = b.g_b2;
@@ -2938,10 +2980,10 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
     q.C3 = C3; q.Kp3 = b.C1 + (b.xd ? b.KD * 64 : 0); q.ldy3 = ldy; q.ldr3 = ldr;
     q.w3_bytes = (unsigned)((size_t)C3 * q.Kp3 * 2);
     q.g_w3 = b.g_w3; q.g_b3 = b.g_b3; q.g_y3 = b.g_y;
-    const int BM = b.C1 == 64 ? 128 : 64;
+    const int BM = b.C1 == 128 ? 64 : 128;
     const int KT1 = b.C1 / 64;
     if (b.w1) {
-        if (!b.b1 || !b.o1 || (b.CN != 64 && b.CN != 128) || (b.C1 == 128 && b.CN != 128)) return hipErrorInvalidValue;
+        if (!b.b1 || !b.o1 || (b.CN != 64 && b.CN != 128 && b.CN != 256) || (b.C1 == 128 && b.CN != 128) || ((b.C1 == 256) != (b.CN == 256))) return hipErrorInvalidValue;
         const int ldo = b.ldo ? b.ldo : b.CN;
         if (ldo % 8) return hipErrorInvalidValue;
         Bneck231Dev qq;
@@ -2950,6 +2992,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
         qq.w1_bytes = (unsigned)((size_t)b.CN * C3 * 2);
         qq.g_w1 = b.g_w1; qq.g_b1 = b.g_b1; qq.g_o1 = b.g_o1;
         qq.xd = nullptr; qq.xdC = 0; qq.xd_bytes = 0; qq.g_xd = 0;
+        qq.xcd_tiles = 0;
         if (b.xd) {
             const size_t xdb = (((size_t)d.B * d.H * d.W - 1) * b.xdC + b.KD * 64) * 2;
             if (xdb >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
@@ -2993,6 +3036,27 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
             if (ed != hipSuccess) return ed;
             void* ad[] = {&qq};
             return hipLaunchKernel(fd, dim3((d.M + BMd - 1) / BMd, d.groups), dim3(512), ad, ldsd, s);
+        }
+        if (b.C1 == 256) {
+            // RGB layer3 (16 x 16 maps at 256-pixel frames): 128-pixel tiles, one workgroup per CU (149 KB: the parked 128 x 256 tile 64 KB, a 32 KB
+            // expansion-weight slice, the 16 KB slice block, ONE 32 KB buffer for the reduction's weight slice, 5 KB of biases; phase A's 3-deep ring
+            // of 48 KB tap tiles lives in the same bytes before that), identity rows streamed two slices deep (ID_STREAM)
+            const size_t lb = (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (size_t)BM * 128 + (size_t)b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
+            const size_t ra = 3 * (size_t)(BM + b.C1) * 128;
+            const size_t lds256 = lb > ra ? lb : ra;
+            if (lds256 > 160 * 1024) return hipErrorInvalidValue;
+            const void* f2 = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 256, 256, 0, false, 0, 1>)
+                                           : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 256, 256, 0, false, 0, 1>);
+            hipError_t e2 = hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e2 != hipSuccess) return e2;
+            void* a2[] = {&qq};
+            static const bool no_xcd = dev_env("HCM_NO_BNECK_XCD") != nullptr;
+            if (d.groups == 2 && !no_xcd) {
+                const int tiles = (d.M + BM - 1) / BM;
+                qq.xcd_tiles = tiles;
+                return hipLaunchKernel(f2, dim3(((tiles + 3) / 4) * 8, 1), dim3(512), a2, lds256, s);
+            }
+            return hipLaunchKernel(f2, dim3((d.M + BM - 1) / BM, d.groups), dim3(512), a2, lds256, s);
         }
         static const bool image = dev_env("HCM_BNECK_IMAGE") != nullptr;
         size_t lds1 = image ? (size_t)KT1 * BM * 128 + (size_t)KT1 * 64 * 128 + (64 * 132 * 4 / 2 + 1024) + (size_t)BM * 128 + (size_t)b.CN * 128

@@ -73,6 +73,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 // 256 x 256-tile, 8-phase GEMM for wide token-major linear layers (gemm256.hip); bit-identical to launch_igemm's kernels
 bool gemm256_applicable(const IGemm& g, int dt);
 hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s);
+hipError_t gemm256_prof_read(unsigned long long* host, bool reset);   // phase counters of the profiled 256 x 256 GEMM builds: [16 workgroups][8 waves][8]
 // Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,
 // C1 = 64 or 128 (igemm.hip: bneck23_kernel).  Weights as for launch_igemm: w2 [C1][9*C1] (k = (kh*3+kw)*C1 + ci), w3 [4*C1][C1].
 struct Bneck23 {
@@ -109,6 +110,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 // operands and caches the fastest (process-wide); hcm_finalize() runs one tuning step at max_batch.
 void igemm_set_tuning(bool on);
 size_t igemm_tuned_shapes();
+hipError_t launch_mark(unsigned long long* slot, hipStream_t s);     // development aid: wall-clock stamp in stream order (HCM_MARKS=1)
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEMM_PROF=1 phase counters
 
 // 7x7/2 pad-3 stem on a 16-bit trunk: the raw RGB frame (f32 or uint8, NHWC3) is first packed ONCE into a zero-bordered

@@ -188,6 +188,9 @@ struct hcm_ctx {
     std::string err;
     hcm_ctx() { for (auto& f : depth_fold) f = 1.f; }
     bool taps_on = false;
+    // development aid (make DEV=1, HCM_MARKS=1): wall-clock stamps of named points of a step, see Fwd::mark
+    unsigned long long* marks_dev = nullptr;
+    std::vector<std::string> mark_names;
     std::map<std::string, hcm::Tap> taps;
     hipStream_t stream = nullptr;   // the caller's stream of the current call
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the encoder chains (forward.cpp step())

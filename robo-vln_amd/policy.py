@@ -101,6 +101,7 @@ class HCMEngine:
         self._guard_every = int(guard_every)
         self._guard_tick = 0
         self._guard_seen = 0
+        self.guard_alarm = 0                            # deferred alarms of act(gather=True) steps, see guard_check()
         self._gstream = None
         self._static = None
         cfg.validate()
@@ -139,8 +140,10 @@ class HCMEngine:
             _lib.check(self._lib.hcm_query(self._h, what, C.byref(out)), self._h)
         return out.value
 
-    def _guard_poll(self, stream):
-        """Every `guard_every` act() calls: non-blocking read of the overflow guard (the value is the one an EARLIER poll enqueued)."""
+    def _guard_poll(self, stream, defer=False):
+        """Every `guard_every` act() calls: non-blocking read of the overflow guard (the value is the one an EARLIER poll enqueued).
+        defer=True (act(gather=True): env-sharded ranks): the alarm is only RECORDED (self.guard_alarm) -- a rank that raised on its own in
+        the middle of a rollout would leave its peers blocked in the next step's all-gather; guard_check() agrees on it across ranks."""
         if self._guard_every <= 0:
             return
         self._guard_tick += 1
@@ -150,9 +153,31 @@ class HCMEngine:
         _lib.check(self._lib.hcm_guard_poll(self._h, stream, C.byref(out)), self._h)
         if out.value > self._guard_seen:
             new, self._guard_seen = out.value - self._guard_seen, out.value
+            if defer:
+                self.guard_alarm += new
+                return
             raise FloatingPointError(f"overflow guard: {new} (environment, recurrent step) pairs had non-finite activations in front of a recurrent "
                                      "cell since the last check -- broken sensor frames, or a sub-network outside its fp16 range "
                                      "(engine.calibrate(observations) on real observations; engine.calibration_report())")
+
+    def guard_check(self, group=None):
+        """Env-sharded ranks: agree on the deferred overflow-guard alarms (MAX over the ranks of `group`, one tiny all-reduce) and raise
+        FloatingPointError on EVERY rank when any rank has one -- all ranks leave the rollout at the same step, nobody is left inside a
+        collective.  rollout() calls it every `guard_every` steps; a single-process engine raises from act() directly and needs no call."""
+        alarm = int(self.guard_alarm)
+        if self.comm_world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            t = torch.tensor([alarm], device=self.device, dtype=torch.int64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+            alarm = int(t.item())
+        if alarm:
+            self.guard_alarm = 0
+            raise FloatingPointError(f"overflow guard: up to {alarm} (environment, recurrent step) pairs on one rank had non-finite activations in "
+                                     "front of a recurrent cell since the last check (engine.calibrate(observations); engine.calibration_report())")
+
+    def comm_abort(self):
+        """Tear the library's communicator down (hcm_comm_abort): for a rank that is going to stop stepping outside an agreed point."""
+        _lib.check(self._lib.hcm_comm_abort(self._h), self._h)
+        self.comm_world, self.comm_rank = 0, 0
 
     @property
     def num_recurrent_layers(self):
@@ -223,6 +248,9 @@ class HCMEngine:
                                                self._stream()), self._h)
             if release_host_weights:
                 _lib.check(self._lib.hcm_release_host_weights(self._h), self._h)
+        # a re-build zeroes the device guard word: the polled counter starts again (a stale _guard_seen would hide that many new alarms)
+        self._guard_seen = 0
+        self._guard_tick = 0
         return self.calibration_report()
 
     def close(self):
@@ -378,8 +406,9 @@ class HCMEngine:
                                                     st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
                                                     st["hh"][i].data_ptr(), st["lh"][i].data_ptr(), flags, C.c_void_p(gs.cuda_stream)), self._h)
                 st["tick"] += 1
-                self._guard_poll(C.c_void_p(gs.cuda_stream))
             cur.wait_stream(gs)
+            # (after the join: an alarm raised from here leaves the caller's stream ordered behind the step it interrupts)
+            self._guard_poll(C.c_void_p(gs.cuda_stream), defer=gather)
         return (st["gat"][i] if gather else st["rec"][i]), st["hh"][i], st["lh"][i]
 
     # ---- training / validation path: T*N frames per call, RNNStateEncoder.seq_forward (state_encoder.py:83-133)
@@ -448,7 +477,7 @@ class HCMEngine:
                 _lib.check(self._lib.hcm_act_ex(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
                                                 _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
                                                 rec.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, self._stream()), self._h)
-            self._guard_poll(self._stream())
+            self._guard_poll(self._stream(), defer=gather)
         return rec, hh2, lh2
 
     def refresh_instruction(self, instruction, env_indices, instruction_lengths=None):

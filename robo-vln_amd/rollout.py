@@ -90,6 +90,14 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         out.append(full.clone())
         prev_done = done_fn(t, lo, hi)
         st.after_step(hh, lh, prev_done)
+        # env-sharded ranks on the library's collective: act(gather=True) only RECORDS an overflow-guard alarm; the ranks agree on it here, at
+        # the same step on every rank, so that nobody is left inside the next step's all-gather (a NaN row in the gathered record -- a peer
+        # whose step failed, hcm_act_gather -- ends the rollout the same way)
+        if lib_gather:
+            eng = policy.engine
+            every = getattr(eng, "_guard_every", 0)
+            if every > 0 and (t + 1) % every == 0:
+                eng.guard_check()
     # overflow guard of the HIP engine (hcm_query(HCM_STEP_NONFINITE)): a NaN / inf anywhere upstream of the state encoders would
     # otherwise leave the squashing cells as a finite, wrong action -- checked once per rollout (it synchronises), loudly
     if guard is not None:

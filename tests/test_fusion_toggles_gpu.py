@@ -55,6 +55,9 @@ def test_fused_rgb_trunk_launches_equal_the_separate_ones():
         plain = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK_FUSE": "1", "HCM_NO_STEM_HPOOL": "1", "HCM_NO_PRED_FUSE": "1"}, os.path.join(d, "b.npz"))
         nonext = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK_NEXT": "1"}, os.path.join(d, "c.npz"))
         default = _run({}, os.path.join(d, "e.npz"))
+        # round 4: layer3's bottleneck tails (256 mid channels) fused with the next block's reduction, the hi | lo pair split over the XCDs
+        no256 = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK256": "1"}, os.path.join(d, "h.npz"))
+        noxcd = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_NO_BNECK_XCD": "1"}, os.path.join(d, "i.npz"))
         # the register-epilogue form of the fused bottleneck launch (v_permlane16_swap regrouping, the default) against its LDS-image form
         image = _run({"HCM_NO_BNECK_DSFOLD": "1", "HCM_NO_VLA_FUSE": "1", "HCM_BNECK_IMAGE": "1"}, os.path.join(d, "f.npz"))
         image_ds = _run({"HCM_BNECK_IMAGE": "1"}, os.path.join(d, "g.npz"))
@@ -62,6 +65,8 @@ def test_fused_rgb_trunk_launches_equal_the_separate_ones():
         assert np.array_equal(fused[k], plain[k]), k
         assert np.array_equal(fused[k], nonext[k]), k
         assert np.array_equal(fused[k], image[k]), k
+        assert np.array_equal(fused[k], no256[k]), k
+        assert np.array_equal(fused[k], noxcd[k]), k
         assert np.array_equal(default[k], image_ds[k]), k          # ... also with the down-sample conv folded into the expansion GEMM
     assert np.isfinite(default["rec"]).all()
     # shipped configuration (down-sample conv folded into the expansion GEMM): one rounding fewer on that path

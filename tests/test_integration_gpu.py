@@ -223,6 +223,32 @@ def test_library_all_gather_world_one(graph):
         assert got.shape == (B, 7) and torch.equal(got, ref)
         with pytest.raises(RuntimeError):
             eng.comm_init()                                      # one communicator per handle
+        # a rank whose own step fails still takes part in the step's collective, with an all-NaN record, and reports its error afterwards
+        # (a rank that simply returned would leave its peers blocked in ncclAllGather: the private communicator has no watchdog)
+        gat = torch.zeros(B, 7, device="cuda")
+        loc = torch.zeros(B, 7, device="cuda")
+        rc = lib.hcm_act_gather(eng._h, obs["rgb"].data_ptr(), _lib.HCM_F32, obs["depth"].data_ptr(), obs["instruction"].data_ptr(), _lib.HCM_I64, None, B, 513,
+                                z.data_ptr(), z.data_ptr(), m.data_ptr(), loc.data_ptr(), z.clone().data_ptr(), z.clone().data_ptr(), 0, gat.data_ptr(),
+                                None)                            # L = 513 > BERT's position table: the step is refused
+        torch.cuda.synchronize()
+        assert rc != 0 and b"NaN record" in lib.hcm_last_error(eng._h)
+        assert torch.isnan(gat).all() and torch.isnan(loc).all()
+        # env-sharded ranks: an overflow-guard alarm inside act(gather=True) is only recorded; guard_check() raises it (on every rank at once)
+        eng._guard_every = 1
+        bad = dict(obs)
+        bad["depth"] = obs["depth"].clone()
+        bad["depth"][1, 5, 7, 0] = float("nan")
+        for _ in range(4):
+            eng.act(bad, z, z, m, gather=True)                   # must not raise
+            torch.cuda.synchronize()
+        assert eng.guard_alarm > 0
+        with pytest.raises(FloatingPointError):
+            eng.guard_check()
+        assert eng.guard_alarm == 0
+        eng.comm_abort()                                         # ncclCommAbort; the handle may create a new communicator afterwards
+        assert eng.comm_world == 0
+        with pytest.raises(RuntimeError):
+            eng.act(obs, z, z, m, gather=True)
     finally:
         if created:
             dist.destroy_process_group()

@@ -363,7 +363,9 @@ def test_bottleneck_tail_fused(prec, cfg):
 @pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 1, 64), (3, 17, 15, 64, 1, 64), (2, 16, 16, 128, 2, 128), (1, 24, 20, 128, 1, 128), (2, 16, 16, 64, 1, 128),
                                  (5, 9, 11, 64, 2, 64), (2, 64, 64, 64, 1, 64),
                                  # halo phase A (tiles of whole image rows): 128 mid channels on 32- and 16-wide maps, 64 mid channels with a 128-wide reduction
-                                 (2, 32, 32, 128, 1, 128), (3, 16, 16, 128, 1, 128), (2, 64, 64, 64, 1, 128), (1, 32, 32, 64, 1, 64)])
+                                 (2, 32, 32, 128, 1, 128), (3, 16, 16, 128, 1, 128), (2, 64, 64, 64, 1, 128), (1, 32, 32, 64, 1, 64),
+                                 # 256 mid channels (RGB layer3; round 4): streamed identity rows, one workgroup per CU; ragged last tile, stride 2
+                                 (2, 16, 16, 256, 1, 256), (3, 8, 8, 256, 1, 256), (1, 12, 20, 256, 1, 256), (2, 16, 16, 256, 2, 256)])
 def test_bottleneck_tail_next_fused(prec, cfg):
     """Bottleneck tail + the next block's 1x1 reduction in one launch: both outputs BIT-identical to the three stand-alone convs."""
     lib, L = _lib()
@@ -392,6 +394,47 @@ def test_bottleneck_tail_next_fused(prec, cfg):
     torch.cuda.synchronize()
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
     assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+
+
+@pytest.mark.parametrize("cfg", [(256, 3, 8, 8, 1), (256, 5, 12, 20, 1), (64, 3, 17, 15, 1), (128, 1, 24, 20, 1), (64, 5, 9, 11, 2)])
+def test_bottleneck_tail_next_ragged_tile_race_screen(cfg):
+    """Round 4 found a rare wrong tile in the fused launch on RAGGED last tiles: a wave whose pixel rows all lie past M issues no store
+    instructions, so the counted `vmcnt(TMB)` at the top of the next slice left that wave's own weight pieces in flight across the barrier
+    (6-11 of 300 runs differed at 256 mid channels).  The same inputs many times, beside uneven load on a second stream; every word of both
+    outputs must equal the first run's."""
+    lib, L = _lib()
+    code, tdt, tol = DT["fp16"]
+    C1, B, H, W, stride = cfg
+    C3, CN = 4 * C1, C1
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = _rnd(B, H, W, C1).cuda().to(tdt)
+    w2 = _rnd(C1, 3, 3, C1, scale=(9 * C1) ** -0.5 * 1.7, seed=1).cuda().to(tdt)
+    b2 = _rnd(C1, scale=0.2, seed=2).cuda()
+    w3 = _rnd(C3, 1, 1, C1, scale=C1 ** -0.5 * 1.7, seed=3).cuda().to(tdt)
+    b3 = _rnd(C3, scale=0.2, seed=4).cuda()
+    w1 = _rnd(CN, 1, 1, C3, scale=C3 ** -0.5 * 1.7, seed=6).cuda().to(tdt)
+    b1 = _rnd(CN, scale=0.2, seed=7).cuda()
+    idt = _rnd(B, Ho, Wo, C3, seed=5).cuda().to(tdt)
+    side = torch.cuda.Stream()
+    big = torch.randn(2048, 2048, device="cuda", dtype=torch.float16)
+    ref = None
+    for it in range(120):
+        y = torch.full((B, Ho, Wo, C3), float("nan"), device="cuda", dtype=tdt)
+        o1 = torch.full((B, Ho, Wo, CN), float("nan"), device="cuda", dtype=tdt)
+        if it % 3 == 1:
+            with torch.cuda.stream(side):
+                big @ big
+        elif it % 3 == 2:
+            with torch.cuda.stream(side):
+                for _ in range(10):
+                    big.add_(1.0)
+        assert lib.hcm_op_bottleneck_tail_next(_p(x), _p(w2), _p(b2), _p(w3), _p(b3), _p(idt), _p(y), _p(w1), _p(b1), _p(o1), code, B, H, W, C1,
+                                               stride, CN, None) == 0
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (y, o1)
+        else:
+            assert torch.equal(y.view(torch.int16), ref[0].view(torch.int16)) and torch.equal(o1.view(torch.int16), ref[1].view(torch.int16)), it
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
