@@ -310,13 +310,17 @@ struct Fwd {
             static const bool no_tail = dev_env("HCM_NO_BNECK_FUSE") != nullptr;
             static const bool no_next = dev_env("HCM_NO_BNECK_NEXT") != nullptr;
             static const bool no_256 = dev_env("HCM_NO_BNECK256") != nullptr;        // layer3 (256 mid channels) as a launch per conv (A/B, toggle test)
+            static const bool force_256 = dev_env("HCM_FORCE_BNECK256") != nullptr;   // ... fused whatever the grid size (the toggle test's small batch)
             const BottleneckW* nb = bi + 1 < t.blocks.size() ? &t.blocks[bi + 1] : nullptr;
             static const int next_only = dev_env("HCM_BNECK_NEXT_ONLY") ? atoi(dev_env("HCM_BNECK_NEXT_ONLY")) : 0;   // A/B aid: 64 or 128 = only blocks with that many mid channels
             const bool next = nb && !no_next && (!next_only || next_only == b.c2.Cout) && nb->c1.KH == 1 && nb->c1.KW == 1 && nb->c1.Cin == b.c3.Cout && nb->c1.Kp == nb->c1.Cin &&
                               nb->c1.bias && nb->c1.groups == b.c2.groups && nb->c1.dt == b.c2.dt &&
                               ((nb->c1.Cout == b.c2.Cout && (nb->c1.Cout == 64 || nb->c1.Cout == 128 || nb->c1.Cout == 256)) || (b.c2.Cout == 64 && nb->c1.Cout == 128));
             // (256 mid channels -- layer3: only the "tail + next block's reduction" form exists, so the layer's last block stays a launch per conv)
-            const bool c1_ok = b.c2.Cout == 64 || b.c2.Cout == 128 || (b.c2.Cout == 256 && next && !no_256);
+            // ... and only when its 128-pixel tiles fill the chip (one 149 KB workgroup per CU: a tile's ~70 us are a latency chain that a small grid
+            // cannot hide -- B = 16: 69 us fused vs 34 us as three launches; B = 64: 83 vs 111)
+            const long tiles256 = (long)b.c2.groups * (((long)B * ((x.H + 2 - 3) / b.stride + 1) * ((x.W + 2 - 3) / b.stride + 1) + 127) / 128);
+            const bool c1_ok = b.c2.Cout == 64 || b.c2.Cout == 128 || (b.c2.Cout == 256 && next && !no_256 && (tiles256 >= 192 || force_256));
             if (!t.gn && !no_tail && (b.c2.dt == DT_BF16 || b.c2.dt == DT_F16) && c1_ok && b.c2.KH == 3 &&
                 b.c2.Cin == b.c2.Cout && b.c2.Kp == 9 * b.c2.Cin && b.c3.Cout == 4 * b.c2.Cout && b.c3.Kp == b.c2.Cout && b.c2.bias && b.c3.bias &&
                 b.c3.groups == b.c2.groups) {

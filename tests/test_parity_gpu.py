@@ -18,7 +18,8 @@ TOL = {"fp32": 1e-3, "fp16": 1e-2, "bf16": 1e-2}
 # path rounds storage to 11 significant bits per layer (fp16 everywhere since the end of round 2).  Measured over all cases: fp32
 # <= 1.3e-5; 16-bit <= 9.7e-3 (worst: hi.vla_depth, fed by the depth trunk's few-channel GroupNorm groups; 1.2e-2 while the cross-modal block
 # was on bf16).
-TAP_REL = {"fp32": 1e-4, "fp16": 1.5e-2}
+# "bf16" (8 significant bits in BERT, the RGB trunks and the cross-modal block): measured <= 1.6e-2 (round 4, eight cases; worst hi.vla_depth, then hi.vla_rgb 1.4e-2 and hi.bert 1.3e-2) -- bound 2.2e-2
+TAP_REL = {"fp32": 1e-4, "fp16": 1.5e-2, "bf16": 2.2e-2}
 
 
 def _check(name, precision, **kw):
@@ -192,10 +193,21 @@ def test_bf16_mode_batch64_three_steps(name, batch):
     from tests import parity_util
     import torch
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    rep = parity_util.run_case(name, "bf16", taps=False, batch=batch, steps=3)
+    rep = parity_util.run_case(name, "bf16", taps=True, batch=batch, steps=3)
     print(parity_util.format_report(rep))
     for s in rep["steps"]:
         assert s["max_abs"] <= 1e-2, s
+    # the intermediates on their own (step 0, whole tensors): an error must not hide behind the recurrent cell's squashing in this mode either
+    for k, (mx, mean, ref, rel) in rep["taps"].items():
+        assert rel <= TAP_REL["bf16"] or ref == 0.0 and mx == 0.0, f"{name}[bf16] tap {k}: rel-l2 {rel:.3e} > {TAP_REL['bf16']}"
+
+
+@pytest.mark.parametrize("name", ["cfg4_L160_N6", "native_224_256", "rgb_160x224", "depth192_128", "ablate_depth_128"])
+def test_bf16_mode_other_configs(name):
+    """precision="bf16" on the golden cases beyond configs[0] / [1]: configs[4] (L = 160, N = 6 -- the longest chain of bf16 roundings: BERT over
+    160 tokens, six cross-modal layers), the reference's native frame sizes, a non-square RGB frame, a non-power-of-two depth map and an ablated
+    encoder -- record, captured intermediates and the golden vectors of the imported reference, through the same checks as the fp16 mode."""
+    _check(name, "bf16")
 
 
 @pytest.mark.parametrize("sub", [{"bert": "bf16"}, {"vla": "bf16"}, {"bert": "bf16", "vla": "bf16"}])
