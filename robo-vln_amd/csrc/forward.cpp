@@ -61,6 +61,31 @@ struct Fwd {
         else ck(hipMemcpyAsync(t.dev, p, n * 4, hipMemcpyDeviceToDevice, s), "tap copy");
     }
 
+    // ---------------------------------------------------------------- GroupNorm on load (round 4)
+    // A conv of the GroupNorm trunk whose output map is large (statistics from its epilogue) no longer launches gn_apply_kernel: its output stays
+    // UN-normalised and a `Pending` record says how to normalise it; the conv that consumes the tensor applies it while staging its operand
+    // (igemm.hip igemm_gnin_kernel).  pend_in: the record of the tensor the NEXT conv() call reads (consumed by that call); defer_out: where
+    // conv_gn may leave the record of its output instead of launching the apply pass.  flush() materialises a pending tensor with the old kernel
+    // (non-conv consumers, ineligible shapes, captured taps).  HCM_NO_GN_ONLOAD=1 (development build): the apply launches of rounds 1-3.
+    struct Pending {
+        bool valid = false;
+        void* x = nullptr; const void* res = nullptr; const float* stats = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+        int B = 0, hw = 0, C = 0, G = 0, ps = 0, relu = 0, dt = 0; float eps = 1e-5f;
+        bool writeback = false;          // the consumer also stores the normalised tensor (a block output: the next residual add reads it)
+    };
+    Pending pend_in;
+    Pending* defer_out = nullptr;
+    void flush(Pending& q) {
+        if (!q.valid) return;
+        q.valid = false;
+        if (dry) return;
+        ck(launch_groupnorm_apply(q.x, q.res, q.gamma, q.beta, q.stats, q.ps, q.dt, q.B, q.hw, q.C, q.G, q.eps, q.relu, s), "groupnorm apply (flush)");
+    }
+    bool gn_onload_enabled() const {
+        static const bool off = dev_env("HCM_NO_GN_ONLOAD") != nullptr;
+        return !off && !ctx->taps_on;
+    }
+
     // ---------------------------------------------------------------- primitive wrappers
     // conv followed by GroupNorm (+ residual + ReLU): one launch when the output map is small enough for the fused
     // epilogue (igemm.hip), else conv + the stand-alone GroupNorm kernels
@@ -68,6 +93,7 @@ struct Fwd {
                  int Wo, int cg_true = 0) {
         static const bool no_fuse = dev_env("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
+        struct ClearDefer { Pending*& p; ~ClearDefer() { p = nullptr; } } clear_defer{defer_out};     // a request is for THIS call only
         const float eps = 1e-5f * w.fold * w.fold;          // range-folded conv (ConvW::fold): GroupNorm((fold * x), eps * fold^2) == GroupNorm(x, eps)
         if (cg_true) {
             // zero-padded output channels (compression conv of 64*k-pixel frames, k not a power of two): the statistics count the real
@@ -90,6 +116,14 @@ struct Fwd {
             if (!no_cs && !w.bias && groupnorm_apply_ok(w.dt, hw, C, G) && w.Cout % cg == 0) {
                 float* stats = alloc_f(gn_stats_floats(in.B, hw, G));
                 conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo, nullptr, 0, stats, cg, hw, G);
+                if (defer_out && gn_onload_enabled()) {
+                    // normalised by whoever reads it (GroupNorm on load)
+                    Pending& q = *defer_out;
+                    q.valid = true; q.x = out; q.res = res; q.stats = stats; q.gamma = n.gamma; q.beta = n.beta;
+                    q.B = in.B; q.hw = hw; q.C = C; q.G = G; q.ps = hw / 64; q.relu = relu ? 1 : 0; q.dt = w.dt; q.eps = eps; q.writeback = false;
+                    defer_out = nullptr;
+                    return;
+                }
                 static const bool skip_apply = dev_env("HCM_SKIP_GN_APPLY") != nullptr;
                 if (!dry && !skip_apply) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, eps, relu ? 1 : 0, s), "groupnorm apply");
                 return;
@@ -100,17 +134,29 @@ struct Fwd {
     }
     void conv(const ConvW& w, const Act& in, void* out, int stride, int pad, const void* res, int act, int Ho, int Wo,
               const NormW* gnw = nullptr, int gn_cg = 0, float* cs_part = nullptr, int cs_cg = 0, int cs_hw = 0, int cs_G = 0, float gn_eps = 1e-5f) {
+        Pending pin = pend_in;
+        pend_in.valid = false;
+        if (pin.valid && pin.x != in.p) { flush(pin); }             // (a record for another tensor: cannot happen in the trunk loop; be safe)
         if (dry) return;
         IGemm g;
         g.cs_part = cs_part; g.cs_cg = cs_cg; g.cs_hw = cs_hw; g.cs_G = cs_G;
         if (gnw) { g.gn_gamma = gnw->gamma; g.gn_beta = gnw->beta; g.gn_cg = gn_cg; g.gn_hw = Ho * Wo; g.gn_eps = gn_eps; }
         g.x = in.p; g.w = w.w; g.bias = w.bias; g.res = res; g.y = out;
+        if (pin.valid) {
+            g.gi_stats = pin.stats; g.gi_gamma = pin.gamma; g.gi_beta = pin.beta; g.gi_ps = pin.ps; g.gi_cg = pin.C / pin.G; g.gi_G = pin.G;
+            g.gi_hw = pin.hw; g.gi_relu = pin.relu; g.gi_eps = pin.eps; g.gi_res = pin.res; g.gi_out = pin.writeback ? pin.x : nullptr;
+        }
         g.B = in.B; g.H = in.H; g.W = in.W; g.Cin = in.C; g.xC = in.C;
         g.Ho = Ho; g.Wo = Wo; g.KH = w.KH; g.KW = w.KW; g.stride = stride; g.pad = pad;
         g.M = in.B * Ho * Wo; g.N = w.Cout; g.K = w.K; g.Kp = w.Kp; g.ldy = w.Cout; g.ldr = w.Cout; g.act = act;
         if (w.groups > 1) {     // hi|lo pair: group g reads channels [g*Cin, (g+1)*Cin) and writes [g*Cout, (g+1)*Cout)
             g.Cin = w.Cin; g.xC = in.C; g.ldy = g.ldr = w.groups * w.Cout;
             g.groups = w.groups; g.g_x = w.Cin; g.g_w = (long long)w.Cout * w.Kp; g.g_b = w.Cout; g.g_y = w.Cout;
+        }
+        if (pin.valid && !igemm_gnin_ok(g, w.dt)) {
+            // this consumer cannot normalise on load: materialise the tensor first
+            flush(pin);
+            g.gi_stats = nullptr; g.gi_res = nullptr; g.gi_out = nullptr;
         }
         ck(launch_igemm(g, w.dt, s), "conv igemm");
         // (with the fused GroupNorm epilogue the un-normalised values never leave f32 registers: `out` is the normalised map)
@@ -251,6 +297,7 @@ struct Fwd {
         int xi = 1;
         int bidx = 0;
         int pre = -1;          // slot already holding THIS block's 1x1 reduction output (computed by the previous block's fused launch)
+        Pending xpend;         // GroupNorm trunk: the block input x is still un-normalised (its first consumer, the block's c1, normalises + stores it)
         // (development build, timing only -- the results are then wrong: HCM_GN_STOP=<k> drops the launches of the GroupNorm trunks' blocks
         //  k.. and of the compression conv, HCM_SKIP_GN_APPLY=1 the stand-alone normalisation passes)
         static const int gn_stop = dev_env("HCM_GN_STOP") ? atoi(dev_env("HCM_GN_STOP")) : -1;
@@ -261,6 +308,7 @@ struct Fwd {
             // identity bottlenecks behind the layer's first block is ONE launch, a workgroup per (sample, trunk) -- igemm.hip depth_l3_kernel
             static const bool no_l3 = dev_env("HCM_NO_DEPTH_L3") != nullptr;
             if (t.gn && !no_l3 && !ctx->taps_on && pre < 0 && x.H * x.W == 64 && x.H == 8 && t.groups == 16) {
+                flush(xpend);      // (8 x 8 maps come out of fused epilogues: nothing is pending here at 256-pixel frames)
                 auto plain = [&](const BottleneckW& q) {
                     const bool dt16 = q.c1.dt == DT_F16 || q.c1.dt == DT_BF16;
                     return dt16 && !q.has_ds && q.stride == 1 && q.c1.KH == 1 && q.c1.Cin == 512 && q.c1.Cout == 128 && q.c1.Kp == 512 && q.c2.KH == 3 && q.c2.KW == 3 &&
@@ -302,8 +350,13 @@ struct Fwd {
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
             const bool have_o1 = pre >= 0;
             pre = -1;
+            Pending p1, p2;
             if (have_o1) {}
-            else if (t.gn) conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
+            else if (t.gn) {
+                if (xpend.valid) { xpend.writeback = true; pend_in = xpend; xpend.valid = false; }     // c1 normalises the block input and stores it
+                defer_out = &p1;
+                conv_gn(b.c1, x, sa, 1, 0, nullptr, b.n1, G, true, x.H, x.W);
+            }
             else conv(b.c1, x, sa, 1, 0, nullptr, ACT_RELU, x.H, x.W);
             // BN-folded trunks, 64 / 128 mid channels (layer1, layer2), 16-bit storage: 3x3 conv + 1x1 expansion + identity in ONE
             // launch, the mid tensor stays in LDS (igemm.hip: bneck23_kernel; bit-identical to the two launches)
@@ -370,7 +423,11 @@ struct Fwd {
                 continue;
             }
             Act o2{sb, B, Ho2, Wo2, CO(b.c2)};
-            if (t.gn) conv_gn(b.c2, o1, sb, b.stride, 1, nullptr, b.n2, G, true, Ho2, Wo2);
+            if (t.gn) {
+                pend_in = p1; p1.valid = false;
+                defer_out = &p2;
+                conv_gn(b.c2, o1, sb, b.stride, 1, nullptr, b.n2, G, true, Ho2, Wo2);
+            }
             else conv(b.c2, o1, sb, b.stride, 1, nullptr, ACT_RELU, Ho2, Wo2);
             const void* idt = x.p;
             if (b.has_ds) {
@@ -379,6 +436,9 @@ struct Fwd {
                 idt = sa;
             }
             if (t.gn) {
+                pend_in = p2; p2.valid = false;
+                // the block output stays pending when another bottleneck follows: its c1 normalises, adds the identity and stores it
+                if (bi + 1 < t.blocks.size()) defer_out = &xpend;
                 conv_gn(b.c3, o2, sc, 1, 0, idt, b.n3, G, true, Ho2, Wo2);          // relu(GN(conv) + identity)
             } else {
                 conv(b.c3, o2, sc, 1, 0, idt, ACT_RELU, Ho2, Wo2);                  // relu(bn(conv) + identity), fused
@@ -391,6 +451,7 @@ struct Fwd {
                 mark(tapname + ".layer" + std::to_string(bidx == 3 ? 1 : bidx == 7 ? 2 : bidx == 13 ? 3 : 4) + "_end");
             }
         }
+        flush(xpend);
         if (t.gn) {
             int fr = (xi + 1) & 3;
             conv_gn(t.compress, x, slot[fr], 1, 1, nullptr, t.n_compress, t.pair ? 2 : 1, true, x.H, x.W, t.compress_true);

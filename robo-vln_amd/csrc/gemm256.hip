@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
 bool gemm256_applicable(const IGemm& g, int dt) {
     if (dt != DT_BF16 && dt != DT_F16) return false;
     if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
-    if (g.out_f32 || g.res_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0) return false;
+    if (g.out_f32 || g.res_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0 || g.gi_stats) return false;
     const int Kp = g.Kp ? g.Kp : g.K, ldx = g.xC ? g.xC : g.Cin, ldy = g.ldy ? g.ldy : g.N, ldr = g.ldr ? g.ldr : g.N;
     if (g.K % 64 || Kp % 8 || ldx % 8 || ldy % 8 || g.N % 8 || (g.res && ldr % 8)) return false;
     if ((size_t)g.M * ldx * 2 >= 0x7FFFFFF0ull || (size_t)g.N * Kp * 2 >= 0x7FFFFFF0ull) return false;   // offsets + the out-of-range sentinel

@@ -60,6 +60,9 @@ struct IGemmDev {
     // GroupNorm statistics of the conv output from the f32 tile image: per (sample, 64-row block, group) sum / sum of squares into
     // cs_part[((b * cs_hw / 64 + block) * cs_G + group) * 2] (the stand-alone statistics launch and its read of the map disappear)
     float* cs_part; int cs_cg, cs_hw, cs_G;
+    // GroupNorm on load (IGemm::gi_*, igemm_gnin_kernel)
+    const float* gi_stats; const float* gi_gamma; const float* gi_beta; int gi_ps, gi_cg, gi_G, gi_hw, gi_relu; float gi_eps;
+    const char* gi_res; char* gi_out;
 };
 
 template <typename T> struct Mma;
@@ -823,6 +826,265 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmDev p) {
 
     const uint4 no_pre[1] = {make_uint4(0u, 0u, 0u, 0u)};
     igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, no_pre, false);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// GroupNorm ON LOAD (round 4): the register-staged implicit GEMM whose operand staging also NORMALISES.  The GroupNorm trunk's large maps
+// (>= 256 pixels per sample) used to take conv (+ statistics in its epilogue) -> gn_apply_kernel (a read + write pass and a launch of their
+// own: 27 launches, 0.9 GB, 0.33 ms per step) -> next conv.  Here the consumer conv reads the UN-normalised map and applies
+// relu?(x * scale - shift (+ residual)) per (sample, channel) between its global loads and its LDS stores; scale / shift come from the
+// producer's per-(sample, 64-pixel block, group) sums, combined in the prologue exactly as gn_apply_kernel combines them (same order, same
+// expressions: the staged values are bit-identical to what that kernel would have stored).  A tile is BM pixels of ONE sample (launcher:
+// Ho * Wo % BM == 0), so the table is one sample's Cin channels, in LDS behind the two tile buffers.  With gi_out (1x1, stride 1, one channel
+// tile) the normalised values are written back as well -- the block output the next residual add reads.  Out-of-image taps of a 3x3 stay zero
+// (the zero padding applies to the normalised map).  Reference op: habitat's GroupNorm ResNet bottleneck, resnet_encoders.py:27-62.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_gnin_kernel(IGemmDev p) {
+    constexpr int CH = Tr<T>::CH;
+    constexpr int BK = 8 * CH;
+    constexpr int TM = BM / 32, TN = BN / 32, A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = blockIdx.y;
+    if (p.groups > 1) {
+        const long long g = grp;
+        p.x += g * p.g_x * (long long)sizeof(T);
+        p.w += g * p.g_w * (long long)sizeof(T);
+        if (p.bias) p.bias += g * p.g_b;
+        if (p.gn_cg) { p.gn_gamma += g * p.g_b; p.gn_beta += g * p.g_b; }
+        if (p.res) p.res += g * p.g_y * (long long)sizeof(T);
+        p.y += g * p.g_y * (long long)(p.out_f32 ? 4 : sizeof(T));
+        if (p.gi_res) p.gi_res += g * p.g_x * (long long)sizeof(T);
+        if (p.gi_out) p.gi_out += g * p.g_x * (long long)sizeof(T);
+    }
+    int tile_m, tile_n;
+    if (!tile_of_block(p, blockIdx.x, tile_m, tile_n)) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int HoWo = p.Ho * p.Wo;
+    const int smp = m0 / HoWo;                                   // the tile's sample (input and output)
+
+    float* s_scale = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    float* s_shift = s_scale + p.Cin;
+    float* s_mean = s_shift + p.Cin;
+    float* s_rstd = s_mean + 64;
+    float* s_part = s_rstd + 64;                                  // [ng][PS][2]
+    int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_pix[i] = b * p.H * p.W;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride_w - p.pad;
+        } else {
+            a_pix[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+        }
+    }
+    const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* rg = reinterpret_cast<const T*>(p.gi_res);
+    T* og = reinterpret_cast<T*>(p.gi_out);
+    const T* wg = reinterpret_cast<const T*>(p.w);
+    const bool spatial = (p.KH * p.KW) > 1;
+    const bool wback = og != nullptr && tile_n == 0;
+
+    uint4 rsa[A_IT], rsb[B_IT], rsr[A_IT];
+    size_t roff[A_IT];
+    bool rok[A_IT];
+    int rci = 0;
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + c * CH;
+        const bool kvalid = k < p.K;
+        int kh = 0, kw = 0, ci = k;
+        if (spatial) {
+            const int khw = k >> p.cin_shift;
+            ci = k & (p.Cin - 1);
+            kh = (khw * p.kw_rcp) >> 16;
+            kw = khw - kh * p.KW;
+        }
+        rci = ci;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = kvalid && a_pix[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const size_t off = (size_t)(a_pix[i] + iy * p.W + ix) * p.xC + ci;
+            rok[i] = ok; roff[i] = off;
+            uint4 v = make_uint4(0, 0, 0, 0), r = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                v = *reinterpret_cast<const uint4*>(xg + off);
+                if (rg) r = *reinterpret_cast<const uint4*>(rg + off);
+            }
+            rsa[i] = v; rsr[i] = r;
+        }
+        const bool kvalid_w = k < p.Kp;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kvalid_w && n < p.N) v = *reinterpret_cast<const uint4*>(wg + (size_t)n * p.Kp + k);
+            rsb[i] = v;
+        }
+    };
+    // normalise the staged operand chunks (after the loads have been issued, before they go to LDS)
+    auto transform = [&]() {
+        float sc[CH], sh[CH];
+        const bool cvalid = rci + CH <= p.Cin;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { sc[j] = cvalid ? s_scale[rci + j] : 0.f; sh[j] = cvalid ? s_shift[rci + j] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            if (!rok[i]) continue;                                  // out of the image / past M / past K: stays zero
+            float v[CH], r[CH];
+            cvt_chunk<T>(rsa[i], v);
+            if (rg) cvt_chunk<T>(rsr[i], r);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float o = v[j] * sc[j] - sh[j];
+                if (rg) o += r[j];
+                if (p.gi_relu) o = relu_f(o);
+                v[j] = o;
+            }
+            rsa[i] = pack_chunk<T>(v);
+            if (wback) *reinterpret_cast<uint4*>(og + roff[i]) = rsa[i];
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* sa = smem + buf * TILE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int r = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(sa + r * 128 + ((c ^ (r & 7)) << 4)) = rsa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int r = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(sb + r * 128 + ((c ^ (r & 7)) << 4)) = rsb[i];
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + BK - 1) / BK;
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int cur) {
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xa[TM], wb[TN];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / 2) + j * 16 + fr;
+                xa[j] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * (BN / 2) + i * 16 + fr;
+                wb[i] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(acc[i][j], wb[i], xa[j]);
+        }
+    };
+    load_tiles(0);
+    // ---- this sample's scale / shift for the conv group's Cin input channels: gn_apply_kernel's arithmetic, verbatim -- the partial sums of a group are
+    // added in block order by ONE thread -- but fetched by PS x groups threads at once (one round trip instead of PS dependent ones per workgroup),
+    // and behind the first tile's global loads, which do not depend on it
+    {
+        const int ch0 = (p.groups > 1 ? grp * (int)p.g_x : 0);   // first input channel of this conv group inside the map
+        const int ng = p.Cin / p.gi_cg, g0 = ch0 / p.gi_cg;
+        for (int e = tid; e < ng * p.gi_ps; e += 256) {
+            const int g = e / p.gi_ps, i = e - g * p.gi_ps;
+            const float2 o = *reinterpret_cast<const float2*>(p.gi_stats + (((size_t)smp * p.gi_ps + i) * p.gi_G + g0 + g) * 2);
+            s_part[e * 2] = o.x; s_part[e * 2 + 1] = o.y;
+        }
+        __syncthreads();
+        for (int g = tid; g < ng; g += 256) {
+            float a = 0.f, q = 0.f;
+            for (int i = 0; i < p.gi_ps; ++i) { a += s_part[(g * p.gi_ps + i) * 2]; q += s_part[(g * p.gi_ps + i) * 2 + 1]; }
+            const float inv_n = 1.0f / ((float)p.gi_hw * (float)p.gi_cg);
+            const float mean = a * inv_n;
+            const float var = relu_f(q * inv_n - mean * mean);
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(var + p.gi_eps);
+        }
+        __syncthreads();
+        for (int ch = tid; ch < p.Cin; ch += 256) {
+            const int g = ch / p.gi_cg;
+            const float sc = s_rstd[g] * p.gi_gamma[ch0 + ch];
+            s_scale[ch] = sc;
+            s_shift[ch] = s_mean[g] * sc - p.gi_beta[ch0 + ch];
+        }
+        __syncthreads();
+    }
+    transform();
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        compute(cur);
+        if (kt + 1 < nk) { transform(); store_tiles(cur ^ 1); }
+        __syncthreads();
+    }
+    const uint4 no_pre[1] = {make_uint4(0u, 0u, 0u, 0u)};
+    igemm_epilogue<T, BM, BN>(p, acc, smem, m0, n0, tid, wm, wn, fr, fg, no_pre, false);
+}
+
+template <typename T, int BM, int BN>
+static hipError_t launch_gnin_cfg(IGemmDev d, hipStream_t s) {
+    d.tilesM = (d.M + BM - 1) / BM;
+    d.tilesN = (d.N + BN - 1) / BN;
+    d.map = 0;
+    const int grid = ((d.tilesM + 7) / 8) * 8 * d.tilesN;
+    size_t lds = 2 * (size_t)(BM + BN) * 128 + (size_t)(2 * d.Cin + 128 + 2 * (d.Cin / d.gi_cg) * d.gi_ps) * 4;
+    const size_t lds_c = (size_t)BM * (BN + 4) * 4 + 1024 + (d.cs_part ? 64 * 8 * 2 * 4 : 0);
+    if (lds_c > lds) lds = lds_c;
+    const void* fn = reinterpret_cast<const void*>(igemm_gnin_kernel<T, BM, BN>);
+    static DeviceOnce once;
+    if (once.need()) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        once.done();
+    }
+    void* args[] = {&d};
+    return hipLaunchKernel(fn, dim3(grid, d.groups), dim3(256), args, lds, s);
+}
+template <typename T>
+static hipError_t launch_gnin(const IGemmDev& d, hipStream_t s) {
+    if (d.gn_cg) return launch_gnin_cfg<T, 64, 128>(d, s);        // fused GroupNorm epilogue: 64 x 128 tiles of whole samples and groups
+    // 128-pixel tiles when the map allows and there are plenty of them (every workgroup pays the scale / shift prologue once)
+    const bool big = (d.Ho * d.Wo) % 128 == 0 && (long)d.groups * (d.M / 128) >= 512;
+    if (d.N <= 32) return big ? launch_gnin_cfg<T, 128, 32>(d, s) : launch_gnin_cfg<T, 64, 32>(d, s);
+    if (d.N <= 64) return big ? launch_gnin_cfg<T, 128, 64>(d, s) : launch_gnin_cfg<T, 64, 64>(d, s);
+    return big ? launch_gnin_cfg<T, 128, 128>(d, s) : launch_gnin_cfg<T, 64, 128>(d, s);
+}
+bool igemm_gnin_ok(const IGemm& g, int dt) {
+    if (dt != DT_BF16 && dt != DT_F16) return false;
+    const int hw_out = g.Ho * g.Wo;
+    if (!g.gi_stats || !g.gi_gamma || !g.gi_beta || g.gi_cg < 1 || g.gi_ps < 1 || g.gi_hw < 1) return false;
+    if (g.x_src_dt >= 0 || g.hpool || g.out_f32 || g.res_f32 || hw_out % 64 || g.M % hw_out || g.Cin % 8 || g.Cin % g.gi_cg || g.Cin > 1024 ||
+        g.Cin / g.gi_cg > 64 || (g.KH * g.KW > 1 && (g.Cin & (g.Cin - 1))))
+        return false;
+    if (g.groups > 1 && (g.g_x % g.gi_cg)) return false;
+    if (g.gi_out && (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.N > 128)) return false;
+    if (g.gi_res && !g.gi_out && (g.KH * g.KW > 1)) return false;     // (a residual on a 3x3 consumer is never needed)
+    return true;
 }
 
 // Register epilogue (round 3) for the plain case -- 16-bit output, bias / residual / activation only, a wave tile of an EVEN number of
@@ -1897,7 +2159,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // parked tile is two K blocks deep).  The slice is then requested behind the top-of-slice barrier -- every wave has left the previous
 // reduction -- and waited for at the slice-block barrier, a whole expansion + epilogue later.
 template <typename T, int BM, int C1, int CN, int KD = 0, bool PROF = false, int NWB = 0, int W1B = 2>
-__global__ __launch_bounds__(512, C1 >= 256 ? 2 : 4) void bneck231r_kernel(Bneck231Dev qq) {
+__global__ __launch_bounds__(512, (C1 >= 256 || (BM == 128 && C1 == 128)) ? 2 : 4) void bneck231r_kernel(Bneck231Dev qq) {
     // phase timing (HCM_IGEMM_PROF=1 builds, read through hcm_debug_igemm_prof): per-wave cycle totals [0] prologue up to the first barrier,
     // [1] phase A K loop, [2] park + top-of-slice waits and barriers, [3] expansion MFMAs, [4] register epilogues, [5] slice-block barrier +
     // reduction MFMAs + final epilogue, [6] waves, [7] K iterations
@@ -2860,6 +3122,15 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
     if (d.cs_part && (d.gn_cg || d.bias || g.x_src_dt >= 0 || d.cs_cg < 1 || 32 % d.cs_cg || d.N % d.cs_cg || d.cs_hw % 64 || d.M % d.cs_hw))
         return hipErrorInvalidValue;
+    d.gi_stats = nullptr;
+    if (g.gi_stats) {
+        if (!igemm_gnin_ok(g, dt)) return hipErrorInvalidValue;
+        if (d.gn_cg && (d.gn_hw <= 0 || 64 % d.gn_hw || d.M % d.gn_hw || d.gn_cg % 8 || 128 % d.gn_cg || d.N % d.gn_cg || d.bias || !d.gn_beta))
+            return hipErrorInvalidValue;
+        d.gi_stats = g.gi_stats; d.gi_gamma = g.gi_gamma; d.gi_beta = g.gi_beta; d.gi_ps = g.gi_ps; d.gi_cg = g.gi_cg; d.gi_G = g.gi_G;
+        d.gi_hw = g.gi_hw; d.gi_relu = g.gi_relu; d.gi_eps = g.gi_eps; d.gi_res = (const char*)g.gi_res; d.gi_out = (char*)g.gi_out;
+        return dt == DT_BF16 ? launch_gnin<bf16>(d, s) : launch_gnin<f16>(d, s);
+    }
     if (d.gn_cg) {
         // fused GroupNorm: 64-row tiles of whole samples, 128 channels of whole groups (igemm_epilogue)
         if (g.x_src_dt >= 0 || d.gn_hw <= 0 || 64 % d.gn_hw || d.M % d.gn_hw || d.gn_cg % 8 || 128 % d.gn_cg || d.N % d.gn_cg || d.bias ||
@@ -3076,6 +3347,25 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s) {
                     : b.CN == 64 ? reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 64>) : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 64, 128>);
         }
         static const bool no_halo = dev_env("HCM_NO_BNECK_HALO") != nullptr;
+        // round 4: 128 mid channels (layer2) on 128-PIXEL tiles, one 92 KB workgroup per CU instead of two 64-pixel ones.  A tile streams the block's
+        // 557 KB of weights (3x3 295 KB + expansion 131 KB + next reduction 131 KB) from L2 whatever its size: 2048 64-pixel tiles = 1.14 GB per launch
+        // (the pair at B = 64) against 0.39 GB of activations -- the launch was bound by that stream (134 us = 2.9 TB/s of HBM traffic, 0.28 of the
+        // matrix rate).  HCM_BNECK128_BM64=1 (development build): the 64-pixel tiles.
+        static const bool bm64 = dev_env("HCM_BNECK128_BM64") != nullptr;
+        if (!image && !no_halo && !bm64 && b.C1 == 128 && b.CN == 128 && b.stride == 1 && d.W % 16 == 0 && 128 % d.W == 0 && (d.Ho * d.Wo) % 128 == 0 &&
+            (long)d.groups * (d.M / 128) >= 192) {
+            const size_t halo = (size_t)KT1 * ((((128 / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 8192;
+            size_t lds = (size_t)KT1 * 128 * 128 + (size_t)KT1 * 64 * 128 + (size_t)128 * 128 + (size_t)b.CN * 128 + (size_t)(4 * b.C1 + b.CN) * 4;
+            if (halo > lds) lds = halo;
+            if (lds <= 96 * 1024) {
+                const void* fb = dt == DT_BF16 ? reinterpret_cast<const void*>(bneck231r_kernel<bf16, 128, 128, 128, 0, false, kHaloRing, 1>)
+                                               : reinterpret_cast<const void*>(bneck231r_kernel<f16, 128, 128, 128, 0, false, kHaloRing, 1>);
+                hipError_t eb = hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (eb != hipSuccess) return eb;
+                void* ab[] = {&qq};
+                return hipLaunchKernel(fb, dim3(d.M / 128, d.groups), dim3(512), ab, lds, s);
+            }
+        }
         bool halo_on = false;
         if (!image && !no_halo && b.stride == 1 && d.W % 16 == 0 && BM % d.W == 0 && (d.Ho * d.Wo) % BM == 0) {
             const size_t halo = (size_t)KT1 * ((((BM / d.W + 2) * (d.W + 2)) + 7) & ~7) * 128 + (size_t)kHaloRing * 8192;

@@ -67,9 +67,19 @@ struct IGemm {
     // (sample, 64-row pixel block, group) -> cs_part[((b * cs_hw / 64 + block) * cs_G + group) * 2]; cs_hw % 64 == 0, 32 % cs_cg == 0.
     // launch_groupnorm_apply then normalises without a statistics pass over the map.
     float* cs_part = nullptr; int cs_cg = 0, cs_hw = 0, cs_G = 0;
+    // GroupNorm ON LOAD (round 4; 16-bit GroupNorm trunks, large maps): x is the UN-normalised output of the producing conv, whose epilogue left
+    // sum / sum of squares per (sample, 64-pixel block, group) in gi_stats (the cs_part layout, gi_ps blocks per sample).  The register-staged
+    // kernel igemm_gnin_kernel normalises while it stages the operand -- relu?(x * scale[s][c] - shift[s][c] (+ gi_res)), rounded to T exactly as
+    // gn_apply_kernel would have stored it -- so the stand-alone apply pass and its launch disappear.  gi_out (1x1 stride-1 convs with one channel
+    // tile only): the normalised values are also written back (in place is fine: a pixel row is staged by exactly one workgroup) -- the block output
+    // that the NEXT residual add needs.  x, gi_res and gi_out share the pixel stride xC and the group offset g_x.
+    const float* gi_stats = nullptr; const float* gi_gamma = nullptr; const float* gi_beta = nullptr;
+    int gi_ps = 0, gi_cg = 0, gi_G = 0, gi_hw = 0, gi_relu = 0; float gi_eps = 1e-5f;
+    const void* gi_res = nullptr; void* gi_out = nullptr;
     int impl = 0;                // 0: launch_igemm chooses; 1: igemm_dma_kernel / igemm_kernel only; 2: the 256 x 256-tile kernel of gemm256.hip only
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
+bool igemm_gnin_ok(const IGemm& g, int dt);          // can launch_igemm take this conv with a GroupNorm-on-load operand (gi_*)?
 // 256 x 256-tile, 8-phase GEMM for wide token-major linear layers (gemm256.hip); bit-identical to launch_igemm's kernels
 bool gemm256_applicable(const IGemm& g, int dt);
 hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s);

@@ -107,3 +107,18 @@ def test_depth_layer3_run_equals_the_launch_per_conv_form():
         err = np.abs(a[k] - b[k]).max()
         print(k, err)
         assert err <= 2e-3, (k, err)
+
+
+@pytest.mark.parametrize("env", [{}, {"HCMT_DEPTH_HW": "256", "HCMT_L": "32"}, {"HCMT_DEPTH_HW": "384"}])
+def test_groupnorm_on_load_equals_the_apply_launches(env):
+    """Round 4: the GroupNorm trunk's large maps are normalised by the conv that READS them (igemm_gnin_kernel: scale / shift per (sample,
+    channel) from the producer's epilogue sums, applied between the global loads and the LDS stores, the block output written back by the next
+    block's first conv) instead of by 22 gn_apply_kernel launches per step.  Same sums in the same order, same expressions, same rounding: the whole
+    step must equal the step with the apply launches (HCM_NO_GN_ONLOAD=1) bit for bit -- 128-pixel depth frames (layer1 on 16 x 16 maps),
+    256-pixel (layer1 32 x 32, layer2 16 x 16, the bench configuration) and 384-pixel (non-power-of-two maps downstream)."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_GN_ONLOAD="1"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    assert np.isfinite(a["rec"]).all()

@@ -365,7 +365,9 @@ def test_bottleneck_tail_fused(prec, cfg):
                                  # halo phase A (tiles of whole image rows): 128 mid channels on 32- and 16-wide maps, 64 mid channels with a 128-wide reduction
                                  (2, 32, 32, 128, 1, 128), (3, 16, 16, 128, 1, 128), (2, 64, 64, 64, 1, 128), (1, 32, 32, 64, 1, 64),
                                  # 256 mid channels (RGB layer3; round 4): streamed identity rows, one workgroup per CU; ragged last tile, stride 2
-                                 (2, 16, 16, 256, 1, 256), (3, 8, 8, 256, 1, 256), (1, 12, 20, 256, 1, 256), (2, 16, 16, 256, 2, 256), (96, 16, 16, 256, 1, 256)])
+                                 (2, 16, 16, 256, 1, 256), (3, 8, 8, 256, 1, 256), (1, 12, 20, 256, 1, 256), (2, 16, 16, 256, 2, 256), (96, 16, 16, 256, 1, 256),
+                                 # 128 mid channels on 128-pixel tiles (taken from 192 tiles up)
+                                 (24, 32, 32, 128, 1, 128), (96, 16, 16, 128, 1, 128)])
 def test_bottleneck_tail_next_fused(prec, cfg):
     """Bottleneck tail + the next block's 1x1 reduction in one launch: both outputs BIT-identical to the three stand-alone convs."""
     lib, L = _lib()
