@@ -341,6 +341,45 @@ struct Fwd {
                     continue;
                 }
             }
+            // GroupNorm trunk, 32 x 32 maps with 128 / 32 channels or 16 x 16 with 256 / 64 (the depth encoder's layer1 / layer2 at 256-pixel frames): a run
+            // of identity bottlenecks is ONE launch, a whole sample of one trunk per workgroup -- depth_blk.hip (round 4)
+            static const bool no_blk = dev_env("HCM_NO_DEPTH_BLK") != nullptr;
+            // (not in the sizing pass: the launch-per-conv form, which a step with captured taps takes, carves statistics buffers this form does not need)
+            if (t.gn && !no_blk && !ctx->taps_on && !dry && pre < 0 && x.H == x.W && (x.H == 32 || x.H == 16) && t.groups == 16) {
+                const int Cb = x.H == 32 ? 128 : 256, Cm = Cb / 4;
+                auto plain = [&](const BottleneckW& q) {
+                    const bool dt16 = q.c1.dt == DT_F16 || q.c1.dt == DT_BF16;
+                    return dt16 && !q.has_ds && q.stride == 1 && q.c1.KH == 1 && q.c1.Cin == Cb && q.c1.Cout == Cm && q.c1.Kp == Cb && q.c2.KH == 3 && q.c2.KW == 3 &&
+                           q.c2.Cin == Cm && q.c2.Cout == Cm && q.c2.Kp == 9 * Cm && q.c3.KH == 1 && q.c3.Cin == Cm && q.c3.Cout == Cb && q.c3.Kp == Cm &&
+                           !q.c1.bias && !q.c2.bias && !q.c3.bias && q.c2.dt == q.c1.dt && q.c3.dt == q.c1.dt && q.c1.groups == q.c2.groups &&
+                           q.c1.groups == q.c3.groups;
+                };
+                size_t run = 0;
+                while (bi + run < t.blocks.size() && run < 4 && plain(t.blocks[bi + run]) && t.blocks[bi + run].c1.groups == t.blocks[bi].c1.groups) ++run;
+                if (run >= 1 && x.C == t.blocks[bi].c1.groups * Cb) {
+                    flush(xpend);                  // the kernel reads the materialised block input
+                    int fo = 0;
+                    while (fo == xi) ++fo;
+                    if (!dry) {
+                        DepthBlk q;
+                        q.x = x.p; q.y = slot[fo]; q.ld = x.C; q.B = B; q.groups = t.blocks[bi].c1.groups; q.nblocks = (int)run; q.side = x.H; q.C = Cb; q.CM = Cm;
+                        for (size_t r = 0; r < run; ++r) {
+                            const BottleneckW& bb = t.blocks[bi + r];
+                            q.w1[r] = bb.c1.w; q.w2[r] = bb.c2.w; q.w3[r] = bb.c3.w;
+                            q.g1[r] = bb.n1.gamma; q.b1[r] = bb.n1.beta; q.g2[r] = bb.n2.gamma; q.b2[r] = bb.n2.beta; q.g3[r] = bb.n3.gamma; q.b3[r] = bb.n3.beta;
+                            q.eps1[r] = 1e-5f * bb.c1.fold * bb.c1.fold; q.eps2[r] = 1e-5f * bb.c2.fold * bb.c2.fold; q.eps3[r] = 1e-5f * bb.c3.fold * bb.c3.fold;
+                        }
+                        ck(launch_depth_blk(q, t.blocks[bi].c1.dt, s), "depth layer1/2 run");
+                        calib_check(slot[fo], t.blocks[bi].c1.dt, B * x.H * x.W, x.C, x.C);
+                    }
+                    x = Act{slot[fo], B, x.H, x.W, x.C};
+                    xi = fo;
+                    bidx += (int)run;
+                    bi += run - 1;
+                    if (bidx == 3 || bidx == 7) mark(tapname + ".layer" + std::to_string(bidx == 3 ? 1 : 2) + "_end");
+                    continue;
+                }
+            }
             const BottleneckW& b = t.blocks[bi];
             int fr[3], nf = 0;
             if (pre >= 0) fr[nf++] = pre;

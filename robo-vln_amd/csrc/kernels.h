@@ -114,6 +114,17 @@ struct DepthL3 {
     float eps1[6] = {}, eps2[6] = {}, eps3[6] = {};
 };
 hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s);
+// Identity bottlenecks of the depth GroupNorm trunk's layer1 (side 32, C 128, CM 32) / layer2 (side 16, C 256, CM 64), a whole sample of one trunk
+// per workgroup (depth_blk.hip, round 4).  x / y: [B][side*side][ld] activations, trunk g at channels [g * C, +C); weights [groups][CM][C],
+// [groups][CM][9*CM] (k = tap * CM + ci), [groups][C][CM]; no biases; 16 GroupNorm groups per trunk.  nblocks > 1 needs x != y.
+struct DepthBlk {
+    const void* x = nullptr; void* y = nullptr;
+    int ld = 0, B = 0, groups = 1, nblocks = 0, side = 0, C = 0, CM = 0;
+    const void* w1[4] = {}; const void* w2[4] = {}; const void* w3[4] = {};
+    const float* g1[4] = {}; const float* b1[4] = {}; const float* g2[4] = {}; const float* b2[4] = {}; const float* g3[4] = {}; const float* b3[4] = {};
+    float eps1[4] = {}, eps2[4] = {}, eps3[4] = {};
+};
+hipError_t launch_depth_blk(const DepthBlk& d, int dt, hipStream_t s);
 hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 
 // While tuning is on, the first launch of every new (shape, dtype) times all tile/staging variants on the real
