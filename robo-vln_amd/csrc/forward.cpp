@@ -166,8 +166,14 @@ struct Fwd {
     // Skinny long-K layers (the M = batch projections behind the encoders, SimpleCNN's 25088-wide FC) would run on a few
     // dozen workgroups with hundreds of serial K steps: they are split along K through the grouped-launch mechanism (group s
     // = columns [s*Ks, (s+1)*Ks) of A and W, f32 partials), then summed in a fixed order with bias + activation.
+    // folded LayerNorm around a BERT GEMM (IGemm::ln_* / rln_*)
+    struct LnFold {
+        const float* ln_s = nullptr; const float* ln_t = nullptr; float* stats_out = nullptr;              // consumer side (QKV / FFN1): forced onto gemm256f_kernel
+        const float* rln_stats = nullptr; const float* rln_gamma = nullptr; const float* rln_beta = nullptr;  // residual side (attention output / FFN2)
+        const float* part_in = nullptr; float* part_out = nullptr; int P = 0; int force_choice = -1;          // partial row sums: producer epilogue -> consumer prologue
+    };
     void linear(const LinW& w, const void* a, int M, int lda, void* y, int ldy, int act, bool out_f32,
-                const void* res = nullptr, int ldr = 0, int wdt = -1) {
+                const void* res = nullptr, int ldr = 0, int wdt = -1, const LnFold* lf = nullptr) {
         const int wd = wdt < 0 ? w.dt : wdt;
         const int CHw = wd == DT_F32 ? 4 : 8;
         int S = 1;
@@ -183,6 +189,12 @@ struct Fwd {
         g.x = a; g.w = w.w; g.bias = w.bias; g.res = res; g.y = y;
         g.B = M; g.Cin = w.K; g.xC = lda; g.M = M; g.N = w.N; g.K = w.K; g.Kp = w.Kp;
         g.ldy = ldy; g.ldr = ldr ? ldr : w.N; g.act = act; g.out_f32 = out_f32 ? 1 : 0;
+        if (lf) {
+            g.ln_s = lf->ln_s; g.ln_t = lf->ln_t; g.ln_stats_out = lf->stats_out; g.ln_eps = 1e-12f;
+            if (lf->ln_s) { g.impl = 2; g.force_gemm256 = 1; }
+            g.ln_part_in = lf->part_in; g.ln_part_out = lf->part_out; g.ln_part_P = lf->P; g.force_choice = lf->force_choice;
+            g.rln_stats = lf->rln_stats; g.rln_gamma = lf->rln_gamma; g.rln_beta = lf->rln_beta;
+        }
         if (S > 1) {
             const int Ks = w.K / S;
             g.K = Ks; g.Cin = Ks; g.bias = nullptr; g.y = part; g.ldy = w.N; g.ldr = w.N; g.act = ACT_NONE; g.out_f32 = 1;
@@ -599,6 +611,65 @@ struct Fwd {
         };
         int li = 0;
         mark("bert.embed");
+        // LayerNorm FOLDED into the GEMMs around it (round 4; fp16 tiles, QKV and FFN1 on the 256 x 256 kernel): the tensor between two projections
+        // stays the pre-LayerNorm sum u, its consumer computes rstd * (u W'^T - mean * s) + t with the row statistics taken inside its own K loop, and
+        // the next residual add rebuilds LayerNorm(u) from those statistics.  24 of the 26 LayerNorm launches of a step disappear (the embedding's is
+        // fused already, the last layer's output is materialised).  HCM_NO_LN_FOLD=1 (development build): the launches.
+        // MEASURED SLOWER and therefore OFF unless HCM_LN_FOLD=1 (development build): taking the row statistics inside the consumer's K loop costs 128
+        // v_dot2_f32_f16 per K tile and wave, ~12 cycles each beside the MFMAs -- gemm256f 29.3 -> 39.0 us per launch, +0.23 ms of kernel time per step
+        // against the 0.155 ms of LayerNorm launches removed (same-box A/B 14 463 vs 14 814 env-steps/s).  Numerically it is fine (toggle test: 3e-5 on the
+        // record).  The statistics would have to come out of the PRODUCER's epilogue (partials per 32-column wave slice, combined in the consumer's
+        // prologue) to pay; not built.
+        static const bool no_fold = dev_env("HCM_LN_FOLD") == nullptr || dev_env("HCM_NO_LN_FOLD") != nullptr;
+        static const int fold_min_rows = dev_env("HCM_LN_FOLD_MIN_ROWS") ? atoi(dev_env("HCM_LN_FOLD_MIN_ROWS")) : 4096;      // (the toggle test's small engine)
+        // Decided per ENGINE (its maximum batch), not per call: the folded form is not bit-identical to the LayerNorm launches, and a refresh of two
+        // environments' instruction streams (hcm_refresh_instruction: BERT at batch 2) must reproduce what the full batch computes, bit for bit --
+        // so in an engine sized for big batches every bert() call folds, the folded GEMMs forced onto gemm256f_kernel whatever the row count (a row's
+        // result there does not depend on the batch it is in).  Engines sized for a few environments keep the launches (the 256-wide tiles would cost
+        // a single-environment step ~0.2 ms).
+        bool fold = !no_fold && dt == DT_F16 && !f32_stream && !ctx->taps_on && !w.layers.empty() && w.layers[0].ff1_f.w != nullptr && (D % 64) == 0 &&
+                    (3 * D) % 8 == 0 && c.bert_inter % 8 == 0 && (size_t)c.max_batch * c.instr_len >= (size_t)fold_min_rows;
+        if (fold) {
+            float* st1 = alloc_f(rmax * 2);                 // (mean, rstd) per row of u1 (pre-ln1) / u2 (pre-ln2)
+            float* st2 = alloc_f(rmax * 2);
+            // HCM_LN_FOLD=2: the row sums come out of the producing projection's register epilogue as partials per 32-column slice (forced onto the
+            // 128 x 128 8-wave tiles whatever the row count) and are combined in the consumer's prologue; =1: taken inside the consumer's K loop
+            static const int fold_mode = atoi(dev_env("HCM_LN_FOLD"));
+            const bool parts = fold_mode >= 2 && D % 32 == 0;
+            const int P = D / 32;
+            float* pt1 = parts ? alloc_f(rmax * P * 2) : nullptr;
+            float* pt2 = parts ? alloc_f(rmax * P * 2) : nullptr;
+            const long b128 = (long)((rows + 127) / 128) * ((D + 127) / 128);
+            const int ch_o = 4 * 6, ch_f2 = b128 <= 256 ? 9 * 6 : 7 * 6;       // attention output: 2-buffer ring; FFN2 (K = 3072): deep / interleaved ring
+            bool xmat = true;                                // x holds a materialised LayerNorm output (the embedding's); afterwards u2 of the previous layer
+            const NormW* prev_ln2 = nullptr;
+            for (const BertLayerW& l : w.layers) {
+                if (li) mark("bert.layer" + std::to_string(li));
+                LnFold fq, fo, f1, f2;
+                if (xmat) linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
+                else {
+                    fq.ln_s = l.qkv_s; fq.ln_t = l.qkv_t; fq.stats_out = st2; fq.part_in = pt2; fq.P = parts ? P : 0;
+                    linear(l.qkv_f, x, rows, D, qkv, 3 * D, ACT_NONE, false, nullptr, 0, -1, &fq);
+                }
+                if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
+                                              L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
+                // u1 = ctx Wo^T + bo + LayerNorm_prev(x)
+                if (!xmat) { fo.rln_stats = st2; fo.rln_gamma = prev_ln2->gamma; fo.rln_beta = prev_ln2->beta; }
+                if (parts) { fo.part_out = pt1; fo.P = P; fo.force_choice = ch_o; }
+                linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D, -1, (xmat && !parts) ? nullptr : &fo);
+                f1.ln_s = l.ff1_s; f1.ln_t = l.ff1_t; f1.stats_out = st1; f1.part_in = pt1; f1.P = parts ? P : 0;
+                linear(l.ff1_f, tmp, rows, D, hbuf, c.bert_inter, ACT_GELU, false, nullptr, 0, -1, &f1);
+                // u2 = h W2^T + b2 + LayerNorm1(u1)
+                f2.rln_stats = st1; f2.rln_gamma = l.ln1.gamma; f2.rln_beta = l.ln1.beta;
+                if (parts) { f2.part_out = pt2; f2.P = P; f2.force_choice = ch_f2; }
+                linear(l.ff2, hbuf, rows, c.bert_inter, x, D, ACT_NONE, false, tmp, D, -1, &f2);
+                xmat = false;
+                prev_ln2 = &l.ln2;
+                ++li;
+            }
+            ln(x, nullptr, *prev_ln2, nullptr, 0, x, rows, D, 1e-12f);        // the encoder's output, materialised (in place: a row is one wave's registers)
+            return;
+        }
         for (const BertLayerW& l : w.layers) {
             if (li) mark("bert.layer" + std::to_string(li));
             linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);

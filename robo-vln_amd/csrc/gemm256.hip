@@ -41,6 +41,9 @@ struct G256Dev {
     int M, N, K, ldx, ldw, ldy, act;
     unsigned x_bytes, w_bytes;
     int tilesM, tilesN, gm, gn;      // XCD grid: the 8 XCDs own gm x gn rectangles of the tile grid (each has a private L2)
+    // folded LayerNorm (IGemm::ln_*): x holds the pre-LayerNorm rows u, w = W diag(gamma)
+    const float* ln_s; const float* ln_t; float* ln_stats_out; float ln_eps;
+    const float* ln_part; int ln_part_P;          // IGemm::ln_part_in: partial row sums from the producer's epilogue (else: taken in the K loop)
 };
 
 template <typename T> struct GMma;
@@ -91,8 +94,10 @@ __device__ __forceinline__ void g_quad(g_f32x4 (&acc)[4][8], const uint4 (&wf)[2
 
 // Epilogue shared by the 8-wave kernels (gemm256_kernel, gemm256f_kernel): wave (wr, wc) holds tokens [wr*128, +128) x channels [wc*64, +64) of the tile,
 // acc[i][j] = channel fragment i x token fragment j, a lane holds 4 consecutive channels of one token.
-template <typename T>
-__device__ __forceinline__ void g_epilogue(const G256Dev& p, g_f32x4 (&acc)[4][8], char* smem, int m0, int n0, int tid, int wr, int wc, int fr, int fg) {
+// LNF: the folded-LayerNorm form -- v = rstd[row] * (acc - mean[row] * ln_s[n]) + ln_t[n] instead of acc + bias[n] (mean / rstd: the lane's 8 token rows j)
+template <typename T, bool LNF = false>
+__device__ __forceinline__ void g_epilogue(const G256Dev& p, g_f32x4 (&acc)[4][8], char* smem, int m0, int n0, int tid, int wr, int wc, int fr, int fg,
+                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
     if (p.res) {
         // ---- residual epilogue: y = act(acc + bias + res), one rounding -- the order of f32 operations of igemm_epilogue.  The accumulators
         // go through an f32 LDS image of HALF the tile at a time (128 rows x 256 channels, rows padded to 1040 B); in the row pass every
@@ -154,11 +159,17 @@ __device__ __forceinline__ void g_epilogue(const G256Dev& p, g_f32x4 (&acc)[4][8
     // shapes 0.4 us faster: inside the box-to-box noise).  The image rows of the parts are disjoint: one barrier per part.
     {
         constexpr int NP = 2, JP = 8 / NP, RP = JP * 16;          // parts, fragment rows per part, tile rows per part and row group
-        float4 b4[4];
+        float4 b4[4], s4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wc * 64 + i * 16 + fg * 4;
-            b4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (LNF) {
+                b4[i] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_t + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s4[i] = n < p.N ? *reinterpret_cast<const float4*>(p.ln_s + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                b4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         const int chunk = tid & 31;                    // 16-byte piece of a 512-byte row
         const int n = n0 + chunk * 8;
@@ -172,8 +183,14 @@ __device__ __forceinline__ void g_epilogue(const G256Dev& p, g_f32x4 (&acc)[4][8
                 float v[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i * 4 + 0] = acc[i][j][0] + b4[i].x; v[i * 4 + 1] = acc[i][j][1] + b4[i].y;
-                    v[i * 4 + 2] = acc[i][j][2] + b4[i].z; v[i * 4 + 3] = acc[i][j][3] + b4[i].w;
+                    if constexpr (LNF) {
+                        const float mu = ln_mean[j], rs = ln_rstd[j];
+                        v[i * 4 + 0] = (acc[i][j][0] - mu * s4[i].x) * rs + b4[i].x; v[i * 4 + 1] = (acc[i][j][1] - mu * s4[i].y) * rs + b4[i].y;
+                        v[i * 4 + 2] = (acc[i][j][2] - mu * s4[i].z) * rs + b4[i].z; v[i * 4 + 3] = (acc[i][j][3] - mu * s4[i].w) * rs + b4[i].w;
+                    } else {
+                        v[i * 4 + 0] = acc[i][j][0] + b4[i].x; v[i * 4 + 1] = acc[i][j][1] + b4[i].y;
+                        v[i * 4 + 2] = acc[i][j][2] + b4[i].z; v[i * 4 + 3] = acc[i][j][3] + b4[i].w;
+                    }
                 }
                 if (p.act == ACT_RELU) {
 #pragma unroll
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(G256Dev p) {
 // tile's buffer is free for tile t+2, and tile t+1 -- requested a whole tile earlier -- has landed (`vmcnt(0)`: the wave's 8 pieces, the
 // barrier makes it everybody's).  Same MFMA instruction, same k order per accumulator (K step 0 then K step 1 of every tile): bit-identical
 // to gemm256_kernel.
-template <typename T, int PROF = 0, int OPT = 0>
+template <typename T, int PROF = 0, int OPT = 0, int LNF = 0>        // LNF: 0 plain, 1 folded LayerNorm with in-loop row statistics, 2 ... with the producer's partials
 __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
@@ -518,6 +535,25 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
+    // LNF: sum and sum of squares of the wave's 128 token rows over K, from the operand fragments the MFMAs consume anyway (fdot2 on packed halves: 8
+    // VALU operations per fragment, 128 per K tile beside 64 MFMAs); the lane's share = its 8-element K chunks of rows j * 16 + fr
+    float ln_su[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ln_sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto ln_acc = [&](const uint4 (&xf)[8]) {
+        if constexpr (LNF == 1 && std::is_same<T, f16>::value) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w[4] = {xf[j].x, xf[j].y, xf[j].z, xf[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const h2 v = __builtin_bit_cast(h2, w[q]);
+                    ln_su[j] = __builtin_amdgcn_fdot2(v, one, ln_su[j], false);
+                    ln_sq[j] = __builtin_amdgcn_fdot2(v, v, ln_sq[j], false);
+                }
+            }
+        }
+    };
     // fragment f of a register set: f < 4 weight fragment i = f (A operand), else token fragment j = f - 4 (B operand)
     auto rd_frag = [&](uint4 (&wf)[4], uint4 (&xf)[8], int f, int ks, unsigned buf) {
         if (f < 4) {
@@ -541,6 +577,25 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
     } else {
         g_wait_vmcnt<0>();
     }
+    if constexpr (LNF == 2) {
+        // row statistics of the tile's 256 token rows from the producer's partials (one thread per row, slices in order: deterministic), into the 4 KB
+        // of LDS behind the two K-tile buffers -- while the first tiles' requests are in flight; every lane copies its 8 rows out before the epilogue
+        // image claims those bytes
+        if (tid < 256) {
+            const int m = m0 + tid;
+            float a = 0.f, q = 0.f;
+            if (m < p.M) {
+                const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + (size_t)m * p.ln_part_P;
+                for (int i = 0; i < p.ln_part_P; ++i) { const float2 v = pp[i]; a += v.x; q += v.y; }
+            }
+            const float inv_k = 1.0f / (float)p.K;
+            const float mean = a * inv_k;
+            const float var = q * inv_k - mean * mean;
+            const float rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+            *reinterpret_cast<float2*>(smem + 2 * G_BUF + tid * 8) = make_float2(mean, rstd);
+            if (p.ln_stats_out && tile_n == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_stats_out + 2 * (size_t)m) = make_float2(mean, rstd);
+        }
+    }
     G_BAR();
 #pragma unroll
     for (int f = 0; f < 12; ++f) rd_frag(wfa, xfa, f, 0, 0);
@@ -562,6 +617,7 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        ln_acc(xfa);
         lap(0);
         // this wave is past its last read of the tile's buffer; its pieces of tile t+1 (requested a tile ago) have landed
         // (sched_barrier: MFMAs are register-only, so hipcc would otherwise sink them below these waits)
@@ -597,6 +653,7 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        ln_acc(xfb);
         lap(3);
     };
     if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(1);      // over waves of OTHER kernels co-resident on the SIMD (a step runs three chains)
@@ -609,7 +666,33 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
     if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                                   // every wave is done with the operand buffers: the epilogue images reuse them
     if constexpr (PROF) t_prev = g_now();
-    g_epilogue<T>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg);
+    if constexpr (LNF == 2) {
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 st = *reinterpret_cast<const float2*>(smem + 2 * G_BUF + (wr * 128 + j * 16 + fr) * 8);
+            mean[j] = st.x; rstd[j] = st.y;
+        }
+        __syncthreads();                               // every lane holds its rows' statistics: the image may overwrite the table
+        g_epilogue<T, true>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg, mean, rstd);
+    } else if constexpr (LNF == 1) {
+        float mean[8], rstd[8];
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = ln_su[j], q = ln_sq[j];
+            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+            mean[j] = a * inv_k;
+            const float var = q * inv_k - mean[j] * mean[j];
+            rstd[j] = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+            const int m = m0 + wr * 128 + j * 16 + fr;
+            if (p.ln_stats_out && wc == 0 && fg == 0 && tile_n == 0 && m < p.M) *reinterpret_cast<float2*>(p.ln_stats_out + 2 * (size_t)m) = make_float2(mean[j], rstd[j]);
+        }
+        g_epilogue<T, true>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg, mean, rstd);
+    } else {
+        g_epilogue<T>(p, acc, smem, m0, n0, tid, wr, wc, fr, fg);
+    }
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lap(5);
@@ -867,6 +950,17 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(G256Dev p) {
 
 #endif  // HCM_DEV_KNOBS
 
+// layout / range constraints only (a forced launch, IGemm::force_gemm256: the folded-LayerNorm GEMMs must run on this kernel at every batch size so that a
+// row's result does not depend on the batch it is computed in)
+static bool gemm256_valid(const IGemm& g, int dt) {
+    if (dt != DT_BF16 && dt != DT_F16) return false;
+    if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;
+    if (g.out_f32 || g.res_f32 || g.groups > 1 || g.gn_gamma || g.cs_part || g.hpool || g.x_src_dt >= 0 || g.gi_stats) return false;
+    const int Kp = g.Kp ? g.Kp : g.K, ldx = g.xC ? g.xC : g.Cin, ldy = g.ldy ? g.ldy : g.N, ldr = g.ldr ? g.ldr : g.N;
+    if (g.K % 64 || Kp % 8 || ldx % 8 || ldy % 8 || g.N % 8 || (g.res && ldr % 8) || g.K < 128) return false;
+    if ((size_t)g.M * ldx * 2 >= 0x7FFFFFF0ull || (size_t)g.N * Kp * 2 >= 0x7FFFFFF0ull) return false;
+    return g.M >= 1 && g.N >= 8;
+}
 bool gemm256_applicable(const IGemm& g, int dt) {
     if (dt != DT_BF16 && dt != DT_F16) return false;
     if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0 || g.H != 1 || g.W != 1) return false;       // plain row-major GEMM
@@ -883,11 +977,14 @@ bool gemm256_applicable(const IGemm& g, int dt) {
 }
 
 hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
-    if (!gemm256_applicable(g, dt)) return hipErrorInvalidValue;
+    if (g.force_gemm256 ? !gemm256_valid(g, dt) : !gemm256_applicable(g, dt)) return hipErrorInvalidValue;
     G256Dev d;
     d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.y = (char*)g.y;
     d.res = (const char*)g.res; d.ldr = g.ldr ? g.ldr : g.N;
     d.M = g.M; d.N = g.N; d.K = g.K; d.ldx = g.xC ? g.xC : g.Cin; d.ldw = g.Kp ? g.Kp : g.K; d.ldy = g.ldy ? g.ldy : g.N; d.act = g.act;
+    d.ln_s = g.ln_s; d.ln_t = g.ln_t; d.ln_stats_out = g.ln_stats_out; d.ln_eps = g.ln_eps; d.ln_part = g.ln_part_in; d.ln_part_P = g.ln_part_P;
+    if (g.ln_part_in && (!g.ln_s || g.ln_part_P < 1)) return hipErrorInvalidValue;
+    if (g.ln_s && (dt != DT_F16 || !g.ln_t || g.res)) return hipErrorInvalidValue;      // folded LayerNorm: fp16, no residual
     d.x_bytes = (unsigned)(((size_t)(g.M - 1) * d.ldx + g.K) * 2);
     d.w_bytes = (unsigned)((size_t)g.N * d.ldw * 2);
     d.tilesM = (g.M + G_BM - 1) / G_BM;
@@ -914,6 +1011,8 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
     if (eight_phase) fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256_kernel<bf16>) : reinterpret_cast<const void*>(gemm256_kernel<f16>);
     else if (g.K <= 1024) fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256f_kernel<bf16, 0, 2>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2>);
     else fn = dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256f_kernel<bf16, 0, 0>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 0>);
+    if (g.ln_s && g.ln_part_in) fn = g.K <= 1024 ? reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2, 2>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 0, 2>);
+    else if (g.ln_s) fn = g.K <= 1024 ? reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 2, 1>) : reinterpret_cast<const void*>(gemm256f_kernel<f16, 0, 0, 1>);
     int threads = 512;
 #ifdef HCM_DEV_KNOBS
     // `make DEV=1` builds only (libhcm_dev.so): g.impl >> 4 selects the experiment builds DESIGN.md section 7 quotes (f16): 1 = SCHED 1;

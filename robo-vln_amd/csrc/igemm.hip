@@ -63,7 +63,19 @@ struct IGemmDev {
     // GroupNorm on load (IGemm::gi_*, igemm_gnin_kernel)
     const float* gi_stats; const float* gi_gamma; const float* gi_beta; int gi_ps, gi_cg, gi_G, gi_hw, gi_relu; float gi_eps;
     const char* gi_res; char* gi_out;
+    // residual = LayerNorm(res) on the fly (IGemm::rln_*)
+    const float* rln_stats; const float* rln_gamma; const float* rln_beta;
+    float* ln_part; int ln_part_P;       // IGemm::ln_part_out: (sum, sum of squares) of every stored row over this wave column's 32 channels
 };
+// the residual chunk rr (8 channels n .. n + 7 of row m, read from the pre-LayerNorm tensor) -> its LayerNorm
+__device__ __forceinline__ void rln_apply(const IGemmDev& p, int m, int n, float (&rr)[8]) {
+    const float2 st = *reinterpret_cast<const float2*>(p.rln_stats + 2 * (size_t)m);
+    const float4 g0 = *reinterpret_cast<const float4*>(p.rln_gamma + n), g1 = *reinterpret_cast<const float4*>(p.rln_gamma + n + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.rln_beta + n), b1 = *reinterpret_cast<const float4*>(p.rln_beta + n + 4);
+    const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rr[e] = (rr[e] - st.x) * st.y * ga[e] + be[e];
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -276,11 +288,13 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
                 if (have_pre) {                 // residual chunk prefetched at kernel start (see igemm_dma_kernel)
                     float rr[8];
                     cvt_chunk<T>(rpre[pass < NPRE ? pass : 0], rr);
+                    if (p.rln_stats) rln_apply(p, m, n, rr);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rr[e];
                 } else if (wide16r) {
                     float rr[8];
                     ld_chunk(rp, rr);
+                    if (p.rln_stats) rln_apply(p, m, n, rr);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rr[e];
                 } else {
@@ -1122,6 +1136,7 @@ __device__ __forceinline__ void igemm_epilogue_regs(const IGemmDev& p, f32x4 (&a
                 float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (have_pre) cvt_chunk<T>(rpre[ip * TM + j], rr);
                 else if (ok) ld_chunk(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n, rr);
+                if (p.rln_stats && ok) rln_apply(p, m, n, rr);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rr[e];
             }
@@ -1131,7 +1146,22 @@ __device__ __forceinline__ void igemm_epilogue_regs(const IGemmDev& p, f32x4 (&a
             } else if (p.act == ACT_GELU) {
                 gelu_vec<T, 8>(v);
             }
-            if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = pack_chunk<T>(v);
+            const uint4 o = pack_chunk<T>(v);
+            if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.y) + (size_t)m * p.ldy + n) = o;
+            if (p.ln_part) {
+                // statistics of the STORED (rounded) values over the 32 channels this wave column holds of row m: the four K-group lanes of the row
+                float r8[8];
+                cvt_chunk<T>(o, r8);
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a += r8[e]; q += r8[e] * r8[e]; }
+                a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+                a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+                if (fg == 0 && m < p.M && n_ok) {
+                    const int slot = (n0 + wn * (BN / WNc) + ip * 32) >> 5;
+                    *reinterpret_cast<float2*>(p.ln_part + ((size_t)m * p.ln_part_P + slot) * 2) = make_float2(a, q);
+                }
+            }
         }
     }
 }
@@ -3122,6 +3152,19 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if (dt != DT_BF16 && dt != DT_F16 && dt != DT_F32) return hipErrorInvalidValue;
     if (d.cs_part && (d.gn_cg || d.bias || g.x_src_dt >= 0 || d.cs_cg < 1 || 32 % d.cs_cg || d.N % d.cs_cg || d.cs_hw % 64 || d.M % d.cs_hw))
         return hipErrorInvalidValue;
+    d.rln_stats = g.rln_stats; d.rln_gamma = g.rln_gamma; d.rln_beta = g.rln_beta;
+    if (g.rln_stats && (!g.res || g.res_f32 || dt == DT_F32 || !g.rln_gamma || !g.rln_beta || (d.N % 8) || (d.ldr % 8) || g.groups > 1 || d.gn_cg || d.cs_part))
+        return hipErrorInvalidValue;              // the LayerNorm-on-the-fly residual exists in the 16-byte residual paths of the 16-bit epilogues only
+    if (g.ln_s) return hipErrorInvalidValue;      // the folded-LayerNorm consumer is gemm256f_kernel only (launch_gemm256)
+    d.ln_part = g.ln_part_out; d.ln_part_P = g.ln_part_P;
+    if (g.ln_part_out) {
+        // partial row statistics come out of the REGISTER epilogue of the 8-wave 128-channel tiles (a wave column = 32 channels = one slot)
+        const int fc = g.force_choice;
+        const bool tile_ok = fc >= 0 && fc < 100 && (fc % 6 == 0 || fc % 6 == 5) && (fc / 6 == 4 || fc / 6 == 5 || fc / 6 == 6 || fc / 6 == 7 || fc / 6 == 9 || fc / 6 == 10);
+        if (!tile_ok || dt == DT_F32 || g.out_f32 || (d.N % 32) || g.ln_part_P != d.N / 32 || d.gn_cg || d.cs_part || g.groups > 1 || (d.ldy % 8) || d.image_epi ||
+            (g.res && (d.ldr % 8)))
+            return hipErrorInvalidValue;
+    }
     d.gi_stats = nullptr;
     if (g.gi_stats) {
         if (!igemm_gnin_ok(g, dt)) return hipErrorInvalidValue;
@@ -3185,6 +3228,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
         }
         return m;
     }();
+    if (g.force_choice >= 0) return launch_dt(d, dt, g.force_choice, s);
     if (!shape_force.empty() && !narrow_stride) {
         auto it = shape_force.find(std::to_string(d.M) + "," + std::to_string(d.N) + "," + std::to_string(d.K));
         if (it != shape_force.end()) return launch_dt(d, dt, it->second, s);

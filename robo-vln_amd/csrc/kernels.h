@@ -76,6 +76,21 @@ struct IGemm {
     const float* gi_stats = nullptr; const float* gi_gamma = nullptr; const float* gi_beta = nullptr;
     int gi_ps = 0, gi_cg = 0, gi_G = 0, gi_hw = 0, gi_relu = 0; float gi_eps = 1e-5f;
     const void* gi_res = nullptr; void* gi_out = nullptr;
+    // LayerNorm folded into the GEMMs around it (round 4, BERT in fp16 mode; forward.cpp bert()).  The tensor BETWEEN two GEMMs stays the pre-LayerNorm
+    // sum u; the LayerNorm h = (u - mean) * rstd * gamma + beta is never materialised:
+    //   consumer (gemm256f_kernel, QKV / FFN1): y = act(rstd[m] * (u W'^T - mean[m] * ln_s[n]) + ln_t[n]), W' = W diag(gamma) (the weight matrix passed
+    //     in), ln_s[n] = sum_k W'[n][k], ln_t[n] = sum_k W[n][k] beta[k] + bias[n]; the row statistics are taken from the operand fragments inside the K
+    //     loop (fdot2) and, with ln_stats_out, written as (mean, rstd) per row for ...
+    //   ... the residual of the NEXT projection (igemm epilogues, attention-output / FFN2): res holds u, the epilogue adds
+    //     (u - mean) * rstd * rln_gamma + rln_beta with (mean, rstd) from rln_stats.
+    const float* ln_s = nullptr; const float* ln_t = nullptr; float* ln_stats_out = nullptr; float ln_eps = 1e-12f;
+    // where the consumer's row statistics come from: ln_part_in = [M][ln_part_P][2] partial (sum, sum of squares) per 32-column slice of the row, left
+    // by the PRODUCER's register epilogue (ln_part_out, igemm 8-wave tiles with 32-channel wave columns: force_choice) and combined in fixed order in
+    // the consumer's prologue; nullptr = taken inside the consumer's own K loop (measured slower: 128 v_dot2 per K tile and wave)
+    const float* ln_part_in = nullptr; int ln_part_P = 0; float* ln_part_out = nullptr;
+    int force_gemm256 = 0;       // 1: gemm256f_kernel whatever the row count (layout constraints only; the folded-LayerNorm consumers)
+    int force_choice = -1;       // >= 0: launch_igemm's (tile, staging variant) choice for this launch (the folded-LayerNorm producers)
+    const float* rln_stats = nullptr; const float* rln_gamma = nullptr; const float* rln_beta = nullptr;
     int impl = 0;                // 0: launch_igemm chooses; 1: igemm_dma_kernel / igemm_kernel only; 2: the 256 x 256-tile kernel of gemm256.hip only
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);

@@ -70,6 +70,10 @@ struct SimpleCnnW {
 struct BertLayerW {
     LinW qkv, o, ff1, ff2;
     NormW ln1, ln2;
+    // folded LayerNorm (fp16 BERT; forward.cpp bert(), IGemm::ln_*): ff1_f = W_ff1 diag(gamma_ln1) with ff1_s[n] = sum_k W'[n][k] (of the ROUNDED
+    // weights) and ff1_t[n] = sum_k W[n][k] beta_ln1[k] + b[n]; qkv_f likewise with the PREVIOUS layer's ln2 (absent in layer 0)
+    LinW qkv_f, ff1_f;
+    float* qkv_s = nullptr; float* qkv_t = nullptr; float* ff1_s = nullptr; float* ff1_t = nullptr;
 };
 struct BertW {
     float* word = nullptr; float* pos = nullptr; float* type0 = nullptr;

@@ -739,6 +739,46 @@ void prepare_high(hcm_ctx* ctx) {
         L.ff1 = make_linear(up, {&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, ctx->dt_bert);
         L.ff2 = make_linear(up, {&T_(ctx, M, p + "output.dense.weight")}, {&T_(ctx, M, p + "output.dense.bias")}, ctx->dt_bert);
         L.ln2 = make_norm(ctx, up, M, p + "output.LayerNorm");
+        if (ctx->dt_bert == DT_F16 && dev_env("HCM_LN_FOLD")) {      // (opt-in experiment of the development build: forward.cpp bert())
+            // LayerNorm folded into the GEMM that consumes it: W' = W diag(gamma), s = row sums of the fp16-ROUNDED W' (so that mean * s cancels exactly
+            // what the MFMAs accumulate for a constant row), t = W beta + b
+            auto fold = [&](const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs, const std::string& lnkey, LinW& out, float*& s_out, float*& t_out) {
+                const std::vector<float>& ga = T_(ctx, M, lnkey + ".weight").f;
+                const std::vector<float>& be = T_(ctx, M, lnkey + ".bias").f;
+                const int K = (int)ws[0]->shape[1];
+                int N = 0;
+                for (auto* w : ws) N += (int)w->shape[0];
+                out.N = N; out.K = K; out.Kp = round_up(K, 32); out.dt = DT_F16;
+                std::vector<float> r((size_t)N * out.Kp, 0.f), sv((size_t)N, 0.f), tv((size_t)N, 0.f);
+                int row = 0;
+                for (size_t wi = 0; wi < ws.size(); ++wi) {
+                    const int n = (int)ws[wi]->shape[0];
+                    for (int i = 0; i < n; ++i, ++row) {
+                        double sa = 0.0, ta = 0.0;
+                        for (int j = 0; j < K; ++j) {
+                            const float w = ws[wi]->f[(size_t)i * K + j];
+                            const float wf = w * ga[j];
+                            r[(size_t)row * out.Kp + j] = wf;
+                            sa += (double)(float)(_Float16)wf;
+                            ta += (double)w * (double)be[j];
+                        }
+                        sv[row] = (float)sa;
+                        tv[row] = (float)(ta + (double)bs[wi]->f[i]);
+                    }
+                }
+                out.w = up.typed(r, DT_F16);
+                out.bias = nullptr;
+                s_out = up.f32(sv);
+                t_out = up.f32(tv);
+            };
+            fold({&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, p + "attention.output.LayerNorm", L.ff1_f, L.ff1_s, L.ff1_t);
+            if (i > 0) {
+                const std::string pp = "embedding_layer.encoder.layer." + std::to_string(i - 1) + ".";
+                fold({&T_(ctx, M, p + "attention.self.query.weight"), &T_(ctx, M, p + "attention.self.key.weight"), &T_(ctx, M, p + "attention.self.value.weight")},
+                     {&T_(ctx, M, p + "attention.self.query.bias"), &T_(ctx, M, p + "attention.self.key.bias"), &T_(ctx, M, p + "attention.self.value.bias")},
+                     pp + "output.LayerNorm", L.qkv_f, L.qkv_s, L.qkv_t);
+            }
+        }
         h.bert.layers.push_back(L);
     }
     // Conv1d(k=1) weights (out,in,1) are linear layers over the token axis

@@ -139,3 +139,23 @@ def test_depth_layer12_runs_equal_the_launch_per_conv_form(env):
         err = np.abs(a[k] - b[k]).max()
         print(k, err)
         assert err <= (4e-3 if env["HCMT_DEPTH_HW"] == "256" else 0.0), (k, err)      # measured 2.1e-3 on the hidden state (five blocks; depth_l3_kernel: 1.4e-3)
+
+
+@pytest.mark.parametrize("env", [{"HCMT_L": "80"}, {"HCMT_L": "37"}, {"HCMT_L": "80", "HCM_LN_FOLD": "2"}, {"HCMT_L": "37", "HCM_LN_FOLD": "2"}])
+def test_layernorm_folded_into_the_gemms_equals_the_launches(env):
+    """Round 4: BERT's LayerNorms folded into the GEMMs around them (the consumer computes rstd * (u W'^T - mean * s) + t with the row statistics taken
+    inside its own K loop, the next residual add rebuilds LayerNorm(u) from them) against the LayerNorm launches (HCM_NO_LN_FOLD=1).  Exact algebra,
+    different rounding points (the LayerNorm output is no longer rounded to fp16 before the GEMM; gamma is rounded into the weights): equal to fp16
+    round-off of a 12-layer... here 1-layer encoder, not bit for bit.  HCM_LN_FOLD_MIN_ROWS=1: the fold is an engine-size decision and this engine is small."""
+    with tempfile.TemporaryDirectory() as d:
+        mode = env.get("HCM_LN_FOLD", "1")       # 1: row statistics inside the consumer's K loop; 2: from the producer's epilogue partials
+        base = {k: v for k, v in env.items() if k != "HCM_LN_FOLD"}
+        a = _run(dict(base, HCM_LN_FOLD=mode, HCM_LN_FOLD_MIN_ROWS="1"), os.path.join(d, "a.npz"))
+        b = _run(dict(base, HCM_LN_FOLD=mode, HCM_LN_FOLD_MIN_ROWS="1", HCM_NO_LN_FOLD="1"), os.path.join(d, "b.npz"))
+        c = _run(dict(base), os.path.join(d, "c.npz"))                   # the default: no fold
+    assert np.isfinite(a["rec"]).all()
+    for k in ("rec", "hh", "lh"):
+        err = np.abs(a[k] - b[k]).max()
+        print(k, err)
+        assert err <= 4e-3, (k, err)
+        assert np.array_equal(b[k], c[k]), k
