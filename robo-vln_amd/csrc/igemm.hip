@@ -1493,6 +1493,118 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         for (; kt + 1 < nk; ++kt) body(kt, std::false_type{}, std::true_type{});
         for (; kt < nk; ++kt) body(kt, std::false_type{}, std::false_type{});
     } else
+    if constexpr (ILV == 3) {
+        // ILV = 3 (round 4; deep ring, one workgroup per CU): the wave software-pipelines its fragment reads ACROSS the barrier.  ILV = 1 reads a tile's
+        // 2 x (TM + TN) fragments at the top of the iteration and every wave then sits in `lgkmcnt` with eight waves hammering the LDS before its first
+        // MFMA (~1330 cycles per 128 x 128 K tile for 544 of matrix work).  Here the K half computed next is always in registers: the first half's
+        // MFMAs run beside the reads of this tile's second half, the second half's beside the reads of the NEXT tile's first half -- which is why
+        // tile kt + 1 must be visible to everybody one barrier earlier than in ILV = 1 (the end-of-iteration wait asks for tile kt + 2: NBUF - 3
+        // tiles stay in flight across the barrier).  Same MFMA order per accumulator: bit-identical.
+        static_assert(NBUF >= 4, "the pipelined loop needs the deep ring");
+        constexpr int HM = TM * TN;                       // MFMAs per K half
+        constexpr int NRD = TM + TN;                      // fragment reads per K half
+        auto piece = [&](int i, unsigned sa2, unsigned sb2, int k, int kh, int kw, int ci) {
+            if (i < A_IT) {
+                const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+                const bool ok = (k < p.K) & (a_pix[i] >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = (unsigned)((a_pix[i] + iy * p.W + ix) * p.xC + ci) * (unsigned)sizeof(T);
+                dma16(sa2 + (wave + NW * i) * 1024, ok ? off : 0xFFFFFFFFu, rx);
+            } else {
+                const int ib = i - A_IT;
+                const int n = n0 + (wave + NW * ib) * 8 + rin;
+                const bool ok = (k < p.Kp) & (n < p.N);
+                const unsigned off = (unsigned)(n * p.Kp + k) * (unsigned)sizeof(T);
+                dma16(sb2 + (wave + NW * ib) * 1024, ok ? off : 0xFFFFFFFFu, rw);
+            }
+        };
+        uint4 xa[2][TM], wb[2][TN];
+        auto rd1 = [&](int f, int ks, int slot) {         // fragment f of a K half: f < TM token fragment, else weight fragment f - TM
+            const char* sa = smem + slot * TILE_BYTES;
+            const char* sb = sa + BM * 128;
+            const int chunk = ks * 4 + fg;
+            if (f < TM) {
+                const int r = wm * (BM / WMc) + f * 16 + fr;
+                xa[ks][f] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((chunk ^ (r & 7)) << 4));
+            } else {
+                const int r = wn * (BN / WNc) + (f - TM) * 16 + fr;
+                wb[ks][f - TM] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((chunk ^ (r & 7)) << 4));
+            }
+        };
+        // tile 1 must be visible as well before the first iteration's second half reads it
+        {
+            int staged = 1;
+            for (int t = 1; t < NBUF - 1; ++t) if (t < nk) ++staged;
+            wait_tiles(staged - 2 > 0 ? staged - 2 : 0);
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int f = 0; f < NRD; ++f) rd1(f, 0, 0);
+        auto body = [&](int kt, auto LIVE, auto NEXT) {
+            constexpr bool live = decltype(LIVE)::value;      // tile kt + NBUF - 1 exists: stage it
+            constexpr bool next = decltype(NEXT)::value;      // tile kt + 1 exists: read its first K half
+            const int slot_new = cur == 0 ? NBUF - 1 : cur - 1;
+            const int slot1 = cur == NBUF - 1 ? 0 : cur + 1;
+            const unsigned sa2 = lds_base + slot_new * TILE_BYTES, sb2 = sa2 + BM * 128;
+            const int k = (kt + NBUF - 1) * BK + c * CH;
+            int kh = 0, kw = 0, ci = k;
+            if (live && spatial) {
+                const int khw = k >> p.cin_shift;
+                ci = k & (p.Cin - 1);
+                kh = (khw * p.kw_rcp) >> 16;
+                kw = khw - kh * p.KW;
+            }
+            lap(1);
+            // ---- first half: K step 0 (set 0) beside the reads of K step 1 (set 1) of this tile, then the first DMA requests
+            int cnt = 0, pc = 0;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    Mma<T>::run(acc[i][j], wb[0][i], xa[0][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (cnt < NRD) rd1(cnt, 1, cur);
+                    else if (live && pc < LPT) { piece(pc, sa2, sb2, k, kh, kw, ci); ++pc; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++cnt;
+                }
+#pragma unroll
+            for (int f = cnt; f < NRD; ++f) rd1(f, 1, cur);       // (tiles with fewer MFMAs per half than fragments)
+            // ---- second half: K step 1 (set 1) beside the reads of the NEXT tile's K step 0 (set 0) and the remaining requests
+            cnt = 0;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    Mma<T>::run(acc[i][j], wb[1][i], xa[1][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (next && cnt < NRD) rd1(cnt, 0, slot1);
+                    else if (live && pc < LPT) { piece(pc, sa2, sb2, k, kh, kw, ci); ++pc; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++cnt;
+                }
+            if (next) {
+#pragma unroll
+                for (int f = cnt; f < NRD; ++f) rd1(f, 0, slot1);
+            }
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                    if (q >= pc) piece(q, sa2, sb2, k, kh, kw, ci);
+            }
+            lap(2);
+            // tile kt + 2 must have landed (it is read from the next iteration's second half on); younger tiles stay in flight
+            if (live) wait_vmcnt<(NBUF - 3) * LPT>(); else wait_tiles(nk - 3 - kt > 0 ? nk - 3 - kt : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lap(3);
+            __builtin_amdgcn_s_barrier();
+            lap(4);
+            cur = slot1;
+        };
+        int kt = 0;
+        for (; kt + (NBUF - 1) < nk; ++kt) body(kt, std::true_type{}, std::true_type{});
+        for (; kt + 1 < nk; ++kt) body(kt, std::false_type{}, std::true_type{});
+        for (; kt < nk; ++kt) body(kt, std::false_type{}, std::false_type{});
+    } else
     if constexpr (ILV == 1) {
         constexpr int NMMA = 2 * TM * TN;
         constexpr int GAP = NMMA / (LPT + 1) >= 1 ? NMMA / (LPT + 1) : 1;
@@ -2741,7 +2853,11 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         const void* fn;
         int threads;
         if constexpr (BN >= 64 && sizeof(T) == 2) {
-            fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6, 8, 2, false, 1>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4, 8, 2, false, 1>);
+            static const bool ilv3 = dev_env("HCM_DEEP_ILV3") != nullptr && atoi(dev_env("HCM_DEEP_ILV3")) != 0;
+            if (ilv3)
+                fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6, 8, 2, false, 3>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4, 8, 2, false, 3>);
+            else
+                fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6, 8, 2, false, 1>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4, 8, 2, false, 1>);
             threads = 512;
         } else {
             fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4>);

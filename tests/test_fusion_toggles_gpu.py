@@ -159,3 +159,15 @@ def test_layernorm_folded_into_the_gemms_equals_the_launches(env):
         print(k, err)
         assert err <= 4e-3, (k, err)
         assert np.array_equal(b[k], c[k]), k
+
+
+@pytest.mark.parametrize("env", [{}, {"HCMT_L": "37", "HCMT_RAGGED": "1"}, {"HCMT_DEPTH_HW": "256", "HCMT_L": "80"}])
+def test_deep_ring_pipelined_loop_equals_the_read_then_multiply_loop(env):
+    # round 4: the one-workgroup-per-CU launches (deep LDS ring) read the next K half's fragments beside the current half's MFMAs, across the
+    # barrier; same MFMA order per accumulator.  At this batch nearly every conv and linear of the step takes the deep ring.
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env, HCM_DEEP_ILV3="1"), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_DEEP_ILV3="0"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["rec"]).all()
