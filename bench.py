@@ -275,7 +275,7 @@ def build_act_workload(args, cfg_idx, rank, world, local_rank, strong_batch=0):
         eng = _StubEngine(cfg, rank, dev)                     # CPU plumbing test of the multi-rank command line only (tests/test_bench_cpu.py)
     else:
         eng = HCMEngine(cfg, hi_sd, None if hi_only else lo_sd, max_batch=max(B, strong_batch), precision=args.precision,
-                        graph=not args.no_graph and not hi_only)
+                        graph=not args.no_graph and not hi_only, chain_graphs={"auto": "auto", "0": False, "1": True}[args.chain_graphs])
     steppers = {}
 
     def make_step(Bx, stager_ok=False):
@@ -396,6 +396,10 @@ def main():
                                                                   "(BASELINE configs[2]: 512; 0 = skip)")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"],
                     help="fp16 = the measured 16-bit mode (range-calibrated fp16 tiles); bf16 = bf16 tiles in BERT / RGB trunks / cross-modal block")
+    ap.add_argument("--latency-leg", type=int, default=1, help="N = 1, configs[1]: also report the synchronous latency of a single-environment (B = 1) step, "
+                    "the reference's own evaluation loop, for both graph replay forms (0 = skip)")
+    ap.add_argument("--chain-graphs", choices=("auto", "0", "1"), default="0", help="engine option chain_graphs for the timed legs: one linear hipGraph per chain "
+                    "(lower host cost and B = 1 latency, 2-4 %% less pipelined throughput); default 0 = the single forked graph, the measured configuration")
     ap.add_argument("--bf16-leg", type=float, default=2.0, help="N = 1, configs[1], --precision fp16: seconds of an additional run of the SAME workload on a "
                                                                  "`precision=\"bf16\"` engine, reported as `bf16_mode` (0 = skip)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: the per-step all-gather through torch.distributed instead of the library's own "
@@ -622,6 +626,35 @@ def main():
         except Exception as e:           # never lose the headline number to the extra leg
             bf16_mode = {"error": str(e)}
 
+    # single-environment latency (N = 1 default run only): the reference's evaluation loop (hierarchical_trainer.py:1088-1107) calls the policy once per
+    # simulator step and needs the action before it can step the simulator, so what it sees is the SYNCHRONOUS latency of a B = 1 step, not a pipelined
+    # rate.  Both replay forms of the library: one hipGraph captured across the forked streams, and one linear graph per chain (HCM_ACT_CHAIN_GRAPHS).
+    single_env = None
+    if (world == 1 and args.config == 1 and args.precision == "fp16" and args.latency_leg and not STUB and not args.h2d and not args.reuse_instruction
+            and not args.batch and not args.total_batch and not args.no_graph):
+        try:
+            import copy
+            import torch
+            a3 = copy.copy(args)
+            a3.batch = 1
+            _, _, eng3, step3, _, _ = build_act_workload(a3, 1, rank, world, local_rank)
+            single_env = {"batch": 1, "steps": 200, "protocol": "act() + synchronise per step; host_us = time inside act() (argument marshalling + graph replay)"}
+            for name, mode in (("forked_graph", False), ("chain_graphs", True)):
+                eng3._chain_graphs = mode
+                for _ in range(20):
+                    step3()
+                _sync()
+                host, t0 = 0.0, time.perf_counter()
+                for _ in range(200):
+                    h0 = time.perf_counter()
+                    step3()
+                    host += time.perf_counter() - h0
+                    _sync()
+                single_env[name] = {"ms_per_step": round((time.perf_counter() - t0) / 200 * 1e3, 3), "host_us_per_step": round(host / 200 * 1e6, 1)}
+            eng3.close()
+        except Exception as e:           # never lose the headline number to the extra leg
+            single_env = {"error": str(e)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = global_B * args.steps / dt
@@ -655,6 +688,8 @@ def main():
             out["overlapped_all_gather"] = overlapped
         if bf16_mode:
             out["bf16_mode"] = bf16_mode
+        if single_env is not None:
+            out["single_env_latency"] = single_env
         if args.config == 3:
             gb = alg_bytes / 1e9
             # BASELINE.json calls this configuration memory-bound; at 16-bit MFMA rates it is not (0.25 GFLOP and 0.46 MB per sample = 540 FLOP/B,
@@ -704,7 +739,7 @@ def main():
         if args.config == 3:
             out["config"]["hipgraph"] = {"enabled": not args.no_graph, "inputs": "read in place from two alternating device buffer sets"}
         if hasattr(eng, "query"):
-            out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
+            out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "chain_graphs": args.chain_graphs, "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
         if not args.no_cpu_baseline and world == 1 and args.config == 1 and not STUB:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, *weights)
             if args.cpu_batches:

@@ -181,7 +181,14 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
  * B = 64 (29 MB of uint8 RGB + f32 depth per step, two boxes): 5.20-5.26 ms against 5.28-5.30 ms with the frames copied in front of the step
  * and 4.64 ms with resident frames -- on this runtime a graph's memcpy nodes overlap its kernels only marginally (eager launches with the
  * copy engine beside them reached 4.95-5.27 ms depending on the host). */
-enum hcm_act_flags { HCM_ACT_REUSE_INSTRUCTION = 1, HCM_ACT_HOST_FRAMES = 2 };
+/* HCM_ACT_CHAIN_GRAPHS (round 4): replay the step as four LINEAR hipGraphs (BERT, depth trunks, RGB trunks, tail), one per chain on the chain's own
+ * stream, stitched by events, instead of ONE graph captured across the forked streams.  hipGraphLaunch enqueues a forked graph node by node at ~2.1 us per
+ * node (0.5-0.8 ms of host time for the step's ~240 nodes, in capture order: at B = 1 the last chain starts 0.3 ms late), a single-stream graph at ~0.1 us per
+ * node.  With the flag the host cost of a step is ~0.18 ms and the synchronous latency of a B = 1 step drops by 7-25 % (box-dependent); the GPU runs the
+ * linear graphs' nodes slightly slower than the forked graph's, so PIPELINED throughput is 2-4 % lower -- a latency option for single-environment loops
+ * (hierarchical_trainer.py:1088-1107 calls the policy once per simulator step), not the measured configuration.  Results are bit-identical.  The side streams
+ * are picked by a one-time timing probe so that the chains' streams do not share a hardware queue.  Ignored together with HCM_ACT_HOST_FRAMES. */
+enum hcm_act_flags { HCM_ACT_REUSE_INSTRUCTION = 1, HCM_ACT_HOST_FRAMES = 2, HCM_ACT_CHAIN_GRAPHS = 4 };
 int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
                const int32_t* lengths, int B, int L,
                const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,

@@ -19,6 +19,7 @@ PRECISIONS = {"fp32": HCM_F32, "fp16": HCM_F16, "bf16": HCM_BF16}
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 HCM_ACT_REUSE_INSTRUCTION = 1
 HCM_ACT_HOST_FRAMES = 2
+HCM_ACT_CHAIN_GRAPHS = 4
 
 STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: KeyError, -4: ValueError, -5: RuntimeError, -6: ValueError,
               -7: MemoryError}

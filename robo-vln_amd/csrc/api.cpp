@@ -1,4 +1,5 @@
 // C ABI of libhcm (include/hcm.h).
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -44,17 +45,96 @@ static bool ids_dt_ok(int d);
 // all pointers, the stream); `run` enqueues the work on h->stream.  A key is run eagerly the first time it is seen (that also
 // performs the one-time kernel attribute setup) and captured -- forked side streams included -- the second time; later
 // calls replay the instantiated graph.
+static void destroy_entry(hcm_ctx::GraphEntry& g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& op : g.prog) if (op.exec) (void)hipGraphExecDestroy(op.exec);
+    g.exec = nullptr;
+    g.prog.clear();
+}
+
+// replay of a segmented entry: the step's top-level fork / chain launches / join, in the order the capture pass recorded them
+static hipError_t replay_segments(hcm_ctx* h, const hcm_ctx::GraphEntry& g) {
+    hipError_t e = hipSuccess;
+    unsigned used = 0;                                   // aux streams that received a launch since the fork
+    for (const auto& op : g.prog) {
+        if (op.kind == 0) {
+            if ((e = hipEventRecord(h->ev_fork, h->stream)) != hipSuccess) return e;
+            for (int i = 0; i < op.n; ++i) if ((e = hipStreamWaitEvent(g.aux[i], h->ev_fork, 0)) != hipSuccess) return e;
+            used = 0;
+        } else if (op.kind == 1) {
+            if ((e = hipGraphLaunch(op.exec, op.st)) != hipSuccess) return e;
+            for (int i = 0; i < 4; ++i) if (op.st == g.aux[i] && op.st != h->stream) used |= 1u << i;
+        } else {
+            for (int i = 0; i < op.n; ++i) {
+                if (!(used & (1u << i))) continue;       // nothing ran there: the fork's wait alone orders nothing anybody needs
+                if ((e = hipEventRecord(h->ev_join[i], g.aux[i])) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(h->stream, h->ev_join[i], 0)) != hipSuccess) return e;
+            }
+        }
+    }
+    return e;
+}
+
+// Pick the side streams of the step's chains so that aux[1] (depth), aux[2] (BERT) and the caller's stream overlap pairwise (model.h).  The probe: two 150 us
+// one-wave spin kernels, one per stream -- side by side they take 150 us, on a shared hardware queue 300.
+static void pick_chain_streams(hcm_ctx* h) {
+    if (h->probed && h->probed_for == h->stream) return;
+    h->probed = true;
+    h->probed_for = h->stream;
+    if (dev_env("HCM_NO_STREAM_PROBE")) return;
+    constexpr double kSpinUs = 150.0;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto overlap = [&](hipStream_t x, hipStream_t y) {
+        double best = 1e30;
+        for (int r = 0; r < 2; ++r) {
+            (void)hipStreamSynchronize(x); (void)hipStreamSynchronize(y);
+            const double t0 = now();
+            (void)launch_spin((unsigned long long)(kSpinUs * 100.0), x);
+            (void)launch_spin((unsigned long long)(kSpinUs * 100.0), y);
+            (void)hipStreamSynchronize(x); (void)hipStreamSynchronize(y);
+            const double dt = now() - t0;
+            if (dt < best) best = dt;
+        }
+        return best < 1.6 * kSpinUs;
+    };
+    std::vector<hipStream_t> cand;
+    for (int i = 0; i < 4; ++i) if (h->aux[i]) cand.push_back(h->aux[i]);
+    for (auto p : h->pool) if (p) cand.push_back(p);
+    (void)launch_spin(1, h->stream); (void)hipStreamSynchronize(h->stream);      // (code object loaded before anything is timed)
+    std::vector<hipStream_t> chosen;
+    for (auto c : cand) {
+        if (chosen.size() >= 2) break;
+        bool ok = overlap(h->stream, c);
+        for (auto k : chosen) ok = ok && overlap(k, c);
+        if (ok) chosen.push_back(c);
+    }
+    if (dev_env("HCM_PROBE_LOG")) fprintf(stderr, "[hcm] stream probe: %zu of %zu candidate streams overlap with the caller's stream and each other\n", chosen.size(), cand.size());
+    if (chosen.size() < 2) return;                                               // (a single hardware queue, or a probe disturbed by other work: keep what we have)
+    // aux[1] <- chosen[0], aux[2] <- chosen[1]; the displaced streams take the chosen ones' old places
+    auto place = [&](int slot, hipStream_t st) {
+        if (h->aux[slot] == st) return;
+        for (int i = 0; i < 4; ++i) if (h->aux[i] == st) { std::swap(h->aux[i], h->aux[slot]); return; }
+        for (auto& p : h->pool) if (p == st) { std::swap(p, h->aux[slot]); return; }
+    };
+    place(1, chosen[0]);
+    place(2, chosen[1]);
+}
+
 template <typename F>
-static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* stream, F run) {
+static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* stream, F run, bool segmented = false) {
     auto eager = [&]() -> int {
         try { run(); } catch (const std::exception& e) { return fail(h, HCM_ERR_HIP, e.what()); }
         ++h->eager_launches;
         return HCM_OK;
     };
+    if (segmented && stream != nullptr && !h->taps_on) pick_chain_streams(h);      // (once per caller stream; eager steps fork onto the same side streams)
     // the legacy default stream cannot be captured; taps allocate and synchronise
     if (!h->use_graph || h->taps_on || stream == nullptr) return eager();
     for (auto& g : h->graphs)
         if (g.key == key) {
+            if (!g.prog.empty()) {
+                if (replay_segments(h, g) != hipSuccess) return fail(h, HCM_ERR_HIP, "replay of the step's chain graphs failed");
+            } else
             if (hipGraphLaunch(g.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
             ++h->graph_launches;
             return HCM_OK;
@@ -65,6 +145,34 @@ static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* strea
         if (h->seen_keys.size() >= 16) h->seen_keys.erase(h->seen_keys.begin());
         h->seen_keys.push_back(key);
         return eager();
+    }
+    if (segmented) {
+        // one linear graph per chain (model.h, SegOp): the capture calls are made by the step itself at its chain boundaries
+        h->seg_mode = true;
+        h->seg_open = false;
+        h->seg_prog.clear();
+        std::string err;
+        try { run(); } catch (const std::exception& e) { err = e.what(); }
+        h->seg_mode = false;
+        if (h->seg_open) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(h->seg_stream, &g); if (g) (void)hipGraphDestroy(g); h->seg_open = false; }
+        hcm_ctx::GraphEntry ge;
+        ge.key = key;
+        ge.prog.swap(h->seg_prog);
+        for (int i = 0; i < 4; ++i) ge.aux[i] = h->aux[i];
+        bool any = false;
+        for (auto& op : ge.prog) any = any || op.kind == 1;
+        if (!err.empty() || !any) {
+            destroy_entry(ge);
+            (void)hipGetLastError();
+            h->use_graph = false;
+            if (!err.empty()) return fail(h, HCM_ERR_HIP, "graph capture failed: " + err);
+            return eager();
+        }
+        if (h->graphs.size() >= 8) { destroy_entry(h->graphs.front()); h->graphs.erase(h->graphs.begin()); }
+        h->graphs.push_back(ge);
+        if (replay_segments(h, h->graphs.back()) != hipSuccess) return fail(h, HCM_ERR_HIP, "replay of the step's chain graphs failed");
+        ++h->graph_launches;
+        return HCM_OK;
     }
     if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(); }
     std::string cap_err;
@@ -83,7 +191,7 @@ static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* strea
     ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ce != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return eager(); }
-    if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+    if (h->graphs.size() >= 8) { destroy_entry(h->graphs.front()); h->graphs.erase(h->graphs.begin()); }
     h->graphs.push_back(ge);
     if (hipGraphLaunch(ge.exec, h->stream) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipGraphLaunch failed");
     ++h->graph_launches;
@@ -414,7 +522,7 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     h->range_fold |= refold;
     (void)hipMemset(h->calib_buf + hcm_ctx::kStepBadWord, 0, 4);          // the overflow this forward ran into is being repaired: the step guard starts again
     h->fp16_fallback |= rebuild;
-    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);      // captured with the old weight pointers
+    for (auto& g : h->graphs) destroy_entry(g);                                   // captured with the old weight pointers
     h->graphs.clear();
     h->seen_keys.clear();
     try {
@@ -503,6 +611,8 @@ int hcm_finalize(hcm_handle h) {
         h->arena.dry = false;
         for (int i = 0; i < 4; ++i) {
             if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
+        for (auto& p : h->pool)
+            if (!p && hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         }
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
@@ -738,7 +848,11 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
     };
-    rc = run_graphed(h, key, stream, body);
+    // HCM_ACT_CHAIN_GRAPHS: one linear graph per chain (staged host frames keep the single forked graph: their copies are enqueued before the chains;
+    // so does the development build's HCM_RGB_SERIAL=0; HCM_SEG_GRAPH=1 / 0 of that build forces the choice for A/B runs)
+    static const bool seg_off = (dev_env("HCM_RGB_SERIAL") && atoi(dev_env("HCM_RGB_SERIAL")) == 0) || (dev_env("HCM_SEG_GRAPH") && atoi(dev_env("HCM_SEG_GRAPH")) == 0);
+    static const bool seg_on = dev_env("HCM_SEG_GRAPH") && atoi(dev_env("HCM_SEG_GRAPH")) != 0;
+    rc = run_graphed(h, key, stream, body, !host_frames && !seg_off && (seg_on || (flags & HCM_ACT_CHAIN_GRAPHS) != 0));
     h->reuse_instruction = false;
     h->host_frames = false;
     if (rc == HCM_OK) { h->last_hi_batch = B; h->last_hi_L = L; } else drop_instruction_cache(h);
@@ -845,9 +959,11 @@ void hcm_destroy(hcm_handle h) {
     if (h->guard_ev) (void)hipEventDestroy(h->guard_ev);
     if (h->guard_host) (void)hipHostFree(h->guard_host);
     for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
-    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : h->graphs) destroy_entry(g);
     for (int i = 0; i < 4; ++i) {
         if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+        if (h->pool[i]) (void)hipStreamDestroy(h->pool[i]);
+        if (h->pool[i + 4]) (void)hipStreamDestroy(h->pool[i + 4]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

@@ -1219,4 +1219,15 @@ hipError_t launch_mark(unsigned long long* slot, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Busy-wait for `ticks` of the 100 MHz wall clock on one wave: the stream-overlap probe of api.cpp (two streams that share a hardware queue run two of these
+// back to back, two that do not run them side by side).
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_spin(unsigned long long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+    return hipGetLastError();
+}
+
 }  // namespace hcm

@@ -396,6 +396,11 @@ struct Fwd {
             int fr[3], nf = 0;
             if (pre >= 0) fr[nf++] = pre;
             for (int i = 0; i < 4; ++i) if (i != xi && i != pre) fr[nf++] = i;
+            // A pending block input still needs its identity (xpend.res: the previous block's input or down-sample output) until THIS block's c1 has
+            // normalised it -- and that slot counts as free here.  c1 must not write its output there: the launch would read the identity rows of some
+            // pixels while other workgroups already store over them (round 4: 0.3-1 % of the steps of a 128-pixel configuration differed from run to
+            // run under the three-chain step; tools/r4_det.py).  c2 / c3 run behind c1 and may take it.
+            if (xpend.valid && xpend.res && slot[fr[0]] == xpend.res) std::swap(fr[0], fr[1]);
             void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
             const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
@@ -1360,17 +1365,45 @@ struct Fwd {
     // disjoint arena region; nothing is released until the step is fully enqueued.
     void fork_join_begin(int n_aux) {
         if (dry || n_aux == 0) return;
+        if (ctx->seg_mode && !ctx->seg_open) { hcm_ctx::SegOp op; op.kind = 0; op.n = n_aux; ctx->seg_prog.push_back(op); return; }
         ck(hipEventRecord(ctx->ev_fork, ctx->stream), "fork record");
         for (int i = 0; i < n_aux; ++i) ck(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0), "fork wait");
     }
     void fork_join_end(int n_aux) {
         if (dry || n_aux == 0) return;
+        if (ctx->seg_mode && !ctx->seg_open) { hcm_ctx::SegOp op; op.kind = 2; op.n = n_aux; ctx->seg_prog.push_back(op); return; }
         for (int i = 0; i < n_aux; ++i) {
             ck(hipEventRecord(ctx->ev_join[i], ctx->aux[i]), "join record");
             ck(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0), "join wait");
         }
     }
     void on(hipStream_t st) { s = st; }
+    // segmented capture (model.h, SegOp): everything a chain enqueues between chain_begin() and chain_end() becomes one graph captured on the
+    // chain's own stream; outside a segmented capture both are no-ops
+    void chain_begin() {
+        if (!ctx->seg_mode || dry) return;
+        ck(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "chain capture begin");
+        ctx->seg_open = true;
+        ctx->seg_stream = s;
+    }
+    void chain_end() {
+        if (!ctx->seg_mode || dry || !ctx->seg_open) return;
+        hipGraph_t g = nullptr;
+        ctx->seg_open = false;
+        ck(hipStreamEndCapture(ctx->seg_stream, &g), "chain capture end");
+        if (!g) return;                                   // (a chain that enqueued nothing, e.g. BERT with the instruction stream cached)
+        size_t nodes = 0;
+        hipError_t e = hipGraphGetNodes(g, nullptr, &nodes);
+        if (e == hipSuccess && nodes > 0) {
+            hcm_ctx::SegOp op;
+            op.kind = 1;
+            op.st = ctx->seg_stream;
+            e = hipGraphInstantiate(&op.exec, g, nullptr, nullptr, 0);
+            if (e == hipSuccess) ctx->seg_prog.push_back(op);
+        }
+        (void)hipGraphDestroy(g);
+        ck(e, "chain graph instantiate");
+    }
     // development aid: stamp the wall clock at this point of the current chain (no-op unless hcm_create saw HCM_MARKS=1 in a DEV build)
     void mark(const std::string& name) {
         if (!ctx->marks_dev || dry) return;
@@ -1411,12 +1444,15 @@ struct Fwd {
         // then the depth trunks) so they are not delayed by the ~2.5 us/launch it takes to enqueue the bulk RGB chains.
         // chain 3: BERT
         on(a2);
+        chain_begin();
         mark("bert.start");
         // (the workspace layout is identical from step to step, so hb.I / hb.Q of the previous step are still in place when the
         //  caller declares the instructions unchanged)
         if (do_hi && !(skip & 8) && !(ctx->reuse_instruction && !dry)) hi_bert(ids, ids_dt, B, hb);
+        chain_end();
         // chains 2 and 4: the two depth trunks (small, latency-bound kernels that fill the gaps of the RGB chains)
         on(a1);
+        chain_begin();
         mark("depth.start");
         const bool dshare = do_hi && do_lo && ctx->hi.depth_shared && !ctx->lo.depth_simple;
         const bool pair = do_hi && do_lo && ctx->hi.has_depth_pair && !ctx->lo.depth_simple;
@@ -1430,8 +1466,10 @@ struct Fwd {
         on(a1);
         if (do_lo && !pair && !dshare && !ctx->cfg.ablate_depth && !(skip & 4)) lo_depth(depth, B, lb);
         mark("depth.end");
+        chain_end();
         // chain 0 (caller's stream): the high-level RGB trunk (or the low-level one when it is the only model)
         on(main_s);
+        chain_begin();
         mark("rgb.start");
         const bool rshare = do_hi && do_lo && ctx->hi.rgb_shared && !ctx->lo.rgb_simple;
         const bool rpair = do_hi && do_lo && ctx->hi.has_rgb_pair && !ctx->lo.rgb_simple;
@@ -1445,7 +1483,9 @@ struct Fwd {
         if (do_hi && do_lo && !rpair && !rshare && !ctx->cfg.ablate_rgb && !(skip & 2)) lo_rgb(rgb, rgb_dt, B, lb);
         on(main_s);
         mark("rgb.end");
+        chain_end();
         if (multi) fork_join_end(4);
+        chain_begin();
         mark("tail.start");
         if (do_hi && do_lo && T == 1) { lo_early = &lb; lo_h_in_early = lo_h_in; }
         if (do_hi) hi_tail(B, hb, hi_h_in, mask, logits, ld_logits, hi_h_out);
@@ -1457,6 +1497,7 @@ struct Fwd {
         }
         if (do_lo) lo_tail(B, lb, lo_h_in, mask, st_ids, vel, ld_vel, stop, ld_stop, lo_h_out);
         mark("tail.end");
+        chain_end();
     }
 };
 

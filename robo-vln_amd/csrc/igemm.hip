@@ -1501,7 +1501,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_dma_kernel(IGemmDev p) {
         // tile kt + 1 must be visible to everybody one barrier earlier than in ILV = 1 (the end-of-iteration wait asks for tile kt + 2: NBUF - 3
         // tiles stay in flight across the barrier).  Same MFMA order per accumulator: bit-identical.
         static_assert(NBUF >= 4, "the pipelined loop needs the deep ring");
-        constexpr int HM = TM * TN;                       // MFMAs per K half
         constexpr int NRD = TM + TN;                      // fragment reads per K half
         auto piece = [&](int i, unsigned sa2, unsigned sb2, int k, int kh, int kw, int ci) {
             if (i < A_IT) {

@@ -146,6 +146,7 @@ hipError_t launch_bneck23(const Bneck23& b, int dt, hipStream_t s);
 // operands and caches the fastest (process-wide); hcm_finalize() runs one tuning step at max_batch.
 void igemm_set_tuning(bool on);
 size_t igemm_tuned_shapes();
+hipError_t launch_spin(unsigned long long ticks, hipStream_t s);
 hipError_t launch_mark(unsigned long long* slot, hipStream_t s);     // development aid: wall-clock stamp in stream order (HCM_MARKS=1)
 hipError_t igemm_prof_read(unsigned long long* host8, bool reset);   // HCM_IGEMM_PROF=1 phase counters
 

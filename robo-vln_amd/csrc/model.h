@@ -202,7 +202,21 @@ struct hcm_ctx {
     bool concurrent = true;
     // hipGraph cache of the fused step (hcm_act): keyed by (B, dtypes, every pointer argument).  A key is run eagerly the
     // first time it is seen and captured (all forked streams included) the second time; replays cost one graph launch.
-    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; };
+    // Round 4: the fused step is replayed as LINEAR graphs, one per chain, stitched by events outside the graphs.  hipGraphLaunch of a graph
+    // captured with forked streams costs the host ~2.1 us per node (0.7-0.8 ms for the step's ~240 nodes: at B = 1 the step was bounded by
+    // it and the RGB chain started 0.31 ms late); a graph captured on ONE stream goes down ROCm's batched-submission path at ~0.1 us per
+    // node (tools/native/graph_launch_mt.hip).  `prog` = the step's top-level structure as recorded during capture.
+    struct SegOp { int kind = 0; int n = 0; hipGraphExec_t exec = nullptr; hipStream_t st = nullptr; };   // kind 0 fork(n aux), 1 launch, 2 join(n aux)
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; std::vector<SegOp> prog; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; };
+    // Chains only overlap when their streams sit on different hardware queues (ROCm multiplexes streams onto a few; a linear graph is enqueued whole, so two
+    // chains on one queue run strictly one after the other).  `pool` = spare streams; before the first segmented capture on a caller stream the side streams
+    // are re-picked by a timing probe so that BERT's, the depth chain's and the caller's stream overlap pairwise (api.cpp, pick_chain_streams).
+    hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t probed_for = nullptr;
+    bool probed = false;
+    bool seg_mode = false, seg_open = false;        // segmented capture in progress / a chain's capture is open
+    hipStream_t seg_stream = nullptr;
+    std::vector<SegOp> seg_prog;
     std::vector<GraphEntry> graphs;
     std::vector<std::vector<uint64_t>> seen_keys;
     bool use_graph = true;

@@ -73,7 +73,7 @@ class HCMEngine:
 
     def __init__(self, cfg: HCMConfig, high_level_state_dict=None, low_level_state_dict=None, max_batch=64,
                  precision="fp16", device=None, sub_precision=None, graph=False, max_instr_len=None, keep_host_weights=False, guard_every=64,
-                 share_trunks=True):
+                 share_trunks=True, chain_graphs="auto"):
         """precision (fp32 accumulation, fp32 recurrent cells / heads in every mode):
           "fp16"  fp16 storage + fp16 MFMA tiles in every sub-network, behind the range calibration of hcm_finalize (the measured 16-bit mode:
                   record error 2.6e-3 at B = 64).  A trunk that leaves the fp16 range gets an exact power-of-two range fold (`range_fold`),
@@ -89,6 +89,10 @@ class HCMEngine:
         graph=True: act() runs on an engine-owned stream with engine-owned static I/O buffers, so that libhcm replays
         one captured hipGraph per step; the returned record / hidden tensors then alias those buffers and stay valid
         until the second-next act() call (ping-pong), which is what a rollout loop that rebinds them every step needs.
+        chain_graphs (with graph=True): replay the step as one LINEAR hipGraph per encoder chain instead of one graph captured across the forked
+        streams (HCM_ACT_CHAIN_GRAPHS, include/hcm.h): 0.18 ms of host time per step instead of 0.5-0.8 ms and a lower synchronous latency at B = 1,
+        2-4 % less pipelined throughput.  "auto" = for calls of one or two environments (the reference's own evaluation loop, one policy call per
+        simulator step); True / False force it.  Bit-identical either way.
         max_instr_len: the longest instruction (tokens) a call may carry; sizes the workspace.  Every call takes its own
         (B or 1, L <= max_instr_len) ids, as the reference model does (its eval loop feeds the unpadded tokens of the episode's
         instruction, common/utils.py:18-20).  Default: cfg.instr_len.  BERT's position table allows up to 512."""
@@ -97,6 +101,9 @@ class HCMEngine:
         # `fp16_fallback`); keep_host_weights=True keeps the f32 host copies so that `calibrate(observations)` can repeat the check -- and
         # the repair -- on real observations
         self._graph = bool(graph)
+        if chain_graphs not in ("auto", True, False):
+            raise ValueError('chain_graphs must be "auto", True or False')
+        self._chain_graphs = chain_graphs
         self.comm_world, self.comm_rank = 0, 0          # > 0 once comm_init() has created the RCCL communicator
         self._guard_every = int(guard_every)
         self._guard_tick = 0
@@ -456,6 +463,12 @@ class HCMEngine:
         if gather and not self.comm_world:
             raise RuntimeError("act(gather=True) needs comm_init() first")
         flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
+        if self._graph and not host_frames:
+            cg = self._chain_graphs
+            if cg == "auto":
+                cg = int(observations["rgb"].shape[0]) <= 2
+            if cg:
+                flags |= _lib.HCM_ACT_CHAIN_GRAPHS
         if self._graph:
             rec, hh2, lh2 = self._act_graph(observations, hi_hidden, lo_hidden, masks, flags, gather)
             if out is not None:

@@ -124,6 +124,81 @@ def test_rollout_with_cached_instructions_equals_recomputing():
     eng.close()
 
 
+@pytest.mark.parametrize("B", [1, 3])
+@pytest.mark.parametrize("reuse", [False, True])
+def test_chain_graphs_equal_the_forked_graph(B, reuse):
+    """HCM_ACT_CHAIN_GRAPHS: the step replayed as one linear hipGraph per encoder chain (stitched by events outside the graphs) gives the bits of the
+    single graph captured across the forked streams and of eager launches -- over several steps whose frames change in place (so the replays read new
+    data and the recurrent state threads through), also with the instruction stream cached (the BERT chain's graph is then empty), and at the batch
+    of one where chain_graphs="auto" switches it on."""
+    from robo_vln_amd import _lib
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
+    T = 6
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=7)
+    engs = [HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True, chain_graphs=True),
+            HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True, chain_graphs=False),
+            HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=False),
+            HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True)]          # "auto"
+    frames = [synth.make_observations(cfg, B, step=t, seed=7) for t in range(T)]
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in frames[0].items()}
+    R = cfg.num_recurrent_layers
+    state = [(torch.zeros(R, B, cfg.hidden, device="cuda"), torch.zeros(R, B, cfg.hidden, device="cuda")) for _ in engs]
+    m = torch.ones(B, device="cuda")
+    for t in range(T):
+        obs["rgb"].copy_(torch.from_numpy(frames[t]["rgb"]).cuda())
+        obs["depth"].copy_(torch.from_numpy(frames[t]["depth"]).cuda())
+        outs = []
+        for i, e in enumerate(engs):
+            r, hh, lh = e.act(obs, state[i][0], state[i][1], m, reuse_instruction=reuse and t > 0)
+            r, hh, lh = r.clone(), hh.clone(), lh.clone()
+            state[i] = (hh, lh)
+            outs.append((r, hh, lh))
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), t
+        assert torch.isfinite(outs[0][0]).all()
+    assert engs[0].query(_lib.HCM_GRAPH_LAUNCHES) >= 2 and engs[1].query(_lib.HCM_GRAPH_LAUNCHES) >= 2
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.parametrize("depth_hw", [128, 192])
+def test_three_chain_step_is_deterministic(depth_hw):
+    """Race screen (round 4): every replay form runs every step TWICE from the same inputs and must agree with itself and with the others, 300 steps of
+    changing frames at frame sizes whose depth trunk takes the generic bottleneck path.  GroupNorm on load once let a block's first conv write its
+    output over the identity rows the same launch was still reading (a slot counted as free while a pending record needed it): 0.3-1 % of the steps
+    differed from run to run -- only with the other chains competing for the chip, which no single-kernel test sees (tools/step_determinism.py)."""
+    from robo_vln_amd.policy import HCMEngine
+    cfg = HCMConfig(rgb_hw=128, depth_hw=depth_hw, instr_len=20, bert_layers=2).validate()
+    B, T = 3, 300
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=7)
+    engs = [HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True, chain_graphs=True),
+            HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=True, chain_graphs=False),
+            HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=False)]
+    frames = [synth.make_observations(cfg, B, step=t, seed=7) for t in range(6)]
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in frames[0].items()}
+    R = cfg.num_recurrent_layers
+    hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+    m = torch.ones(B, device="cuda")
+    bad = 0
+    for t in range(T):
+        obs["rgb"].copy_(torch.from_numpy(frames[t % 6]["rgb"]).cuda())
+        obs["depth"].copy_(torch.from_numpy(frames[t % 6]["depth"]).cuda())
+        torch.cuda.synchronize()
+        runs = []
+        for e in engs:
+            for _ in range(2):
+                r, h2, l2 = e.act(obs, hh, lh, m)
+                runs.append((r.clone(), h2.clone(), l2.clone()))
+                torch.cuda.synchronize()
+        bad += sum(not all(torch.equal(a, b) for a, b in zip(runs[0], o)) for o in runs[1:])
+        hh, lh = runs[0][1], runs[0][2]
+    for e in engs:
+        e.close()
+    assert bad == 0, f"{bad} of {5 * T} repeated steps differed"
+
+
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("rgb_uint8", [True, False])
 def test_host_frames_equal_device_frames(graph, rgb_uint8):

@@ -11,8 +11,8 @@ from robo_vln_amd.policy import HCMEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cfg = HCMConfig().validate()
 hi, lo = synth.make_weights(cfg, seed=0)
-for graph in (True, False):
-    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", graph=graph)
+for graph, chain in ((True, False), (True, True), (False, False)):
+    eng = HCMEngine(cfg, hi, lo, max_batch=B, precision="fp16", graph=graph, chain_graphs=chain)
     obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=0, rgb_uint8=True).items()}
     R = cfg.num_recurrent_layers
     hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda")
@@ -33,8 +33,8 @@ for graph in (True, False):
         rec, hh, lh = eng.act(obs, hh, lh, m)
     torch.cuda.synchronize()
     pipe = (time.perf_counter() - t0) / n
-    print(f"B={B} graph={graph}: synchronised per step {wall * 1e3:.3f} ms (host enqueue {host / n * 1e6:.0f} us), back-to-back {pipe * 1e3:.3f} ms per step")
-    if graph:
+    print(f"B={B} graph={graph} chain_graphs={chain}: synchronised per step {wall * 1e3:.3f} ms (host enqueue {host / n * 1e6:.0f} us), back-to-back {pipe * 1e3:.3f} ms per step")
+    if graph and not chain:
         pr = cProfile.Profile(); pr.enable()
         for _ in range(200):
             rec, hh, lh = eng.act(obs, hh, lh, m)

@@ -5,8 +5,8 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/$1; mkdir -p $OUT; cd $REPO
 VAR=$2; N=${3:-3}; shift 3 || true
 export HCM_DEV_LIB=1
 for i in $(seq 1 $N); do
-  timeout 300 python bench.py --steps 40 --warmup 5 --sustain 0 --no-cpu-baseline --bf16-leg 0 --no-kernel-probe "$@" > $OUT/base_$i.json 2> $OUT/base_$i.err
-  env $VAR timeout 300 python bench.py --steps 40 --warmup 5 --sustain 0 --no-cpu-baseline --bf16-leg 0 --no-kernel-probe "$@" > $OUT/alt_$i.json 2> $OUT/alt_$i.err
+  timeout 300 python bench.py --steps 40 --warmup 5 --sustain 0 --no-cpu-baseline --bf16-leg 0 --latency-leg 0 --no-kernel-probe "$@" > $OUT/base_$i.json 2> $OUT/base_$i.err
+  env $VAR timeout 300 python bench.py --steps 40 --warmup 5 --sustain 0 --no-cpu-baseline --bf16-leg 0 --latency-leg 0 --no-kernel-probe "$@" > $OUT/alt_$i.json 2> $OUT/alt_$i.err
 done
 python - <<PY
 import json, glob
