@@ -611,10 +611,10 @@ int hcm_finalize(hcm_handle h) {
         h->arena.dry = false;
         for (int i = 0; i < 4; ++i) {
             if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
-        for (auto& p : h->pool)
-            if (!p && hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         }
+        for (auto& p : h->pool)
+            if (hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         if (const char* e = getenv("HCM_SERIAL")) h->concurrent = atoi(e) == 0;
         if (const char* e = getenv("HCM_GRAPH")) h->use_graph = atoi(e) != 0;

@@ -2852,7 +2852,9 @@ static hipError_t launch_cfg(IGemmDev d, int variant, hipStream_t s) {
         const void* fn;
         int threads;
         if constexpr (BN >= 64 && sizeof(T) == 2) {
-            static const bool ilv3 = dev_env("HCM_DEEP_ILV3") != nullptr && atoi(dev_env("HCM_DEEP_ILV3")) != 0;
+            // the pipelined loop (ILV = 3, fragment reads of the next K half beside the current half's MFMAs) is the default; HCM_DEEP_ILV3=0 of the
+            // development build selects the read-then-multiply loop (ILV = 1) for the toggle test
+            static const bool ilv3 = !(dev_env("HCM_DEEP_ILV3") != nullptr && atoi(dev_env("HCM_DEEP_ILV3")) == 0);
             if (ilv3)
                 fn = nb == ND6 ? reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, ND6, 8, 2, false, 3>) : reinterpret_cast<const void*>(igemm_dma_kernel<T, BM, BN, 4, 8, 2, false, 3>);
             else
