@@ -398,8 +398,9 @@ def main():
                     help="fp16 = the measured 16-bit mode (range-calibrated fp16 tiles); bf16 = bf16 tiles in BERT / RGB trunks / cross-modal block")
     ap.add_argument("--latency-leg", type=int, default=1, help="N = 1, configs[1]: also report the synchronous latency of a single-environment (B = 1) step, "
                     "the reference's own evaluation loop, for both graph replay forms (0 = skip)")
-    ap.add_argument("--chain-graphs", choices=("auto", "0", "1"), default="0", help="engine option chain_graphs for the timed legs: one linear hipGraph per chain "
-                    "(lower host cost and B = 1 latency, 2-4 %% less pipelined throughput); default 0 = the single forked graph, the measured configuration")
+    ap.add_argument("--chain-graphs", choices=("auto", "0", "1"), default=None, help="engine option chain_graphs for the timed legs: one linear hipGraph per chain "
+                    "(lower host cost and B = 1 latency, 2-4 %% less pipelined throughput); default 0 = the single forked graph, the measured configuration -- "
+                    "except with --h2d, where the default is the engine's own choice (auto: the frame copies overlap BERT in that form)")
     ap.add_argument("--bf16-leg", type=float, default=2.0, help="N = 1, configs[1], --precision fp16: seconds of an additional run of the SAME workload on a "
                                                                  "`precision=\"bf16\"` engine, reported as `bf16_mode` (0 = skip)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: the per-step all-gather through torch.distributed instead of the library's own "
@@ -415,6 +416,8 @@ def main():
                     "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
+    if args.chain_graphs is None:
+        args.chain_graphs = "auto" if args.h2d else "0"
     if args.gpus > 1 and "RANK" not in os.environ:
         if args.config != 1:
             raise SystemExit("--config 0/3/4 are single-GPU roofline lines; the multi-GPU workload is configs[1]/[2]")

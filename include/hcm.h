@@ -187,7 +187,9 @@ int hcm_act(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
  * node.  With the flag the host cost of a step is ~0.18 ms and the synchronous latency of a B = 1 step drops by 7-25 % (box-dependent); the GPU runs the
  * linear graphs' nodes slightly slower than the forked graph's, so PIPELINED throughput is 2-4 % lower -- a latency option for single-environment loops
  * (hierarchical_trainer.py:1088-1107 calls the policy once per simulator step), not the measured configuration.  Results are bit-identical.  The side streams
- * are picked by a one-time timing probe so that the chains' streams do not share a hardware queue.  Ignored together with HCM_ACT_HOST_FRAMES. */
+ * are picked by a one-time timing probe so that the chains' streams do not share a hardware queue.  Together with HCM_ACT_HOST_FRAMES the replay enqueues the
+ * two frame copies itself, outside the graphs, at the head of their chains' streams: they then run beside BERT (B = 64, PCIe-inclusive: 4.87 -> 4.40 ms per step;
+ * a gain from ~4 MB per frame tensor up -- smaller pinned copies are carried out by the calling thread behind the stream's earlier work). */
 enum hcm_act_flags { HCM_ACT_REUSE_INSTRUCTION = 1, HCM_ACT_HOST_FRAMES = 2, HCM_ACT_CHAIN_GRAPHS = 4 };
 int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype,
                const int32_t* lengths, int B, int L,

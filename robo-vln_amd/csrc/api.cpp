@@ -61,8 +61,10 @@ static hipError_t replay_segments(hcm_ctx* h, const hcm_ctx::GraphEntry& g) {
             if ((e = hipEventRecord(h->ev_fork, h->stream)) != hipSuccess) return e;
             for (int i = 0; i < op.n; ++i) if ((e = hipStreamWaitEvent(g.aux[i], h->ev_fork, 0)) != hipSuccess) return e;
             used = 0;
-        } else if (op.kind == 1) {
-            if ((e = hipGraphLaunch(op.exec, op.st)) != hipSuccess) return e;
+        } else if (op.kind == 1 || op.kind == 3) {
+            if (op.kind == 1) e = hipGraphLaunch(op.exec, op.st);
+            else e = hipMemcpyAsync(op.dst, op.src, op.bytes, hipMemcpyHostToDevice, op.st);
+            if (e != hipSuccess) return e;
             for (int i = 0; i < 4; ++i) if (op.st == g.aux[i] && op.st != h->stream) used |= 1u << i;
         } else {
             for (int i = 0; i < op.n; ++i) {
@@ -848,11 +850,11 @@ int hcm_act_ex(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth,
         run_step(h, true, true, rgb, rgb_dtype, depth, ids, ids_dtype, B, hi_h_in, lo_h_in, mask, nullptr, record, ld, record + 4, ld,
                  record + 6, ld, hi_h_out, lo_h_out);
     };
-    // HCM_ACT_CHAIN_GRAPHS: one linear graph per chain (staged host frames keep the single forked graph: their copies are enqueued before the chains;
-    // so does the development build's HCM_RGB_SERIAL=0; HCM_SEG_GRAPH=1 / 0 of that build forces the choice for A/B runs)
+    // HCM_ACT_CHAIN_GRAPHS: one linear graph per chain (the development build's HCM_RGB_SERIAL=0 keeps the single forked graph; HCM_SEG_GRAPH=1 / 0 of that
+    // build forces the choice for A/B runs)
     static const bool seg_off = (dev_env("HCM_RGB_SERIAL") && atoi(dev_env("HCM_RGB_SERIAL")) == 0) || (dev_env("HCM_SEG_GRAPH") && atoi(dev_env("HCM_SEG_GRAPH")) == 0);
     static const bool seg_on = dev_env("HCM_SEG_GRAPH") && atoi(dev_env("HCM_SEG_GRAPH")) != 0;
-    rc = run_graphed(h, key, stream, body, !host_frames && !seg_off && (seg_on || (flags & HCM_ACT_CHAIN_GRAPHS) != 0));
+    rc = run_graphed(h, key, stream, body, !seg_off && (seg_on || (flags & HCM_ACT_CHAIN_GRAPHS) != 0));
     h->reuse_instruction = false;
     h->host_frames = false;
     if (rc == HCM_OK) { h->last_hi_batch = B; h->last_hi_L = L; } else drop_instruction_cache(h);

@@ -1435,8 +1435,19 @@ struct Fwd {
             // chain's compute run beside the copies.  The RGB frames go FIRST: the copy engine works in submission order and the RGB trunks are
             // the long chain (the depth chain's kernels fill gaps, they can start 0.3 ms later)
             const size_t n_rgb = (size_t)B * ctx->cfg.rgb_h * ctx->cfg.rgb_w * 3 * (rgb_dt == DT_U8 ? 1 : 4), n_dep = (size_t)B * ctx->cfg.depth_h * ctx->cfg.depth_w * 4;
+            if (ctx->seg_mode) {
+                // per-chain linear graphs: the copies are enqueued by the replay itself, OUTSIDE the graphs, at the head of their chains' streams --
+                // both are in the copy engines' queues a few microseconds after the call, with BERT running beside them
+                hcm_ctx::SegOp c0, c1;
+                c0.kind = c1.kind = 3;
+                c0.st = main_s; c0.dst = ctx->stage_rgb; c0.src = rgb; c0.bytes = n_rgb;
+                c1.st = a1; c1.dst = ctx->stage_depth; c1.src = depth; c1.bytes = n_dep;
+                ctx->seg_prog.push_back(c0);
+                ctx->seg_prog.push_back(c1);
+            } else {
             ck(hipMemcpyAsync(ctx->stage_rgb, rgb, n_rgb, hipMemcpyHostToDevice, main_s), "rgb frames H2D");
             ck(hipMemcpyAsync(ctx->stage_depth, depth, n_dep, hipMemcpyHostToDevice, a1), "depth frames H2D");
+            }
             rgb = ctx->stage_rgb;
             depth = ctx->stage_depth;
         }

@@ -206,7 +206,10 @@ struct hcm_ctx {
     // captured with forked streams costs the host ~2.1 us per node (0.7-0.8 ms for the step's ~240 nodes: at B = 1 the step was bounded by
     // it and the RGB chain started 0.31 ms late); a graph captured on ONE stream goes down ROCm's batched-submission path at ~0.1 us per
     // node (tools/native/graph_launch_mt.hip).  `prog` = the step's top-level structure as recorded during capture.
-    struct SegOp { int kind = 0; int n = 0; hipGraphExec_t exec = nullptr; hipStream_t st = nullptr; };   // kind 0 fork(n aux), 1 launch, 2 join(n aux)
+    struct SegOp {                                   // kind 0 fork(n aux), 1 launch exec on st, 2 join(n aux), 3 host -> device copy on st (staged host frames)
+        int kind = 0; int n = 0; hipGraphExec_t exec = nullptr; hipStream_t st = nullptr;
+        void* dst = nullptr; const void* src = nullptr; size_t bytes = 0;
+    };
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; std::vector<SegOp> prog; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; };
     // Chains only overlap when their streams sit on different hardware queues (ROCm multiplexes streams onto a few; a linear graph is enqueued whole, so two
     // chains on one queue run strictly one after the other).  `pool` = spare streams; before the first segmented capture on a caller stream the side streams

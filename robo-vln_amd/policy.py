@@ -92,7 +92,8 @@ class HCMEngine:
         chain_graphs (with graph=True): replay the step as one LINEAR hipGraph per encoder chain instead of one graph captured across the forked
         streams (HCM_ACT_CHAIN_GRAPHS, include/hcm.h): 0.18 ms of host time per step instead of 0.5-0.8 ms and a lower synchronous latency at B = 1,
         2-4 % less pipelined throughput.  "auto" = for calls of one or two environments (the reference's own evaluation loop, one policy call per
-        simulator step); True / False force it.  Bit-identical either way.
+        simulator step), and for host_frames=True calls whose frame tensors are at least 4 MB each (the copies then overlap BERT: +5-12 % PCIe-inclusive
+        throughput from B = 24 up); True / False force it.  Bit-identical either way.
         max_instr_len: the longest instruction (tokens) a call may carry; sizes the workspace.  Every call takes its own
         (B or 1, L <= max_instr_len) ids, as the reference model does (its eval loop feeds the unpadded tokens of the episode's
         instruction, common/utils.py:18-20).  Default: cfg.instr_len.  BERT's position table allows up to 512."""
@@ -463,10 +464,16 @@ class HCMEngine:
         if gather and not self.comm_world:
             raise RuntimeError("act(gather=True) needs comm_init() first")
         flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
-        if self._graph and not host_frames:
+        if self._graph:
             cg = self._chain_graphs
             if cg == "auto":
-                cg = int(observations["rgb"].shape[0]) <= 2
+                if host_frames:
+                    # the replay enqueues the two frame copies itself, at once and outside the graphs, so they run beside BERT (B = 64: 4.87 -> 4.40 ms
+                    # PCIe-inclusive); below ~4 MB a pinned host -> device copy is carried out by the calling thread behind the stream's earlier work
+                    cg = min(observations["rgb"].numel() * observations["rgb"].element_size(),
+                             observations["depth"].numel() * observations["depth"].element_size()) >= (4 << 20)
+                else:
+                    cg = int(observations["rgb"].shape[0]) <= 2
             if cg:
                 flags |= _lib.HCM_ACT_CHAIN_GRAPHS
         if self._graph:

@@ -199,7 +199,7 @@ def test_three_chain_step_is_deterministic(depth_hw):
     assert bad == 0, f"{bad} of {5 * T} repeated steps differed"
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "chain"])
 @pytest.mark.parametrize("rgb_uint8", [True, False])
 def test_host_frames_equal_device_frames(graph, rgb_uint8):
     """HCM_ACT_HOST_FRAMES: pinned host frames handed to the library (one host->device copy per encoder chain, inside the captured step)
@@ -210,8 +210,9 @@ def test_host_frames_equal_device_frames(graph, rgb_uint8):
     cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
     B, T = 3, 6
     hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
-    eng_d = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
-    eng_h = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=graph)
+    # ("chain": per-chain linear graphs, where the replay enqueues the copies itself, outside the graphs, at the head of the chains' streams)
+    eng_d = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=bool(graph), chain_graphs=graph == "chain")
+    eng_h = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=bool(graph), chain_graphs=graph == "chain")
     frames = [synth.make_observations(cfg, B, step=t, seed=5, rgb_uint8=rgb_uint8) for t in range(T)]
     host = {"rgb": torch.empty(B, 128, 128, 3, dtype=torch.uint8 if rgb_uint8 else torch.float32).pin_memory(),
             "depth": torch.empty(B, 128, 128, 1).pin_memory()}
