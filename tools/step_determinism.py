@@ -1,5 +1,5 @@
 """Which replay form is flaky?  Every engine runs every step TWICE from the same inputs; counts steps where an engine disagrees with itself and where
-the forms disagree with each other.  usage: r4_det.py [B] [steps]   env R4_MODES=forked,eager[,chain]"""
+the forms disagree with each other.  usage: step_determinism.py [B] [steps]   env R4_MODES=forked,eager[,chain] R4_FULL=1 R4_DEPTH_HW=<n>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,9 @@ from robo_vln_amd.config import HCMConfig
 from robo_vln_amd.policy import HCMEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=2).validate()
+# R4_FULL=1: BASELINE configs[1] (256-pixel frames, L = 80, 12 BERT layers) instead of the small configuration; R4_DEPTH_HW=<n>: depth frame size
+cfg = (HCMConfig() if os.environ.get("R4_FULL") else
+       HCMConfig(rgb_hw=128, depth_hw=int(os.environ.get("R4_DEPTH_HW", "128")), instr_len=20, bert_layers=2)).validate()
 hi, lo = synth.make_weights(cfg, seed=7)
 modes = {"chain": dict(graph=True, chain_graphs=True), "forked": dict(graph=True, chain_graphs=False), "eager": dict(graph=False)}
 want = os.environ.get("R4_MODES", "forked,eager").split(",")
