@@ -41,10 +41,6 @@ static void drop_instruction_cache(hcm_ctx* h);
 static bool rgb_dt_ok(int d);
 static bool ids_dt_ok(int d);
 
-// hipGraph cache shared by the fused entry points: `key` = every argument that the enqueued work depends on (batch, dtypes,
-// all pointers, the stream); `run` enqueues the work on h->stream.  A key is run eagerly the first time it is seen (that also
-// performs the one-time kernel attribute setup) and captured -- forked side streams included -- the second time; later
-// calls replay the instantiated graph.
 static void destroy_entry(hcm_ctx::GraphEntry& g) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& op : g.prog) if (op.exec) (void)hipGraphExecDestroy(op.exec);
@@ -80,9 +76,9 @@ static hipError_t replay_segments(hcm_ctx* h, const hcm_ctx::GraphEntry& g) {
 // Pick the side streams of the step's chains so that aux[1] (depth), aux[2] (BERT) and the caller's stream overlap pairwise (model.h).  The probe: two 150 us
 // one-wave spin kernels, one per stream -- side by side they take 150 us, on a shared hardware queue 300.
 static void pick_chain_streams(hcm_ctx* h) {
-    if (h->probed && h->probed_for == h->stream) return;
-    h->probed = true;
-    h->probed_for = h->stream;
+    for (auto st : h->probed_for) if (st == h->stream) return;                    // (a caller that alternates between streams is probed once per stream)
+    if (h->probed_for.size() >= 8) return;
+    h->probed_for.push_back(h->stream);
     if (dev_env("HCM_NO_STREAM_PROBE")) return;
     constexpr double kSpinUs = 150.0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -122,6 +118,11 @@ static void pick_chain_streams(hcm_ctx* h) {
     place(2, chosen[1]);
 }
 
+// hipGraph cache shared by the fused entry points: `key` = every argument that the enqueued work depends on (batch, dtypes,
+// all pointers, the stream); `run` enqueues the work on h->stream.  A key is run eagerly the first time it is seen (that also
+// performs the one-time kernel attribute setup) and captured -- forked side streams included -- the second time; later
+// calls replay the instantiated graph.
+// segmented = HCM_ACT_CHAIN_GRAPHS: one linear graph per chain, captured by the step itself at its chain boundaries (model.h, SegOp).
 template <typename F>
 static int run_graphed(hcm_ctx* h, const std::vector<uint64_t>& key, void* stream, F run, bool segmented = false) {
     auto eager = [&]() -> int {

@@ -215,8 +215,7 @@ struct hcm_ctx {
     // chains on one queue run strictly one after the other).  `pool` = spare streams; before the first segmented capture on a caller stream the side streams
     // are re-picked by a timing probe so that BERT's, the depth chain's and the caller's stream overlap pairwise (api.cpp, pick_chain_streams).
     hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t probed_for = nullptr;
-    bool probed = false;
+    std::vector<hipStream_t> probed_for;
     bool seg_mode = false, seg_open = false;        // segmented capture in progress / a chain's capture is open
     hipStream_t seg_stream = nullptr;
     std::vector<SegOp> seg_prog;
