@@ -9,6 +9,7 @@ from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig
 from robo_vln_amd.policy import HCMEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+REUSE = bool(int(os.environ.get("REUSE", "0")))      # REUSE=1: the instruction stream cached after the first step (HCM_ACT_REUSE_INSTRUCTION, opt-in)
 cfg = HCMConfig().validate()
 hi, lo = synth.make_weights(cfg, seed=0)
 for graph, chain in ((True, False), (True, True), (False, False)):
@@ -17,27 +18,29 @@ for graph, chain in ((True, False), (True, True), (False, False)):
     R = cfg.num_recurrent_layers
     hh = torch.zeros(R, B, cfg.hidden, device="cuda"); lh = torch.zeros(R, B, cfg.hidden, device="cuda")
     m = torch.ones(B, device="cuda")
+    eng._stepped = False
     for _ in range(10):
-        rec, hh, lh = eng.act(obs, hh, lh, m)
+        rec, hh, lh = eng.act(obs, hh, lh, m, reuse_instruction=REUSE and eng._stepped)
+        eng._stepped = True
     torch.cuda.synchronize()
     n = 200
     t0 = time.perf_counter(); host = 0.0
     for _ in range(n):
         h0 = time.perf_counter()
-        rec, hh, lh = eng.act(obs, hh, lh, m)
+        rec, hh, lh = eng.act(obs, hh, lh, m, reuse_instruction=REUSE and eng._stepped)
         host += time.perf_counter() - h0
         torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n
     t0 = time.perf_counter()
     for _ in range(n):
-        rec, hh, lh = eng.act(obs, hh, lh, m)
+        rec, hh, lh = eng.act(obs, hh, lh, m, reuse_instruction=REUSE and eng._stepped)
     torch.cuda.synchronize()
     pipe = (time.perf_counter() - t0) / n
     print(f"B={B} graph={graph} chain_graphs={chain}: synchronised per step {wall * 1e3:.3f} ms (host enqueue {host / n * 1e6:.0f} us), back-to-back {pipe * 1e3:.3f} ms per step")
     if graph and not chain:
         pr = cProfile.Profile(); pr.enable()
         for _ in range(200):
-            rec, hh, lh = eng.act(obs, hh, lh, m)
+            rec, hh, lh = eng.act(obs, hh, lh, m, reuse_instruction=REUSE and eng._stepped)
         pr.disable(); torch.cuda.synchronize()
         st = pstats.Stats(pr); st.sort_stats("cumulative"); st.print_stats(18)
     eng.close()
