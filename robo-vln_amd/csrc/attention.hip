@@ -132,7 +132,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
 }
 
 template <typename T, int MAXKT>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+__global__ __launch_bounds__(512) void attention_mfma_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                              T* __restrict__ out, int heads, int Lq, int Lk0, int ldq, int ldk,
                                                              int ldv, int ldo, int q_batch_mod, const int* __restrict__ klens) {
     int Lk = Lk0;                             // keys this sample attends over (uniform per workgroup); rows keep the stride Lk0
@@ -153,7 +153,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
     const int wave = tid >> 6;
 
     // stage K (swizzled rows) and V^T; rows >= Lk are zero
-    for (int e = tid; e < Lkp * 8; e += 256) {
+    // the first query tile's fragments are requested BEFORE the K / V staging: their round trip runs beside it instead of behind the barrier
+    const int fr = lane & 15, fg = lane >> 4;
+    const int QT = (Lq + 15) / 16;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (wave < QT) {
+        int qrow = wave * 16 + fr;
+        if (qrow >= Lq) qrow = Lq - 1;
+        const T* qp = q + ((size_t)bq * Lq + qrow) * ldq + h * D;
+        q0 = *reinterpret_cast<const uint4*>(qp + fg * 8);
+        q1 = *reinterpret_cast<const uint4*>(qp + 32 + fg * 8);
+    }
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;   // one wave per 16-query tile up to eight (round 4: L = 80 is five tiles -- four waves left three idle for half the kernel)
+    for (int e = tid; e < Lkp * 8; e += nthreads) {
         const int row = e >> 3, c = e & 7;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (row < Lk) {
@@ -171,15 +183,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
     }
     __syncthreads();
 
-    const int fr = lane & 15, fg = lane >> 4;
-    const int QT = (Lq + 15) / 16;
-    for (int qt = wave; qt < QT; qt += 4) {
+    for (int qt = wave; qt < QT; qt += nwaves) {
         // B operand: Q rows of this tile (clamped: rows past Lq compute garbage that is never stored)
-        int qrow = qt * 16 + fr;
-        if (qrow >= Lq) qrow = Lq - 1;
-        const T* qp = q + ((size_t)bq * Lq + qrow) * ldq + h * D;
-        const uint4 q0 = *reinterpret_cast<const uint4*>(qp + fg * 8);
-        const uint4 q1 = *reinterpret_cast<const uint4*>(qp + 32 + fg * 8);
+        if (qt != wave) {
+            int qrow = qt * 16 + fr;
+            if (qrow >= Lq) qrow = Lq - 1;
+            const T* qp = q + ((size_t)bq * Lq + qrow) * ldq + h * D;
+            q0 = *reinterpret_cast<const uint4*>(qp + fg * 8);
+            q1 = *reinterpret_cast<const uint4*>(qp + 32 + fg * 8);
+        }
 
         f32x4_t sc[MAXKT];
         float mx = -3.0e38f;
@@ -276,7 +288,10 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     if ((dt == DT_BF16 || dt == DT_F16) && Lk <= 512 && !(valu && atoi(valu))) {
         const int Lkp = (Lk + 31) / 32 * 32;
         const size_t lds2 = (size_t)Lkp * 128 + (size_t)64 * (Lkp + 4) * 2;          // 131.6 KB at Lk = 512
-#define LM(T, KT) hipLaunchKernelGGL((attention_mfma_kernel<T, KT>), dim3(B * heads), dim3(256), lds2, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod, klens)
+        static const bool w4 = dev_env("HCM_ATT_W4") != nullptr;          // (development build: the four-wave launch of rounds 1-3, for the A/B)
+        const int qtiles = (Lq + 15) / 16;
+        const int threads = w4 ? 256 : 64 * (qtiles < 4 ? 4 : qtiles > 8 ? 8 : qtiles);
+#define LM(T, KT) hipLaunchKernelGGL((attention_mfma_kernel<T, KT>), dim3(B * heads), dim3(threads), lds2, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, heads, Lq, Lk, ldq, ldk, ldv, ldo, q_batch_mod, klens)
         if (Lk <= 160) { if (dt == DT_BF16) LM(bf16, 10); else LM(f16, 10); }
         else if (Lk <= 256) { if (dt == DT_BF16) LM(bf16, 16); else LM(f16, 16); }
         else { if (dt == DT_BF16) LM(bf16, 32); else LM(f16, 32); }
