@@ -213,11 +213,17 @@ int hcm_refresh_instruction(hcm_handle h, const void* ids, int ids_dtype, const 
  *                        fails (bad argument, workspace, launch error) STILL takes part in the collective, with an all-NaN record, and returns
  *                        its error afterwards -- the private communicator has no watchdog, so a rank that simply returned would leave the
  *                        others blocked in ncclAllGather; they see NaN rows for that rank's environments instead
+ *                        (an argument error that every rank shares -- B outside [1, max_batch], null buffers -- returns HCM_ERR_ARG
+ *                        WITHOUT entering the collective: the element count must agree across ranks)
+ *   hcm_gather_poison    this rank cannot even start its step (its caller failed in front of the library: a broken observation, an exception
+ *                        in the host code) -- join THIS step's all-gather with an all-NaN (B, 7) block so that the peers, which are already
+ *                        inside it, see NaN rows for this rank's environments and leave at the same step
  *   hcm_comm_abort       ncclCommAbort of the handle's communicator (a rank that is going to stop stepping: an exception outside the library,
  *                        shutdown after a peer's NaN record); the handle can create a new one with hcm_comm_init afterwards */
 int hcm_comm_unique_id(void* out128);
 int hcm_comm_init(hcm_handle h, const void* unique_id128, int rank, int world);
 int hcm_comm_abort(hcm_handle h);
+int hcm_gather_poison(hcm_handle h, int B, float* record, float* gathered, void* stream);
 int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
                    int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                    int flags, float* gathered, void* stream);

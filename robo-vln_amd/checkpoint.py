@@ -1,4 +1,5 @@
-"""Reader for the reference's checkpoint format.
+"""Readers for the reference's checkpoint formats: the trainer's own file, and the DDPPO point-nav checkpoint the
+depth trunk is initialised from (`load_ddppo_depth_weights`, models/encoders/resnet_encoders.py:38-52).
 
 `RoboDaggerTrainer.save_checkpoint` writes `torch.save({"high_level_state_dict", "low_level_state_dict", "config"})`
 (robo_vln_baselines/hierarchical_trainer.py:349-363); `_setup_actor_critic_agent` loads the two state_dicts with
@@ -79,6 +80,48 @@ def load_checkpoint(path_or_file, map_location="cpu"):
     for sd in (ckpt["high_level_state_dict"], ckpt["low_level_state_dict"]):
         clean.append({k: v for k, v in sd.items() if not k.endswith(IGNORED_SUFFIXES)})
     return clean[0], clean[1], ckpt.get("config")
+
+
+def load_ddppo_depth_weights(path_or_file, map_location="cpu"):
+    """The remap `VlnResnetDepthEncoder.__init__` applies to a DDPPO point-nav checkpoint (models/encoders/resnet_encoders.py:38-52):
+    for every key of `ckpt["state_dict"]`, drop the first two dotted components (`actor_critic.net.`), keep only what then starts with
+    `visual_encoder.`, and strip that component too.  -> {name relative to `depth_encoder.visual_encoder`: tensor}; the file is read through
+    the same restricted un-pickler as the trainer's checkpoints (its pickled config classes are not importable here either)."""
+    ckpt = torch.load(path_or_file, map_location=map_location, pickle_module=_TolerantPickle, weights_only=False)
+    if "state_dict" not in ckpt:
+        raise KeyError(f"DDPPO checkpoint has no 'state_dict' (keys: {list(ckpt)})")
+    out = {}
+    for k, v in ckpt["state_dict"].items():
+        parts = k.split(".")[2:]                                     # :41
+        if not parts or parts[0] != "visual_encoder":               # :42-43 (a key with fewer than three components raises IndexError in
+            continue                                                 #  the reference; nothing a policy state_dict contains -- skipped)
+        out[".".join(parts[1:])] = v                                 # :45-46
+    if not out:
+        raise KeyError("DDPPO checkpoint holds no '<a>.<b>.visual_encoder.*' tensors")
+    return out
+
+
+def apply_ddppo_depth_weights(state_dict, ddppo_weights, prefix="depth_encoder.visual_encoder."):
+    """`self.visual_encoder.load_state_dict(weights_dict, strict=True)` (resnet_encoders.py:49) on a model state_dict held as a plain dict:
+    the DDPPO names must be EXACTLY the names under `prefix`, shapes equal -- missing / unexpected / mismatched entries raise RuntimeError
+    listing them, as torch's strict load does.  Returns a new dict with those tensors replaced (how the reference gets its depth trunk when
+    it trains from scratch with MODEL.DEPTH_ENCODER.ddppo_checkpoint set; a trainer checkpoint already contains the result)."""
+    own = {k[len(prefix):]: k for k in state_dict if k.startswith(prefix)}
+    if not own:
+        raise KeyError(f"state_dict has no '{prefix}*' entries")
+    missing = sorted(set(own) - set(ddppo_weights))
+    unexpected = sorted(set(ddppo_weights) - set(own))
+    bad_shape = [f"{n}: checkpoint {tuple(ddppo_weights[n].shape)} vs model {tuple(torch.as_tensor(state_dict[own[n]]).shape)}"
+                 for n in sorted(set(own) & set(ddppo_weights)) if tuple(ddppo_weights[n].shape) != tuple(torch.as_tensor(state_dict[own[n]]).shape)]
+    if missing or unexpected or bad_shape:
+        raise RuntimeError("DDPPO depth weights do not fit the depth trunk (strict): " +
+                           "; ".join(x for x in (f"missing {missing[:6]}{'...' if len(missing) > 6 else ''}" if missing else "",
+                                                 f"unexpected {unexpected[:6]}{'...' if len(unexpected) > 6 else ''}" if unexpected else "",
+                                                 f"size mismatch {bad_shape[:6]}" if bad_shape else "") if x))
+    out = dict(state_dict)
+    for n, full in own.items():
+        out[full] = ddppo_weights[n]
+    return out
 
 
 def save_checkpoint(path_or_file, high_level_state_dict, low_level_state_dict, config=None):

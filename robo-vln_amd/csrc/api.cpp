@@ -507,9 +507,6 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
         if (refold & 4) rebuild |= 4;
         refold = 0;
     }
-    // a trunk that leaves fp16 does not need (and no longer reports) a range fold
-    if (rebuild & 2) { for (int pos = 0; pos < hcm_ctx::kDepthPos; ++pos) h->depth_fold[pos] = 1.f; h->range_fold &= ~2; }
-    if (rebuild & 4) { h->rgb_fold = 1.f; h->range_fold &= ~4; }
     if (!rebuild && !refold) return HCM_OK;
     if (pass >= kMaxPasses)
         return fail(h, HCM_ERR_STATE, "fp16 range calibration did not converge within " + std::to_string(kMaxPasses) + " passes (max |x| " +
@@ -518,6 +515,10 @@ static int calibrate_run(hcm_ctx* h, const void* rgb, int rgb_dt, const float* d
     if (!h->host_weights)
         return fail(h, HCM_ERR_STATE, "fp16 range exceeded (max |x| " + std::to_string(h->calib_max[0]) + " BERT / " + std::to_string(h->calib_max[1]) +
                     " depth / " + std::to_string(h->calib_max[2]) + " RGB / " + std::to_string(h->calib_max[3]) + " cross-modal) but the host copies of the weights were released: create the engine with keep_host_weights or a bf16 sub-precision");
+    // a trunk that leaves fp16 does not need (and no longer reports) a range fold -- cleared only now, behind the checks that can still fail the
+    // call: on those error paths the device weights are still the folded ones and hcm_query(HCM_RANGE_FOLD) keeps saying so (round-4 advisor)
+    if (rebuild & 2) { for (int pos = 0; pos < hcm_ctx::kDepthPos; ++pos) h->depth_fold[pos] = 1.f; h->range_fold &= ~2; }
+    if (rebuild & 4) { h->rgb_fold = 1.f; h->range_fold &= ~4; }
     if (rebuild & 1) h->dt_bert = DT_BF16;
     if (rebuild & 2) h->dt_depth = DT_BF16;
     if (rebuild & 4) h->dt_rgb = DT_BF16;
@@ -696,7 +697,18 @@ int hcm_calibrate(hcm_handle h, const void* rgb, int rgb_dtype, const float* dep
     REQUIRE(rgb && depth && (ids || !needs_ids), HCM_ERR_ARG, "null pointer");
     REQUIRE(rgb_dt_ok(rgb_dtype) && ids_dt_ok(ids_dtype), HCM_ERR_ARG, "unsupported rgb/ids dtype");
     if (needs_ids && (rc = check_len(h, L))) return rc;
-    return calibrate_run(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, needs_ids ? L : 1, (hipStream_t)stream);
+    rc = calibrate_run(h, rgb, rgb_dtype, depth, ids, ids_dtype, B, needs_ids ? L : 1, (hipStream_t)stream);
+    // The overflow guard's polled view starts again from what the device word holds NOW (a re-build zeroed it; a measuring pass may have added to it):
+    // a value cached by an earlier hcm_guard_poll -- or still in flight to the host -- would otherwise come back as a new alarm for steps that were
+    // already reported (round-4 advisor).  hcm_calibrate is a construction-time call; the synchronous read costs nothing that matters.
+    if (h->guard_host) {
+        if (h->guard_pending) (void)hipEventSynchronize(h->guard_ev);
+        h->guard_pending = false;
+        unsigned v = 0;
+        if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+            hipMemcpy(&v, h->calib_buf + hcm_ctx::kStepBadWord, 4, hipMemcpyDeviceToHost) == hipSuccess) { h->guard_last = v; *h->guard_host = v; }
+    }
+    return rc;
 }
 
 int hcm_release_host_weights(hcm_handle h) {

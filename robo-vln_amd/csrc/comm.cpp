@@ -5,6 +5,7 @@
 // user of libhcm.so has no load-time dependency on it.
 // No reference counterpart: the reference evaluates one environment in one process (hierarchical_trainer.py:1088-1107).
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -31,10 +32,16 @@ struct Rccl {
 
 void rccl_load(Rccl& r) {
     // the copy the process already maps (a torch process: torch/lib/librccl.so) wins by SONAME; otherwise ROCm's
+    // HCM_RCCL_LIB=<path>: an explicit library instead (a site's own RCCL build; tests/stub_rccl's shared-memory stand-in, which gives
+    // hcm_act_gather a real peer on a one-GPU box) -- named explicitly, it must load: no silent fall-through to the system copy
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (const char* own = std::getenv("HCM_RCCL_LIB"); own && *own) {
+        r.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.err = std::string("HCM_RCCL_LIB=") + own + " not loadable: " + (dlerror() ? dlerror() : "?"); return; }
+    }
     for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.lib) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
     r.GetUniqueId = (int (*)(UniqueId*))dlsym(r.lib, "ncclGetUniqueId");
@@ -117,13 +124,28 @@ int hcm_comm_abort(hcm_handle h) {
     return HCM_OK;
 }
 
+int hcm_gather_poison(hcm_handle h, int B, float* record, float* gathered, void* stream) {
+    if (!h) return HCM_ERR_ARG;
+    if (!h->comm) return fail(h, HCM_ERR_STATE, "hcm_gather_poison: no communicator (hcm_comm_init)");
+    if (!record || !gathered || B < 1 || B > h->cfg.max_batch) return fail(h, HCM_ERR_ARG, "hcm_gather_poison: bad buffer / batch");
+    (void)hipMemsetAsync(record, 0xFF, (size_t)B * 7 * sizeof(float), (hipStream_t)stream);
+    Rccl& r = rccl();
+    const int nrc = r.AllGather(record, gathered, (size_t)B * 7, kNcclFloat32, (Comm)h->comm, (hipStream_t)stream);
+    if (nrc != kNcclSuccess) return fail(h, HCM_ERR_HIP, nccl_msg(r, "ncclAllGather", nrc));
+    return HCM_OK;
+}
+
 int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* depth, const void* ids, int ids_dtype, const int32_t* lengths,
                    int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                    int flags, float* gathered, void* stream) {
     if (!h) return HCM_ERR_ARG;
     if (!h->comm) return fail(h, HCM_ERR_STATE, "hcm_act_gather: no communicator (hcm_comm_init)");
     if (!gathered) return fail(h, HCM_ERR_ARG, "hcm_act_gather: null gather buffer");
-    if (!record || B < 1) return fail(h, HCM_ERR_ARG, "hcm_act_gather: bad record buffer / batch");
+    // Pure argument errors return WITHOUT joining the collective: every rank passes the same B (the collective's element count must agree across
+    // ranks, B * 7 floats each), so a B the handle cannot run is refused identically on every rank and nobody enters ncclAllGather; joining with a
+    // count the peers do not share is undefined in NCCL (round-4 advisor).  Only failures BEHIND this point take the poisoned-record path.
+    if (!record || B < 1 || B > h->cfg.max_batch)
+        return fail(h, HCM_ERR_ARG, "hcm_act_gather: bad record buffer, or batch outside [1, max_batch] (no collective was entered; all ranks must pass the same B)");
     const int rc = hcm_act_ex(h, rgb, rgb_dtype, depth, ids, ids_dtype, lengths, B, L, hi_h_in, lo_h_in, mask, record, hi_h_out, lo_h_out, flags, stream);
     const std::string step_err = rc != HCM_OK ? h->err : std::string();
     // A rank whose own step failed STILL takes part in the collective -- with a poisoned (all-NaN) record -- and reports its error afterwards:

@@ -399,9 +399,11 @@ struct Fwd {
             // A pending block input still needs its identity (xpend.res: the previous block's input or down-sample output) until THIS block's c1 has
             // normalised it -- and that slot counts as free here.  c1 must not write its output there: the launch would read the identity rows of some
             // pixels while other workgroups already store over them (round 4: 0.3-1 % of the steps of a 128-pixel configuration differed from run to
-            // run under the three-chain step; tools/r4_det.py).  c2 / c3 run behind c1 and may take it.
+            // run under the three-chain step; tools/step_determinism.py, test_three_chain_step_is_deterministic).  c2 / c3 run behind c1 and may take it.
+            if (nf != 3) throw std::runtime_error("trunk slot rotation: expected three free activation slots");
             if (xpend.valid && xpend.res && slot[fr[0]] == xpend.res) std::swap(fr[0], fr[1]);
             void* sa = slot[fr[0]]; void* sb = slot[fr[1]]; void* sc = slot[fr[2]];
+            if (xpend.valid && xpend.res && sa == xpend.res) throw std::runtime_error("trunk slot rotation: c1 would overwrite a pending identity");
             const int Ho2 = (x.H + 2 - 3) / b.stride + 1, Wo2 = (x.W + 2 - 3) / b.stride + 1;
             Act o1{sa, B, x.H, x.W, CO(b.c1)};
             const bool have_o1 = pre >= 0;

@@ -109,6 +109,8 @@ class HCMEngine:
         self._guard_every = int(guard_every)
         self._guard_tick = 0
         self._guard_seen = 0
+        self._gather_B = 0                              # per-rank batch of the library collective (act(gather=True)), 0 before the first such call
+        self._gather_entered = False
         self.guard_alarm = 0                            # deferred alarms of act(gather=True) steps, see guard_check()
         self._gstream = None
         self._static = None
@@ -186,6 +188,7 @@ class HCMEngine:
         """Tear the library's communicator down (hcm_comm_abort): for a rank that is going to stop stepping outside an agreed point."""
         _lib.check(self._lib.hcm_comm_abort(self._h), self._h)
         self.comm_world, self.comm_rank = 0, 0
+        self._gather_B = 0
 
     @property
     def num_recurrent_layers(self):
@@ -256,8 +259,10 @@ class HCMEngine:
                                                self._stream()), self._h)
             if release_host_weights:
                 _lib.check(self._lib.hcm_release_host_weights(self._h), self._h)
-        # a re-build zeroes the device guard word: the polled counter starts again (a stale _guard_seen would hide that many new alarms)
-        self._guard_seen = 0
+        # hcm_calibrate re-synchronised the library's polled view of the overflow guard with the device word (zeroed by a re-build, possibly
+        # raised by the measuring passes): alarms are counted from THAT value on -- neither a stale count (which would hide new alarms) nor a
+        # cached earlier one (which would raise again for steps already reported)
+        self._guard_seen = self.query(_lib.HCM_STEP_NONFINITE)
         self._guard_tick = 0
         return self.calibration_report()
 
@@ -403,6 +408,7 @@ class HCMEngine:
                 if gather:
                     if "gat" not in st:
                         st["gat"] = [torch.empty(self.comm_world * B, 7, device=self.device) for _ in range(2)]
+                    self._gather_entered = True
                     _lib.check(self._lib.hcm_act_gather(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
                                                         g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
                                                         st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
@@ -463,6 +469,31 @@ class HCMEngine:
         (hcm_act_gather: one ncclAllGather enqueued by the library behind the step)."""
         if gather and not self.comm_world:
             raise RuntimeError("act(gather=True) needs comm_init() first")
+        if not gather:
+            return self._act_impl(observations, hi_hidden, lo_hidden, masks, out, reuse_instruction, host_frames, False)
+        # env-sharded ranks: whatever fails on THIS rank in front of the library (a malformed observation, a shape error) must not leave the peers
+        # alone inside this step's all-gather -- the rank joins it with an all-NaN block (hcm_gather_poison) and raises afterwards; the peers see
+        # its NaN rows and leave at the same step (rollout()).  Failures inside hcm_act_gather take the same path in the library itself.
+        self._gather_entered = False
+        try:
+            return self._act_impl(observations, hi_hidden, lo_hidden, masks, out, reuse_instruction, host_frames, True)
+        except Exception:
+            if not self._gather_entered and self._gather_B:
+                with torch.cuda.device(self.device):
+                    B = self._gather_B
+                    scratch = torch.empty((1 + self.comm_world) * B, 7, device=self.device, dtype=torch.float32)
+                    self._lib.hcm_gather_poison(self._h, B, scratch.data_ptr(), scratch[B:].data_ptr(), self._stream())
+                    torch.cuda.current_stream().synchronize()
+            raise
+
+    def _act_impl(self, observations, hi_hidden, lo_hidden, masks, out, reuse_instruction, host_frames, gather):
+        if gather and not self._gather_B:
+            # the per-rank batch of the collective (every rank passes the same B): known from the first call on, so that a later call that
+            # cannot even read its observations still knows how many rows its peers expect
+            try:
+                self._gather_B = int(observations["rgb"].shape[0])
+            except Exception:
+                self._gather_B = 0
         flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
         if self._graph:
             cg = self._chain_graphs
@@ -489,6 +520,7 @@ class HCMEngine:
             if gather:
                 local = torch.empty(B, 7, device=self.device, dtype=torch.float32)
                 rec = out if out is not None else torch.empty(self.comm_world * B, 7, device=self.device, dtype=torch.float32)
+                self._gather_entered = True
                 _lib.check(self._lib.hcm_act_gather(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
                                                     _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
                                                     local.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, rec.data_ptr(), self._stream()), self._h)

@@ -82,6 +82,15 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
                        else policy.act(obs, st.hi_hidden, st.lo_hidden, None, st.masks, **kw))
         if lib_gather:
             full = rec
+            # A peer whose step failed contributed an all-NaN block (hcm_act_gather) and is about to raise out of its own act(): it will never
+            # enter the next step's collective.  Every rank sees the same gathered record, so every healthy rank leaves HERE, at the same step,
+            # and tears its communicator down (no watchdog on it) instead of blocking one step later (round-4 advisor).  The env loop reads
+            # the record on the host every step anyway (actions go to the simulators), so the test costs no extra synchronisation there.
+            if bool(torch.isnan(full).any()):
+                bad_ranks = sorted({int(r) for r in torch.nonzero(torch.isnan(full).any(1)).flatten().cpu() // num_envs})
+                policy.engine.comm_abort()
+                raise RuntimeError(f"rollout step {t}: rank(s) {bad_ranks} contributed a NaN action record to the all-gather (their step failed, "
+                                   "or their activations left the arithmetic range); communicator aborted on this rank")
         elif world > 1:
             full = torch.empty(global_envs, RECORD_WIDTH, device=rec.device, dtype=rec.dtype)
             gather_records(rec, full)
@@ -92,7 +101,7 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         st.after_step(hh, lh, prev_done)
         # env-sharded ranks on the library's collective: act(gather=True) only RECORDS an overflow-guard alarm; the ranks agree on it here, at
         # the same step on every rank, so that nobody is left inside the next step's all-gather (a NaN row in the gathered record -- a peer
-        # whose step failed, hcm_act_gather -- ends the rollout the same way)
+        # whose step failed, hcm_act_gather -- ended the rollout above, on every rank at this same step)
         if lib_gather:
             eng = policy.engine
             every = getattr(eng, "_guard_every", 0)

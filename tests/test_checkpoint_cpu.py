@@ -137,3 +137,56 @@ def test_untrusted_pickle_cannot_run_code():
     hi, lo, conf = checkpoint.load_checkpoint(buf)
     assert not os.path.exists(marker)
     assert isinstance(conf, dict) and type(conf).__name__ == "system"
+
+
+def test_ddppo_depth_checkpoint_remap_on_the_reference_written_fixture():
+    """VlnResnetDepthEncoder.__init__'s DDPPO remap (models/encoders/resnet_encoders.py:38-52) on tests/golden/ref_ddppo_structure.pth -- a hollow
+    DDPPO checkpoint whose visual-encoder names come from the reference class and which the REAL reference constructor loaded strictly when
+    oracle/gen_ddppo_fixture.py wrote it: the remapped names are exactly the 162 `depth_encoder.visual_encoder.*` names of the trainer-checkpoint
+    fixture (also written by the reference modules), shapes equal, the non-encoder keys are gone."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    dd = checkpoint.load_ddppo_depth_weights(os.path.join(here, "golden", "ref_ddppo_structure.pth"))
+    hi, lo, _ = checkpoint.load_checkpoint(os.path.join(here, "golden", "ref_checkpoint_structure.pth"))
+    pre = "depth_encoder.visual_encoder."
+    for sd in (hi, lo):
+        own = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        assert len(own) == 162 and set(own) == set(dd)
+        assert all(tuple(own[k].shape) == tuple(dd[k].shape) and own[k].dtype == dd[k].dtype for k in own)
+        out = checkpoint.apply_ddppo_depth_weights(sd, dd)
+        assert list(out) == list(sd)                                     # same keys, same order; only the trunk's tensors replaced
+    assert not any("state_encoder" in k or "critic" in k or "prev_action" in k for k in dd)
+
+
+def test_ddppo_depth_weights_values_and_strictness():
+    """Values travel unchanged through the remap, and the load is strict like `load_state_dict(strict=True)` (:49): a missing, an unexpected or a
+    mis-shaped tensor raises RuntimeError naming it."""
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, instr_len=20, bert_layers=1, bert_vocab=512)
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
+    other_hi, _ = synth.make_weights(cfg, seed=6)
+    pre = "depth_encoder.visual_encoder."
+    sd = {"actor_critic.net.visual_encoder." + k[len(pre):]: torch.from_numpy(np.asarray(v)) for k, v in other_hi.items() if k.startswith(pre)}
+    sd["actor_critic.net.state_encoder.rnn.bias_ih_l0"] = torch.zeros(8)
+    sd["actor_critic.critic.fc.weight"] = torch.zeros(1, 512)
+    buf = io.BytesIO()
+    torch.save({"state_dict": sd, "config": {"x": 1}}, buf)
+    buf.seek(0)
+    dd = checkpoint.load_ddppo_depth_weights(buf)
+    for tgt in (hi_sd, lo_sd):
+        out = checkpoint.apply_ddppo_depth_weights(tgt, dd)
+        for k in tgt:
+            want = other_hi[k] if k.startswith(pre) else tgt[k]
+            assert np.array_equal(np.asarray(out[k]), np.asarray(want)), k
+    k0 = next(iter(dd))
+    short = {k: v for k, v in dd.items() if k != k0}
+    with pytest.raises(RuntimeError, match="missing"):
+        checkpoint.apply_ddppo_depth_weights(hi_sd, short)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        checkpoint.apply_ddppo_depth_weights(hi_sd, {**dd, "backbone.not_a_layer.weight": torch.zeros(1)})
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        checkpoint.apply_ddppo_depth_weights(hi_sd, {**dd, k0: torch.zeros(3, 3)})
+    buf = io.BytesIO()
+    torch.save({"model": {}}, buf)
+    buf.seek(0)
+    with pytest.raises(KeyError):
+        checkpoint.load_ddppo_depth_weights(buf)

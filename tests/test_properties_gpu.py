@@ -481,6 +481,45 @@ def test_guard_poll_raises_without_synchronising():
     eng.close()
 
 
+def test_calibrate_after_a_guard_alarm_does_not_report_it_again():
+    """The remedy the alarm recommends is engine.calibrate(observations).  Afterwards the polled guard starts from what the device word holds
+    -- not from a count cached by an earlier hcm_guard_poll, which would come back as a spurious second alarm for steps already reported
+    (round-4 advisor; hcm_calibrate re-synchronises guard_last / the host word, calibrate() re-reads the counter) -- and NEW poisoned steps
+    still raise."""
+    from robo_vln_amd.policy import HCMEngine
+    cfg = _small_cfg()
+    hi_sd, lo_sd = synth.make_weights(cfg, seed=3)
+    n = 2
+    eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=n, precision="fp16", guard_every=1, keep_host_weights=True)
+    obs = {k: torch.from_numpy(v).cuda() for k, v in synth.make_observations(cfg, n, seed=3).items()}
+    R = cfg.num_recurrent_layers
+    z = torch.zeros(R, n, cfg.hidden, device="cuda")
+    m = torch.zeros(n, device="cuda")
+    bad = dict(obs)
+    bad["depth"] = obs["depth"].clone()
+    bad["depth"][1, 5, 7, 0] = float("nan")
+    with pytest.raises(FloatingPointError):
+        for _ in range(8):
+            eng.act(bad, z, z, m)
+            torch.cuda.synchronize()
+    for _ in range(3):                               # let every poisoned step that was enqueued reach the counter and the cached poll value
+        try:
+            eng.act(obs, z, z, m)
+        except FloatingPointError:
+            pass
+        torch.cuda.synchronize()
+    assert eng.nonfinite_steps() > 0
+    eng.calibrate(obs, release_host_weights=False)
+    for _ in range(6):                               # clean steps after the remedy: silent
+        eng.act(obs, z, z, m)
+        torch.cuda.synchronize()
+    with pytest.raises(FloatingPointError):          # and the guard is still armed
+        for _ in range(8):
+            eng.act(bad, z, z, m)
+            torch.cuda.synchronize()
+    eng.close()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_runtime_overflow_guard_counts_poisoned_samples(precision, graph):
