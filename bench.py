@@ -75,9 +75,10 @@ def cpu_baseline(cfg, hi_sd, lo_sd, batch=16, steps=8):
                       f"with {torch.get_num_threads()} threads"}
 
 
-def cpu_baseline_protocol(cfg, hi_sd, lo_sd):
-    """BASELINE.md section 3's protocol (--cpu-batches: minutes of CPU work, NOT part of the default run): batches 4, 16 and 64, best of 5
-    timed steps each."""
+def cpu_baseline_protocol(cfg, hi_sd, lo_sd, budget_s=None):
+    """BASELINE.md section 3's protocol: batches 4, 16 and 64, best of 5 timed steps each after a warm-up step.  budget_s (the
+    default run: ~30 s): the timed steps of a batch size stop once the budget is spent -- a batch-64 step is ~5-8 s of CPU work, so it gets
+    fewer than 5; `steps_timed` says how many each figure is the best of.  --cpu-batches runs the unbounded protocol."""
     import numpy as np
     import torch
     from oracle import hcm_oracle
@@ -87,21 +88,27 @@ def cpu_baseline_protocol(cfg, hi_sd, lo_sd):
     ora = hcm_oracle.PolicyOracle(cfg, hi_sd, lo_sd)
     R = cfg.num_recurrent_layers
     out = {}
+    t_all = time.time()
     for batch in (4, 16, 64):
         hh = torch.zeros(R, batch, cfg.hidden); lh = torch.zeros(R, batch, cfg.hidden)
         obs = synth.make_observations(cfg, batch, step=0, seed=0)
         mask = np.zeros(batch, np.float32)
         _, hh, lh = ora.act(obs, hh, lh, mask)
         mask[:] = 1
-        best = None
+        best, n = None, 0
         for _ in range(5):
             t0 = time.time()
             _, hh, lh = ora.act(obs, hh, lh, mask)
             dt = time.time() - t0
             best = dt if best is None else min(best, dt)
-        out[f"batch_{batch}"] = {"value": round(batch / best, 3), "unit": "env-steps/s", "ms_per_step": round(best * 1e3, 1)}
+            n += 1
+            if budget_s is not None and time.time() - t_all + dt > budget_s * (0.1 if batch == 4 else 0.4 if batch == 16 else 1.0):
+                break
+        out[f"batch_{batch}"] = {"value": round(batch / best, 3), "unit": "env-steps/s", "ms_per_step": round(best * 1e3, 1), "steps_timed": n}
     out["cores"] = ncores
-    out["protocol"] = "best of 5 act() steps per batch size (BASELINE.md section 3), CPU oracle, fp32"
+    out["seconds"] = round(time.time() - t_all, 1)
+    out["protocol"] = ("best of up to 5 act() steps per batch size after one warm-up step (BASELINE.md section 3), CPU oracle, fp32" +
+                       (f"; bounded to ~{budget_s:.0f} s of CPU work in the default run (steps_timed per batch)" if budget_s is not None else ""))
     return out
 
 
@@ -119,7 +126,7 @@ def _time_op(run, n=60, warm=30):
     return e0.elapsed_time(e1) / n          # ms
 
 
-def dominant_kernel_probe(batch, L=80):
+def dominant_kernel_probe(batch, L=80, dtype="f16"):
     """The launches with the largest share of a step's kernel time are the GEMMs of the fp16 BERT encoder
     (profiles/r2b_kernel_trace_bench.md): 12 launches each of QKV (768 -> 2304) and FFN1 (768 -> 3072, GELU) on the 256 x 256-tile
     kernel `gemm256f_kernel` (one barrier per K tile; round 4), and of attention-output (768 -> 768) and FFN2 (3072 -> 768) on `igemm_dma_kernel` (at B = 64 their
@@ -132,18 +139,19 @@ def dominant_kernel_probe(batch, L=80):
     lib = _lib.lib()
     M = batch * L
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tdt, hdt = (torch.bfloat16, _lib.HCM_BF16) if dtype == "bf16" else (torch.float16, _lib.HCM_F16)
     out = {}
     for name, N, K, act, res in (("ffn1", 3072, 768, _lib.ACT_GELU, False), ("qkv", 2304, 768, 0, False),
                                  ("ffn2", 768, 3072, 0, True), ("attn_out", 768, 768, 0, True)):
-        x = (torch.randn(M, K, device="cuda") * 0.5).half()
-        w = (torch.randn(N, K, device="cuda") * 0.03).half()
+        x = (torch.randn(M, K, device="cuda") * 0.5).to(tdt)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(tdt)
         b = torch.randn(N, device="cuda") * 0.1
-        r = (torch.randn(M, N, device="cuda") * 0.5).half() if res else None
-        y = torch.empty(M, N, device="cuda", dtype=torch.float16)
+        r = (torch.randn(M, N, device="cuda") * 0.5).to(tdt) if res else None
+        y = torch.empty(M, N, device="cuda", dtype=tdt)
 
         def run():
             rc = lib.hcm_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(),
-                                   _lib.HCM_F16, M, N, K, act, 0, st)
+                                   hdt, M, N, K, act, 0, st)
             assert rc == 0
         ms = _time_op(run)
         fl = 2.0 * M * N * K
@@ -403,6 +411,8 @@ def main():
                     "except with --h2d, where the default is the engine's own choice (auto: the frame copies overlap BERT in that form)")
     ap.add_argument("--bf16-leg", type=float, default=2.0, help="N = 1, configs[1], --precision fp16: seconds of an additional run of the SAME workload on a "
                                                                  "`precision=\"bf16\"` engine, reported as `bf16_mode` (0 = skip)")
+    ap.add_argument("--h2d-leg", type=float, default=2.0, help="N = 1, configs[1]: seconds of an additional PCIe-inclusive run of the SAME workload (pinned host "
+                    "frames copied inside every step) reported as `h2d` (0 = skip)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: the per-step all-gather through torch.distributed instead of the library's own "
                                                                 "RCCL call behind the step (A/B of rounds 1-2 vs round 3)")
     ap.add_argument("--reuse-instruction", action="store_true",
@@ -626,8 +636,40 @@ def main():
             bf16_mode = {"value": round(l2["global_B"] * n2 / l2["dt"], 2), "ms_per_step": round(l2["dt"] / n2 * 1e3, 3), "steps": n2,
                          "dtype": dtype_string(a2, eng2), "note": "same workload, same timed-region protocol, on an engine built with precision=\"bf16\""}
             eng2.close()
+            if not args.no_kernel_probe:
+                # the mode's own roofline block: the same dominant launch (BERT FFN1 on gemm256f_kernel) on bf16 tiles, timed live like the fp16 one
+                dk2 = dominant_kernel_probe(B2, cfg.instr_len, dtype="bf16")
+                v2 = bf16_mode["value"] * GFLOP[1] / 1e3
+                bf16_mode["roofline"] = {"bound": "mfma", "achieved": dk2["ffn1"]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": dk2["ffn1"]["frac_of_peak"], "traffic": None,
+                                         "scope": "dominant kernel: gemm256f_kernel<bf16> on BERT FFN1 (" + dk2["ffn1"]["shape"] + f"), {dk2['ffn1']['us_per_launch']} us per launch",
+                                         "bert_gemms": dk2,
+                                         "whole_step": {"achieved": round(v2, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(v2 / PEAK_BF16_TFLOPS, 4),
+                                                        "basis": f"{GFLOP[1]} algorithmic GFLOP per env-step x env-steps/s of this mode"}}
         except Exception as e:           # never lose the headline number to the extra leg
             bf16_mode = {"error": str(e)}
+
+    # PCIe-inclusive leg (N = 1 default run only; SURVEY 8d: "report separately with H->D of uint8 RGB + f32 depth included"): the SAME workload with the
+    # frames handed over as pinned HOST tensors every step (HCM_ACT_HOST_FRAMES: the library copies each frame set at the head of the chain that
+    # reads it, per-chain linear graphs).  Never `value`.
+    h2d_leg = None
+    if (world == 1 and args.config == 1 and args.precision == "fp16" and args.h2d_leg > 0 and not STUB and not args.h2d and not args.reuse_instruction
+            and not args.batch and not args.total_batch and not args.no_graph):
+        try:
+            import copy
+            a4 = copy.copy(args)
+            a4.h2d, a4.chain_graphs = True, "auto"
+            _, B4, eng4, step4, _, _ = build_act_workload(a4, 1, rank, world, local_rank)
+            n4 = max(10, int(args.h2d_leg / (dt / args.steps)))
+            l4 = run_leg(B4, step4, n4)
+            per = B4 * (cfg.rgb_hw * cfg.rgb_hw * 3 + cfg.depth_hw * cfg.depth_hw * 4)
+            h2d_leg = {"value": round(l4["global_B"] * n4 / l4["dt"], 2), "ms_per_step": round(l4["dt"] / n4 * 1e3, 3), "steps": n4, "bytes_per_step": per,
+                       "pcie_GBps": round(per / (l4["dt"] / n4) / 1e9, 2),
+                       "note": "same workload with uint8 RGB + f32 depth copied from pinned host memory inside every timed step (act(host_frames=True), "
+                               "chain_graphs=auto); instruction ids resident (they change per episode, not per step)"}
+            eng4.close()
+        except Exception as e:           # never lose the headline number to the extra leg
+            h2d_leg = {"error": str(e)}
 
     # single-environment latency (N = 1 default run only): the reference's evaluation loop (hierarchical_trainer.py:1088-1107) calls the policy once per
     # simulator step and needs the action before it can step the simulator, so what it sees is the SYNCHRONOUS latency of a B = 1 step, not a pipelined
@@ -691,6 +733,8 @@ def main():
             out["overlapped_all_gather"] = overlapped
         if bf16_mode:
             out["bf16_mode"] = bf16_mode
+        if h2d_leg:
+            out["h2d"] = h2d_leg
         if single_env is not None:
             out["single_env_latency"] = single_env
         if args.config == 3:
@@ -745,8 +789,7 @@ def main():
             out["config"]["hipgraph"] = {"enabled": not args.no_graph and args.config in (0, 1), "chain_graphs": args.chain_graphs, "graph_steps": eng.query(7), "eager_steps": eng.query(8)}
         if not args.no_cpu_baseline and world == 1 and args.config == 1 and not STUB:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, *weights)
-            if args.cpu_batches:
-                out["cpu_baseline"]["batches"] = cpu_baseline_protocol(cfg, *weights)
+            out["cpu_baseline"]["batches"] = cpu_baseline_protocol(cfg, *weights, budget_s=None if args.cpu_batches else 30.0)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if hasattr(eng, "close"):
