@@ -368,6 +368,13 @@ int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
  * `dtype` (used by the convert + implicit-GEMM route only, HCM_NO_DEPTH_CONV0=1) (simple_cnns.py:76-84). */
 int hcm_op_depth_conv8x8s4(const float* depth, const void* w, const float* bias, void* y, int dtype, int B, int H, int act, void* scratch,
                            void* stream);
+/* SimpleDepthCNN's three convolutions (models/encoders/simple_cnns.py:76-100; depth branch :104-125) in ONE launch (csrc/simplecnn.hip): depth (B,H,H,1)
+ * f32 -> y (B,h3,h3,32), the map the Linear reads; the 63 x 63 x 32 and 30 x 30 x 64 maps of a 256-pixel frame never leave the chip.  w0 (32,64) as
+ * hcm_op_depth_conv8x8s4 takes it; w1_frag / w2_frag: the 4x4/2 and 3x3/1 weights as (64,512) / (32,576) rows with k = (kh*KW + kw)*Cin + ci (the OHWI
+ * layout of hcm_op_conv2d), passed through hcm_op_pack_frag.  16-bit dtypes, H % 4 == 0, H <= 256.  Bit-identical to hcm_op_depth_conv8x8s4 +
+ * hcm_op_conv2d (ReLU) + hcm_op_conv2d. */
+int hcm_op_simplecnn3(const float* depth, const void* w0, const float* b0, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
+                      void* y, int dtype, int B, int H, void* stream);
 int hcm_op_linear(const void* x, const void* w, const float* bias, const void* residual, void* y,
                   int dtype, int M, int N, int K, int act, int out_f32, void* stream);
 /* One cross-modal layer after the projections for `streams` (1 or 2) visual streams in one launch (csrc/vla_fused.hip;
@@ -388,6 +395,16 @@ int hcm_op_attention(const void* q, const void* k, const void* v, void* out, int
                      int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, void* stream);
 int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
                      void* y, int dtype, int rows, int D, float eps, void* stream);
+/* BERT attention block tail in ONE launch (csrc/bert_block.hip; BertSelfAttention + BertSelfOutput of the BertModel call,
+ * seq2seq_highlevel_cma.py:192-195): y = LayerNorm(softmax(Q K^T / 8) V Wo^T + bo + residual) over B samples of L <= 96 rows, 12 heads of 64;
+ * qkv (B*L, 2304) = Q | K | V, lengths (B,) int32 keys per sample or NULL; wo_frag = the (768, 768) weight in MFMA-fragment order as
+ * hcm_op_pack_frag writes it (N % 16 == 0, K % 32 == 0: the 16-byte chunk W[ct*16 + fr][ks*32 + fg*8 ..] at chunk index (ks*(N/16) + ct)*64 + fg*16 + fr:
+ * a wave's operand fragment is 1 KB contiguous -- hcm_finalize keeps this second copy of every BERT layer's output projection).  Bit-identical to hcm_op_attention + hcm_op_linear
+ * (+ residual) + hcm_op_layernorm.  residual32 / y32 non-NULL: the residual stream and the sum stay f32 (the "bf16" mode's BERT), y is the 16-bit
+ * operand copy of the LayerNorm output and y32 the stream; y may alias residual, y32 may alias residual32. */
+int hcm_op_pack_frag(const void* w, void* out, int dtype, int N, int K, void* stream);
+int hcm_op_bert_attn_block(const void* qkv, const void* wo_frag, const float* bo, const void* residual, const float* residual32, const float* gamma,
+                           const float* beta, void* y, float* y32, int dtype, int B, int L, const int32_t* lengths, float eps, void* stream);
 /* LayerNorm followed by the addition of a row table: y[r] = LN(x[r] (+ residual[r])) + post[r % post_rows]  (the positional
  * encoding of Visual_Ling_Attn, transformer.py:265-269) */
 int hcm_op_layernorm_post(const void* x, const void* residual, const float* gamma, const float* beta, const float* post, int post_rows,

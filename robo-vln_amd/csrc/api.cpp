@@ -1233,6 +1233,17 @@ int hcm_op_layernorm(const void* x, const void* residual, const float* gamma, co
                      int D, float eps, void* stream) {
     return op_rc(launch_layernorm(x, residual, gamma, beta, nullptr, 0, y, op_dt(dtype), rows, D, eps, (hipStream_t)stream));
 }
+int hcm_op_simplecnn3(const float* depth, const void* w0, const float* b0, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
+                      void* y, int dtype, int B, int H, void* stream) {
+    return op_rc(launch_simplecnn3(depth, w0, b0, w1_frag, b1, w2_frag, b2, y, op_dt(dtype), B, H, (hipStream_t)stream));
+}
+int hcm_op_pack_frag(const void* w, void* out, int dtype, int N, int K, void* stream) {
+    return op_rc(launch_pack_frag(w, out, op_dt(dtype), N, K, (hipStream_t)stream));
+}
+int hcm_op_bert_attn_block(const void* qkv, const void* wo, const float* bo, const void* residual, const float* residual32, const float* gamma,
+                           const float* beta, void* y, float* y32, int dtype, int B, int L, const int32_t* lengths, float eps, void* stream) {
+    return op_rc(launch_bert_attn_block(qkv, 2304, wo, bo, residual, residual32, gamma, beta, y, y32, op_dt(dtype), B, L, lengths, eps, (hipStream_t)stream));
+}
 int hcm_op_layernorm_post(const void* x, const void* residual, const float* gamma, const float* beta, const float* post, int post_rows,
                           void* y, int dtype, int rows, int D, float eps, void* stream) {
     return op_rc(launch_layernorm(x, residual, gamma, beta, post, post_rows, y, op_dt(dtype), rows, D, eps, (hipStream_t)stream));

@@ -554,6 +554,17 @@ struct Fwd {
         const int H = w.h, W = w.w;
         const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = (h2 - 3) / 1 + 1;
         const int w1 = (W - 8) / 4 + 1, w2 = (w1 - 4) / 2 + 1, w3 = (w2 - 3) / 1 + 1;
+        // Round 5: the three convolutions of the depth CNN in ONE launch, both intermediate maps in LDS (simplecnn.hip: simplecnn3_kernel; bit-identical
+        // to the launches below; HCM_NO_CNN3=1 of the development build: the launches)
+        static const bool no_cnn3 = dev_env("HCM_NO_CNN3") != nullptr;
+        if (!no_cnn3 && w.cin == 1 && x_dt == DT_F32 && H == W && w.c1_frag && w.c2_frag && w.c0_packed.w && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 &&
+            simplecnn3_ok(dt, H) && !ctx->taps_on) {
+            void* y2f = alloc_t((size_t)B * h3 * w3 * 32);
+            if (!dry) ck(launch_simplecnn3((const float*)x, w.c0_packed.w, w.c0_packed.bias, w.c1_frag, w.c1.bias, w.c2_frag, w.c2.bias, y2f, dt, B, H, s),
+                         "simple cnn (three convolutions, one launch)");
+            linear(w.fc, y2f, B, h3 * w3 * 32, out, ld, ACT_RELU, true);
+            return;
+        }
         void* y0 = alloc_t((size_t)B * h1 * w1 * 32);
         static const bool no_pack = dev_env("HCM_NO_STEM_PACK") != nullptr;
         if (w.c0_packed.w && !no_pack && (x_dt == DT_F32 || x_dt == DT_U8) && (w.cin == 3 || x_dt == DT_F32)) {
@@ -677,9 +688,20 @@ struct Fwd {
             ln(x, nullptr, *prev_ln2, nullptr, 0, x, rows, D, 1e-12f);        // the encoder's output, materialised (in place: a row is one wave's registers)
             return;
         }
+        // Round 5 experiment, OFF unless HCM_BERT_FUSE=1 (development build): attention + output projection + residual + LayerNorm as ONE launch per
+        // layer (bert_block.hip; bit-identical to the three launches below).  MEASURED SLOWER -- 37.7 us against 29.8 us for the three launches at
+        // B = 64, 33 against 15 us at B = 1: a workgroup that owns 48 rows x all 768 columns has to ingest the whole 1.18 MB of W_o through its CU's
+        // one L1 / texture path (64 B and ONE cache-line look-up per clock: >= 9 us, 13-17 measured), behind an attention phase that is one latency
+        // chain per head (17-20 us for 12 heads on 8 waves).  The chip-wide launches spread the same weight bytes over 240 CUs.  DESIGN_LOG R5.1.
+        static const bool no_blk = dev_env("HCM_BERT_FUSE") == nullptr;
+        const bool blk = !no_blk && !w.layers.empty() && w.layers[0].o.dt == dt && w.layers[0].o_frag && bert_attn_block_ok(dt, D, c.bert_heads, L, w.layers[0].o.Kp, 3 * D);
         for (const BertLayerW& l : w.layers) {
             if (li) mark("bert.layer" + std::to_string(li));
             linear(l.qkv, x, rows, D, qkv, 3 * D, ACT_NONE, false);
+            if (blk) {
+                if (!dry) ck(launch_bert_attn_block(qkv, 3 * D, l.o_frag, l.o.bias, f32_stream ? nullptr : x, f32_stream ? xf : nullptr, l.ln1.gamma, l.ln1.beta,
+                                                    x, f32_stream ? xf : nullptr, dt, B, L, lens, 1e-12f, s), "bert attention block");
+            } else {
             if (!dry) ck(launch_attention(qkv, (char*)qkv + (size_t)D * esz, (char*)qkv + (size_t)2 * D * esz, ctxb, dt, B, c.bert_heads,
                                           L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
             if (f32_stream) {
@@ -688,6 +710,7 @@ struct Fwd {
             } else {
                 linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
                 ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
+            }
             }
             linear(l.ff1, x, rows, D, hbuf, c.bert_inter, ACT_GELU, false);
             if (f32_stream) {

@@ -205,6 +205,15 @@ hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, con
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int dt, int B, int heads,
                             int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int q_batch_mod, hipStream_t s, const int* klens = nullptr);
 
+// BERT attention block tail in one launch (bert_block.hip): y = LayerNorm(softmax(Q K^T / 8) V Wo^T + bo + residual) per sample, bit-identical to
+// launch_attention + launch_igemm(+ residual) + launch_layernorm[_f32in].  res32 / y32: the bf16 mode's f32 residual stream.
+bool bert_attn_block_ok(int dt, int D, int heads, int L, int Kp, int ldq);
+// wo_frag: W_o in fragment order (launch_pack_frag; host-side twin: weights.cpp frag_order) -- a wave's 16-column x 32-k MFMA operand fragment is
+// 1 KB contiguous, so that fragment loads straight from L2 cost 8 cache-line look-ups instead of 64
+hipError_t launch_pack_frag(const void* w, void* out, int dt, int N, int K, hipStream_t s);
+hipError_t launch_bert_attn_block(const void* qkv, int ldq, const void* wo_frag, const float* bo, const void* res, const float* res32, const float* gamma,
+                                  const float* beta, void* y, float* y32, int dt, int B, int L, const int* klens, float eps, hipStream_t s);
+
 // One cross-modal layer after the projections, both visual streams in one launch (vla_fused.hip): [attention when Lk <= 32] ->
 // fc_o + residual I -> LayerNorm -> fc1 + ReLU -> fc2 + residual -> LayerNorm [-> mean over the instruction's tokens].  16-bit storage types,
 // d_model 256, 4 heads, d_ff a multiple of 256.  Per-stream pointers are indexed by blockIdx.y.
@@ -265,6 +274,10 @@ hipError_t launch_absmax(const void* x, int dt, int rows, int cols, int ld, unsi
 hipError_t launch_convert_to_f32(const void* x, int dt, float* y, size_t n, hipStream_t s);
 hipError_t launch_convert_from_f32(const float* x, void* y, int dt, size_t n, hipStream_t s);
 // simplecnn.hip: Conv2d(1, 32, 8, stride 4) + bias + activation from the raw f32 depth frame (B,H,H,1), w = [32][64] in the 16-bit storage type
+// SimpleDepthCNN's three convolutions in one launch (simplecnn.hip): the two intermediate maps live in LDS; w1f / w2f in fragment order (launch_pack_frag)
+bool simplecnn3_ok(int dt, int H);
+hipError_t launch_simplecnn3(const float* x, const void* w0, const float* b0, const void* w1f, const float* b1, const void* w2f, const float* b2, void* y,
+                             int dt, int B, int H, hipStream_t s);
 bool depth_conv8x8s4_ok(int dt, int H, int act);
 hipError_t launch_depth_conv8x8s4(const float* x, const void* w, const float* bias, void* y, int dt, int B, int H, int act, hipStream_t s);
 // storage-type conversion between sub-networks (e.g. fp16 depth tokens -> bf16 cross-modal block)

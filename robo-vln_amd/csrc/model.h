@@ -64,11 +64,14 @@ struct TrunkW {
 struct SimpleCnnW {
     ConvW c0, c1, c2;          // 8x8/4 (narrow-channel gather), 4x4/2, 3x3/1
     ConvW c0_packed;           // 16-bit path: k = kh*KR + kw*cp + ci with cp = 4 (RGB, KR = 32) or 1 (depth, KR = 8)
+    void* c1_frag = nullptr;   // c1.w / c2.w in MFMA-fragment order (depth, 16-bit): the three convolutions in one launch (simplecnn.hip)
+    void* c2_frag = nullptr;
     LinW fc;
     int cin = 1, h = 0, w = 0, h3 = 0, w3 = 0;      // frame H x W, final map h3 x w3
 };
 struct BertLayerW {
     LinW qkv, o, ff1, ff2;
+    void* o_frag = nullptr;    // o.w in MFMA-fragment order for the fused attention-block launch (bert_block.hip); 16-bit 768 x 768 only
     NormW ln1, ln2;
     // folded LayerNorm (fp16 BERT; forward.cpp bert(), IGemm::ln_*): ff1_f = W_ff1 diag(gamma_ln1) with ff1_s[n] = sum_k W'[n][k] (of the ROUNDED
     // weights) and ff1_t[n] = sum_k W[n][k] beta_ln1[k] + b[n]; qkv_f likewise with the PREVIOUS layer's ln2 (absent in layer 0)

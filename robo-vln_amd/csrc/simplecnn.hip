@@ -87,6 +87,204 @@ __global__ __launch_bounds__(256) void depth_conv8x8s4_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// SimpleDepthCNN's three convolutions in ONE launch (round 5; models/encoders/simple_cnns.py:76-100, depth branch :104-125):
+//   Conv 8x8/4 (1 -> 32) + ReLU -> Conv 4x4/2 (32 -> 64) + ReLU -> Conv 3x3/1 (64 -> 32),
+// only the raw f32 frame comes in and only the 32-channel map that feeds the Linear goes out.  As three launches the 63 x 63 x 32 and the
+// 30 x 30 x 64 map make a round trip through HBM each (configs[3], B = 256: 144 + 107 MB per step of the 0.63 GB the step moved, against
+// 0.107 GB of algorithmic bytes).
+//
+// A workgroup owns a BAND of N3 = 7 rows of the last map of one frame (four bands at 256 x 256) and everything above it: 9 rows of the
+// second map, 20 of the first, 84 input rows -- halo rows are recomputed (x 1.27 / x 1.2 of the first two convs' work, which is cheap: the
+// path is bounded by the one pass over the frame and by latency).  LDS: the input rows as T (43 KB; later overlaid by the second map), the
+// first map with 80-byte pixels and the second with 144-byte pixels (16 bytes of padding each: the B-operand reads of 16 consecutive output
+// pixels -- 2 or 1 input pixels apart -- then fall on 16 different bank quads).  Weights stay in REGISTERS as A-operand fragments, loaded from
+// the fragment-order copies (launch_pack_frag: 1 KB contiguous per fragment): conv2 a wave holds two of the four 16-channel tiles (32
+// fragments) and works on every fourth pixel tile, conv3 one of the two (18 fragments).  k order, operand roles, bias + ReLU + the one
+// rounding are those of depth_conv8x8s4_kernel / igemm_dma_kernel: BIT-IDENTICAL to the three launches.
+constexpr int S3_N3 = 7;                                  // rows of the last map per workgroup
+constexpr int S3_P1 = 80, S3_P2 = 144;                    // bytes per pixel of the first / second map in LDS
+struct SimpleCnn3Dev {
+    const float* x;                                       // [B][H][H] f32
+    const void* w0; const float* b0;                      // [32][64] (k = kh*8 + kw)
+    const void* w1f; const float* b1;                     // conv2 [64][512] in fragment order
+    const void* w2f; const float* b2;                     // conv3 [32][576] in fragment order
+    void* y;                                              // [B][h3][h3][32]
+    int H, h1, h2, h3, bands;
+};
+__host__ __device__ inline size_t s3_lds_bytes(int H, int h1, int h2) {
+    const int n2 = S3_N3 + 2, n1 = 2 * n2 + 2, nin = 4 * n1 + 4;
+    const size_t in = (size_t)nin * H * 2, m2 = (size_t)n2 * h2 * S3_P2;
+    return ((in > m2 ? in : m2) + 15) / 16 * 16 + (size_t)n1 * h1 * S3_P1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void simplecnn3_kernel(SimpleCnn3Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = p.H, h1 = p.h1, h2 = p.h2, h3 = p.h3;
+    const int band = blockIdx.x % p.bands, b = blockIdx.x / p.bands;
+    const int r3_0 = band * S3_N3;
+    const int n3 = min(S3_N3, h3 - r3_0), n2 = n3 + 2, n1 = 2 * n2 + 2, nin = 4 * n1 + 4;
+    const int n2max = S3_N3 + 2, n1max = 2 * n2max + 2, ninmax = 4 * n1max + 4;
+    const size_t in_bytes = (size_t)ninmax * H * 2, m2_bytes = (size_t)n2max * h2 * S3_P2;
+    T* sx = reinterpret_cast<T*>(smem);                                   // [nin][H] input rows as T; dead after conv1
+    char* c2map = smem;                                                   // [n2][h2] pixels of 144 B (overlays the input rows)
+    char* c1map = smem + ((in_bytes > m2_bytes ? in_bytes : m2_bytes) + 15) / 16 * 16;     // [n1][h1] pixels of 80 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+
+    // ---- the band's input rows: one pass over the frame, rounded to T exactly as the conversion kernel rounds (RNE)
+    const float* xb = p.x + (size_t)b * H * H + (size_t)(8 * r3_0) * H;    // first input row = 4 * (2 * r3_0) ... conv1 row 2*r3_0, x 4
+    {
+        const int q = nin * (H >> 2);
+        for (int e = tid; e < q; e += 512) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)e * 4);
+            T o[4];
+            Tr<T>::st(&o[0], v.x); Tr<T>::st(&o[1], v.y); Tr<T>::st(&o[2], v.z); Tr<T>::st(&o[3], v.w);
+            *reinterpret_cast<uint2*>(sx + (size_t)e * 4) = *reinterpret_cast<const uint2*>(o);
+        }
+    }
+    // conv1 weights (A operand: channel i*16 + fr, k = ks*32 + fg*8 ..) and conv2's fragments of this wave's two channel tiles
+    const T* w0 = reinterpret_cast<const T*>(p.w0);
+    uint4 wa0[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wa0[i][ks] = *reinterpret_cast<const uint4*>(w0 + (size_t)(i * 16 + fr) * 64 + ks * 32 + fg * 8);
+    const int np = wave & 1, mq = wave >> 1;
+    uint4 wa1[2][16];
+    {
+        const T* w1f = reinterpret_cast<const T*>(p.w1f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) wa1[t][ks] = *reinterpret_cast<const uint4*>(w1f + (((size_t)ks * 4 + 2 * np + t) * 64 + lane) * 8);
+    }
+    float4 b40[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b40[i] = *reinterpret_cast<const float4*>(p.b0 + i * 16 + fg * 4);
+    __syncthreads();
+
+    // ---- conv1: 8x8 / 4, K = 64 in two steps, pixels of the band's n1 rows
+    {
+        const int npix = n1 * h1;
+        for (int f = wave; f * 16 < npix; f += 8) {
+            const int pq = f * 16 + fr;
+            const int pc = min(pq, npix - 1);
+            const int r = pc / h1, ox = pc - r * h1;
+            s_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const T* src = sx + (size_t)(4 * r + ks * 4 + fg) * H + 4 * ox;          // 8-byte aligned
+                const uint2 lo = *reinterpret_cast<const uint2*>(src);
+                const uint2 hi = *reinterpret_cast<const uint2*>(src + 4);
+                const uint4 xb4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) SMma<T>::run(acc[i], wa0[i][ks], xb4);
+            }
+            if (pq < npix) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    T o[4];
+                    Tr<T>::st(&o[0], relu_f(acc[i][0] + b40[i].x)); Tr<T>::st(&o[1], relu_f(acc[i][1] + b40[i].y));
+                    Tr<T>::st(&o[2], relu_f(acc[i][2] + b40[i].z)); Tr<T>::st(&o[3], relu_f(acc[i][3] + b40[i].w));
+                    *reinterpret_cast<uint2*>(c1map + (size_t)pq * S3_P1 + (i * 16 + fg * 4) * 2) = *reinterpret_cast<const uint2*>(o);
+                }
+            }
+        }
+    }
+    // conv3's fragments of this wave's channel tile (requested now: the round trip runs beside conv2) and the biases
+    const int nt = wave & 1;
+    uint4 wa2[18];
+    {
+        const T* w2f = reinterpret_cast<const T*>(p.w2f);
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) wa2[ks] = *reinterpret_cast<const uint4*>(w2f + (((size_t)ks * 2 + nt) * 64 + lane) * 8);
+    }
+    float4 b41[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b41[t] = *reinterpret_cast<const float4*>(p.b1 + (2 * np + t) * 16 + fg * 4);
+    const float4 b42 = *reinterpret_cast<const float4*>(p.b2 + nt * 16 + fg * 4);
+    __syncthreads();                                       // the first map is complete; the input rows are dead
+
+    // ---- conv2: 4x4 / 2, one K step per tap (32 channels)
+    {
+        const int npix = n2 * h2;
+        for (int f = mq; f * 16 < npix; f += 4) {
+            const int pq = f * 16 + fr;
+            const int pc = min(pq, npix - 1);
+            const int oy = pc / h2, ox = pc - oy * h2;
+            const char* base = c1map + ((size_t)(2 * oy) * h1 + 2 * ox) * S3_P1 + fg * 16;
+            s_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const uint4 xb4 = *reinterpret_cast<const uint4*>(base + ((size_t)(ks >> 2) * h1 + (ks & 3)) * S3_P1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) SMma<T>::run(acc[t], wa1[t][ks], xb4);
+            }
+            if (pq < npix) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    T o[4];
+                    Tr<T>::st(&o[0], relu_f(acc[t][0] + b41[t].x)); Tr<T>::st(&o[1], relu_f(acc[t][1] + b41[t].y));
+                    Tr<T>::st(&o[2], relu_f(acc[t][2] + b41[t].z)); Tr<T>::st(&o[3], relu_f(acc[t][3] + b41[t].w));
+                    *reinterpret_cast<uint2*>(c2map + (size_t)pq * S3_P2 + ((2 * np + t) * 16 + fg * 4) * 2) = *reinterpret_cast<const uint2*>(o);
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // the second map is complete
+
+    // ---- conv3: 3x3 / 1, two K steps per tap (64 channels), no activation
+    {
+        const int npix = n3 * h3;
+        T* yb = reinterpret_cast<T*>(p.y) + ((size_t)b * h3 + r3_0) * h3 * 32;
+        for (int f = mq; f * 16 < npix; f += 4) {
+            const int pq = f * 16 + fr;
+            const int pc = min(pq, npix - 1);
+            const int oy = pc / h3, ox = pc - oy * h3;
+            const char* base = c2map + ((size_t)oy * h2 + ox) * S3_P2 + fg * 16;
+            s_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {
+                const int tap = ks >> 1, kh = tap / 3, kw = tap - kh * 3;
+                const uint4 xb4 = *reinterpret_cast<const uint4*>(base + ((size_t)kh * h2 + kw) * S3_P2 + (ks & 1) * 64);
+                SMma<T>::run(acc, wa2[ks], xb4);
+            }
+            if (pq < npix) {
+                T o[4];
+                Tr<T>::st(&o[0], acc[0] + b42.x); Tr<T>::st(&o[1], acc[1] + b42.y); Tr<T>::st(&o[2], acc[2] + b42.z); Tr<T>::st(&o[3], acc[3] + b42.w);
+                *reinterpret_cast<uint2*>(yb + (size_t)pq * 32 + nt * 16 + fg * 4) = *reinterpret_cast<const uint2*>(o);
+            }
+        }
+    }
+}
+
+bool simplecnn3_ok(int dt, int H) {
+    if ((dt != DT_BF16 && dt != DT_F16) || H < 36 || H % 4) return false;
+    const int h1 = (H - 8) / 4 + 1, h2 = (h1 - 4) / 2 + 1, h3 = h2 - 2;
+    return h3 >= 1 && s3_lds_bytes(H, h1, h2) <= 160 * 1024;
+}
+
+// y [B][h3][h3][32] = conv3(relu(conv2(relu(conv1(x))))) of SimpleDepthCNN; w1f / w2f: the 4x4 and 3x3 weights ([64][512], [32][576], k = (kh*KW + kw)*Cin + ci)
+// in fragment order (launch_pack_frag)
+hipError_t launch_simplecnn3(const float* x, const void* w0, const float* b0, const void* w1f, const float* b1, const void* w2f, const float* b2, void* y,
+                             int dt, int B, int H, hipStream_t s) {
+    if (!simplecnn3_ok(dt, H) || B < 1) return hipErrorInvalidValue;
+    SimpleCnn3Dev p;
+    p.x = x; p.w0 = w0; p.b0 = b0; p.w1f = w1f; p.b1 = b1; p.w2f = w2f; p.b2 = b2; p.y = y;
+    p.H = H; p.h1 = (H - 8) / 4 + 1; p.h2 = (p.h1 - 4) / 2 + 1; p.h3 = p.h2 - 2; p.bands = (p.h3 + S3_N3 - 1) / S3_N3;
+    const size_t lds = s3_lds_bytes(H, p.h1, p.h2);
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(simplecnn3_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(simplecnn3_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
+    }
+    if (dt == DT_BF16) hipLaunchKernelGGL(simplecnn3_kernel<bf16>, dim3(B * p.bands), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(simplecnn3_kernel<f16>, dim3(B * p.bands), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 bool depth_conv8x8s4_ok(int dt, int H, int act) {
     return (dt == DT_BF16 || dt == DT_F16) && H >= 8 && H % 4 == 0 && (size_t)S_ROWS * H * 2 <= 64 * 1024 && (act == ACT_NONE || act == ACT_RELU);
 }

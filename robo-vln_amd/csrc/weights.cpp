@@ -263,6 +263,23 @@ static ConvW make_conv(int dt, Uploader& up, const HostTensor& w, const std::vec
     return c;
 }
 
+// conv weight OIHW -> [O][K] rows with k = (kh*KW+kw)*I + ci as make_conv lays them out, then in MFMA-FRAGMENT order (device twin: pack_frag_kernel,
+// bert_block.hip): the 16-byte chunk W[ct*16 + fr][ks*32 + fg*8 ..] at chunk index (ks*(O/16) + ct)*64 + fg*16 + fr.  O % 16 == 0, K % 32 == 0.
+static void* make_conv_frag(int dt, Uploader& up, const HostTensor& w) {
+    const int O = (int)w.shape[0], I = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3], K = KH * KW * I;
+    if (O % 16 || K % 32) return nullptr;
+    std::vector<float> fo((size_t)O * K);
+    for (int ks = 0; ks < K / 32; ++ks)
+        for (int ct = 0; ct < O / 16; ++ct)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int o = ct * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + e;
+                    const int tap = k / I, ci = k - tap * I, kh = tap / KW, kw = tap - kh * KW;
+                    fo[(((size_t)ks * (O / 16) + ct) * 64 + l) * 8 + e] = w.f[(((size_t)o * I + ci) * KH + kh) * KW + kw];
+                }
+    return up.typed(fo, dt);
+}
+
 // eval-mode BatchNorm2d folded into the preceding bias-free conv: y = conv(x)*g/sqrt(v+eps) + (b - m*g/sqrt(v+eps))
 static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias, bool stem = false);
 static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn, bool stem = false) {
@@ -656,6 +673,10 @@ static SimpleCnnW make_simple_cnn(hcm_ctx* ctx, int dt, Uploader& up, int model,
     }
     s.c1 = make_conv(dt, up, T_(ctx, model, pre + "cnn.2.weight"), nullptr, &T_(ctx, model, pre + "cnn.2.bias").f);
     s.c2 = make_conv(dt, up, T_(ctx, model, pre + "cnn.4.weight"), nullptr, &T_(ctx, model, pre + "cnn.4.bias").f);
+    if (dt != DT_F32 && cin == 1 && s.c0_packed.w) {
+        s.c1_frag = make_conv_frag(dt, up, T_(ctx, model, pre + "cnn.2.weight"));
+        s.c2_frag = make_conv_frag(dt, up, T_(ctx, model, pre + "cnn.4.weight"));
+    }
     // Flatten() of the NCHW (B,32,h,w) tensor: source column c*S + s; ours is NHWC: s*32 + c
     const int S = s.h3 * s.w3;
     std::vector<int> perm((size_t)S * 32);
@@ -735,6 +756,20 @@ void prepare_high(hcm_ctx* ctx) {
         L.qkv = make_linear(up, {&T_(ctx, M, p + "attention.self.query.weight"), &T_(ctx, M, p + "attention.self.key.weight"), &T_(ctx, M, p + "attention.self.value.weight")},
                             {&T_(ctx, M, p + "attention.self.query.bias"), &T_(ctx, M, p + "attention.self.key.bias"), &T_(ctx, M, p + "attention.self.value.bias")}, ctx->dt_bert);
         L.o = make_linear(up, {&T_(ctx, M, p + "attention.output.dense.weight")}, {&T_(ctx, M, p + "attention.output.dense.bias")}, ctx->dt_bert);
+        static const bool want_frag = dev_env("HCM_BERT_FUSE") != nullptr;      // (development build: the fused attention-block experiment, forward.cpp bert())
+        if (want_frag && (ctx->dt_bert == DT_F16 || ctx->dt_bert == DT_BF16) && L.o.N % 16 == 0 && L.o.K % 32 == 0 && L.o.K == L.o.Kp) {
+            // the same values in MFMA-fragment order (bert_block.hip phase B; device twin: pack_frag_kernel): chunk of 8 at
+            // ((ks * (N / 16) + ct) * 64 + fg * 16 + fr) * 8  <-  W[ct * 16 + fr][ks * 32 + fg * 8 ..]
+            const std::vector<float>& wsrc = T_(ctx, M, p + "attention.output.dense.weight").f;
+            const int N = L.o.N, K = L.o.K;
+            std::vector<float> fo((size_t)N * K);
+            for (int ks = 0; ks < K / 32; ++ks)
+                for (int ct = 0; ct < N / 16; ++ct)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e)
+                            fo[(((size_t)ks * (N / 16) + ct) * 64 + l) * 8 + e] = wsrc[(size_t)(ct * 16 + (l & 15)) * K + ks * 32 + (l >> 4) * 8 + e];
+            L.o_frag = up.typed(fo, ctx->dt_bert);
+        }
         L.ln1 = make_norm(ctx, up, M, p + "attention.output.LayerNorm");
         L.ff1 = make_linear(up, {&T_(ctx, M, p + "intermediate.dense.weight")}, {&T_(ctx, M, p + "intermediate.dense.bias")}, ctx->dt_bert);
         L.ff2 = make_linear(up, {&T_(ctx, M, p + "output.dense.weight")}, {&T_(ctx, M, p + "output.dense.bias")}, ctx->dt_bert);

@@ -34,11 +34,13 @@ def sinusoid_table(L, d):
 class DepthCnnVlaProbe:
     """cnn_sd: SimpleDepthCNN state_dict (keys cnn.{0,2,4,7}.{weight,bias}); vla_sd: Visual_Ling_Attn state_dict (N = 1)."""
 
-    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="fp16", device="cuda", graph=False, fused_layer=True, overlap=True):
+    def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="fp16", device="cuda", graph=False, fused_layer=True, overlap=True,
+                 fused_cnn=True):
         """graph=True: forward() is captured once per batch size into a hipGraph (torch.cuda.CUDAGraph over the library's launches on
         the capture stream) with engine-owned static input / output buffers, and replayed: the ~16 dependent launches then cost one."""
         self._graph = bool(graph)
         self._unfused = not fused_layer                 # launch-per-op cross-modal layer (A/B and test aid)
+        self._fused_cnn = bool(fused_cnn)               # the three convolutions in one launch (hcm_op_simplecnn3); False: launch per conv (A/B and test aid)
         self._overlap = bool(overlap)                   # instruction branch on a second stream
         self._side = torch.cuda.Stream() if overlap else None
         self._graphs = {}
@@ -59,6 +61,13 @@ class DepthCnnVlaProbe:
         self.c0_plain = W(w0)                               # [32][64]: the packed-frame path of the 16-bit builds
         self.c1, self.b1 = W(g(cnn_sd, "cnn.2.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.2.bias"))
         self.c2, self.b2 = W(g(cnn_sd, "cnn.4.weight").transpose(0, 2, 3, 1)), F32(g(cnn_sd, "cnn.4.bias"))
+        # the 4x4 and 3x3 weights once more in MFMA-fragment order, for the one-launch form of the three convolutions
+        self.c1f = self.c2f = None
+        if self.tdt != torch.float32 and self._fused_cnn and depth_hw % 4 == 0 and depth_hw <= 256:
+            self.c1f, self.c2f = torch.empty_like(self.c1), torch.empty_like(self.c2)
+            self._ck(self.lib.hcm_op_pack_frag(_p(self.c1), _p(self.c1f), self.code, 64, 512, None))
+            self._ck(self.lib.hcm_op_pack_frag(_p(self.c2), _p(self.c2f), self.code, 32, 576, None))
+            torch.cuda.synchronize()
         h1 = (depth_hw - 8) // 4 + 1
         h2 = (h1 - 4) // 2 + 1
         h3 = h2 - 3 + 1
@@ -154,17 +163,25 @@ class DepthCnnVlaProbe:
                 I = self._ln(self._lin(ins.reshape(rows, -1), self.ins_fc, rows, act=L_.ACT_RELU), self.ln, rows, self.pe, self.L)
         else:
             I = self._ln(self._lin(ins.reshape(rows, -1), self.ins_fc, rows, act=L_.ACT_RELU), self.ln, rows, self.pe, self.L)
-        y0 = e(B, self.h1, self.h1, 32)
-        if self.tdt != torch.float32 and self.hw % 4 == 0:
+        y2 = None
+        if self.c1f is not None:
+            y2 = e(B, self.h3, self.h3, 32)
+            self._ck(lib.hcm_op_simplecnn3(_p(depth), _p(self.c0_plain), _p(self.b0), _p(self.c1f), _p(self.b1), _p(self.c2f), _p(self.b2), _p(y2), code, B,
+                                           self.hw, self._st()))
+        y0 = e(B, self.h1, self.h1, 32) if y2 is None else None
+        if y2 is not None:
+            pass
+        elif self.tdt != torch.float32 and self.hw % 4 == 0:
             scratch = e(B * self.hw * self.hw + 64)
             self._ck(lib.hcm_op_depth_conv8x8s4(_p(depth), _p(self.c0_plain), _p(self.b0), _p(y0), code, B, self.hw, L_.ACT_RELU, _p(scratch), self._st()))
         else:
             self._ck(lib.hcm_op_stem_conv(_p(depth), L_.HCM_F32, _p(self.c0), _p(self.b0), _p(y0), code, B, self.hw, self.hw, 1, 32, 8, 8, 4, 0,
                                           self.c0_k, self.c0_kp, 0, 1.0, L_.ACT_RELU, self._st()))
-        y1 = e(B, self.h2, self.h2, 64)
-        self._ck(lib.hcm_op_conv2d(_p(y0), _p(self.c1), _p(self.b1), None, _p(y1), code, B, self.h1, self.h1, 32, 64, 4, 4, 2, 0, L_.ACT_RELU, self._st()))
-        y2 = e(B, self.h3, self.h3, 32)
-        self._ck(lib.hcm_op_conv2d(_p(y1), _p(self.c2), _p(self.b2), None, _p(y2), code, B, self.h2, self.h2, 64, 32, 3, 3, 1, 0, L_.ACT_NONE, self._st()))
+        if y2 is None:
+            y1 = e(B, self.h2, self.h2, 64)
+            self._ck(lib.hcm_op_conv2d(_p(y0), _p(self.c1), _p(self.b1), None, _p(y1), code, B, self.h1, self.h1, 32, 64, 4, 4, 2, 0, L_.ACT_RELU, self._st()))
+            y2 = e(B, self.h3, self.h3, 32)
+            self._ck(lib.hcm_op_conv2d(_p(y1), _p(self.c2), _p(self.b2), None, _p(y2), code, B, self.h2, self.h2, 64, 32, 3, 3, 1, 0, L_.ACT_NONE, self._st()))
         tok = self._lin(y2, (self.fc, self.fcb), B, act=L_.ACT_RELU)                 # (B, 128): the one visual token
         V = self._ln(self._lin(tok, self.vis_fc, B, act=L_.ACT_RELU), self.ln, B)     # (B, 1, d)
         if side is not None:

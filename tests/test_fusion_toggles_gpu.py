@@ -27,7 +27,7 @@ cfg = HCMConfig(rgb_hw=128, depth_hw=int(os.environ.get("HCMT_DEPTH_HW", "128"))
                 vla_layers=int(os.environ.get("HCMT_VLA_LAYERS", "1")), bert_layers=1).validate()
 B = 3
 hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
-eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision="fp16", graph=False)
+eng = HCMEngine(cfg, hi_sd, lo_sd, max_batch=B, precision=os.environ.get("HCMT_PREC", "fp16"), graph=False)
 obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=5).items()}
 if os.environ.get("HCMT_RAGGED"):
     obs["instruction_lengths"] = torch.tensor([cfg.instr_len, 3, cfg.instr_len // 2], dtype=torch.int32).cuda()
@@ -171,3 +171,81 @@ def test_deep_ring_pipelined_loop_equals_the_read_then_multiply_loop(env):
     for k in ("rec", "hh", "lh"):
         assert np.array_equal(a[k], b[k]), k
     assert np.isfinite(a["rec"]).all()
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                            # L = 20: one workgroup per sample, ragged last row tile
+    {"HCMT_L": "80"},                                              # the benchmark length: two workgroups per sample (48 + 32 rows)
+    {"HCMT_L": "37", "HCMT_RAGGED": "1"},                          # per-environment token counts (keys limited per sample)
+    {"HCMT_L": "80", "HCMT_PREC": "bf16"},                         # the f32 residual stream form of the "bf16" mode
+    {"HCMT_L": "96", "HCMT_RAGGED": "1", "HCMT_PREC": "bf16"},
+])
+def test_fused_bert_block_equals_the_three_launches(env):
+    """Round 5 experiment (development build, HCM_BERT_FUSE=1; measured slower than the launches it replaces and therefore off by default):
+    attention + output projection + residual + LayerNorm of every BERT layer as ONE launch (csrc/bert_block.hip) -- the same f32 operations in the
+    same order as attention_mfma_kernel + igemm_dma_kernel + layernorm_vec_kernel (layernorm_f32in_kernel in the bf16 mode), so a whole step with it
+    must equal the default step to the bit."""
+    with tempfile.TemporaryDirectory() as d:
+        fused = _run(dict(env, HCM_BERT_FUSE="1"), os.path.join(d, "a.npz"))
+        plain = _run(dict(env), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(fused[k], plain[k]), (k, np.abs(fused[k] - plain[k]).max())
+    assert np.isfinite(fused["rec"]).all()
+
+
+def test_probe_with_the_three_convolutions_in_one_launch_equals_the_launch_per_conv_form():
+    """configs[3]'s probe (robo-vln_amd/probe.py) with SimpleDepthCNN's three convolutions as ONE launch (hcm_op_simplecnn3, the default) against
+    the launch-per-conv form: the same bits, at the BASELINE frame size and at a small one."""
+    import torch
+    from robo_vln_amd import synth
+    from robo_vln_amd.config import HCMConfig
+    from robo_vln_amd.probe import DepthCnnVlaProbe
+    for hw, B in ((256, 5), (128, 3)):
+        cfg = HCMConfig(vla_layers=1).validate()
+        cnn_sd = synth.materialize(synth.simple_cnn_spec("", 1, hw, 128), "probe_cnn", 0)
+        vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
+        rng = np.random.default_rng(0)
+        depth = torch.from_numpy(rng.random((B, hw, hw, 1), dtype=np.float32)).cuda()
+        ins = torch.from_numpy(rng.standard_normal((B, cfg.instr_len, 768), dtype=np.float32)).cuda().half()
+        outs = []
+        for fused in (True, False):
+            pr = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=hw, instr_len=cfg.instr_len, precision="fp16", fused_cnn=fused)
+            assert (pr.c1f is not None) == fused
+            outs.append(pr.forward(depth, ins).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
+def test_low_level_model_with_simplecnn_depth_encoder_fused_equals_launches():
+    """The model path (forward.cpp simple_cnn: Seq2Seq_LowLevel with SimpleDepthCNN, the only reference model that accepts it,
+    seq2seq_lowlevel.py:46-49) with the one-launch form of the three convolutions against HCM_NO_CNN3=1 -- the same bits."""
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import hcm_pkg; hcm_pkg.load()
+from robo_vln_amd import synth
+from robo_vln_amd.config import HCMConfig
+from robo_vln_amd.policy import HCMEngine
+cfg = HCMConfig(rgb_hw=128, depth_hw=256, depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN").validate()
+B = 3
+lo_sd = synth.materialize(synth.low_level_spec(cfg), "lo", 5)
+eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="fp16", graph=False)
+obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_observations(cfg, B, step=0, seed=5).items()}
+R = cfg.num_recurrent_layers
+lh = torch.zeros(R, B, cfg.hidden, device="cuda")
+vel, stop, lh2 = eng.low_forward(obs, lh, torch.zeros(B, device="cuda"), torch.tensor([0, 2, 3], device="cuda"))
+torch.cuda.synchronize()
+np.savez(sys.argv[1], rec=vel.cpu().numpy(), hh=stop.cpu().numpy(), lh=lh2.cpu().numpy())
+eng.close()
+""" % ROOT
+    def run(env_extra, path):
+        env = dict(os.environ, HCM_DEV_LIB="1")
+        env.update(env_extra)
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, cwd=ROOT, timeout=600)
+        return dict(np.load(path))
+    with tempfile.TemporaryDirectory() as d:
+        fused = run({}, os.path.join(d, "a.npz"))
+        plain = run({"HCM_NO_CNN3": "1"}, os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(fused[k], plain[k]), k
+    assert np.isfinite(fused["rec"]).all()

@@ -150,6 +150,54 @@ def test_attention(prec, cfg):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(64, 80), (3, 80), (1, 20), (5, 7), (2, 96), (9, 33), (2, 48), (4, 49)])
+def test_bert_attn_block_equals_the_three_launches(prec, cfg):
+    """hcm_op_bert_attn_block (attention + output projection + residual + LayerNorm of a BERT layer in ONE launch, csrc/bert_block.hip) against the
+    three operators it replaces -- bit for bit, every (B, L) incl. ragged last row tiles and one / two workgroups per sample, output in place
+    on the residual -- and against the plain torch fp32 arithmetic (BertSelfAttention + BertSelfOutput, seq2seq_highlevel_cma.py:192-195)."""
+    lib, L_ = _lib()
+    code, tdt, tol = DT[prec]
+    B, L = cfg
+    D = 768
+    dev = "cuda"
+    qkv = (_rnd(B * L, 3 * D, scale=2.0)).to(tdt)
+    qkv[:, 2 * D:] *= 0.5
+    wo = (_rnd(D, D, seed=1) * (3.0 / D) ** 0.5).to(tdt)
+    bo = _rnd(D, seed=2) * 0.1
+    res = _rnd(B * L, D, seed=3).to(tdt)
+    gamma = _rnd(D, seed=4) * 0.5 + 1.0
+    beta = _rnd(D, seed=5) * 0.1
+    qd, wd, bd, rd, gd, btd = qkv.to(dev), wo.to(dev), bo.to(dev), res.to(dev), gamma.to(dev), beta.to(dev)
+    # the three launches
+    ctx = torch.empty(B * L, D, device=dev, dtype=tdt)
+    assert lib.hcm_op_attention(_p(qd), C.c_void_p(qd.data_ptr() + D * 2), C.c_void_p(qd.data_ptr() + 2 * D * 2), _p(ctx), code, B, 12, L, L,
+                                3 * D, 3 * D, 3 * D, D, None) == 0
+    tmp = torch.empty(B * L, D, device=dev, dtype=tdt)
+    assert lib.hcm_op_linear(_p(ctx), _p(wd), _p(bd), _p(rd), _p(tmp), code, B * L, D, D, 0, 0, None) == 0
+    want = torch.empty(B * L, D, device=dev, dtype=tdt)
+    assert lib.hcm_op_layernorm(_p(tmp), None, _p(gd), _p(btd), _p(want), code, B * L, D, 1e-12, None) == 0
+    # one launch, in place on the residual stream like bert() runs it
+    got = rd.clone()
+    wf = torch.empty_like(wd)
+    assert lib.hcm_op_pack_frag(_p(wd), _p(wf), code, D, D, None) == 0
+    # (the fragment order, element for element: chunk (ks * 48 + ct) * 64 + fg * 16 + fr  <-  W[ct * 16 + fr][ks * 32 + fg * 8 ..])
+    torch.cuda.synchronize()
+    assert torch.equal(wf.view(24, 48, 4, 16, 8).cpu().view(torch.int16), wo.view(48, 16, 24, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(torch.int16))
+    assert lib.hcm_op_bert_attn_block(_p(qd), _p(wf), _p(bd), _p(got), None, _p(gd), _p(btd), _p(got), None, code, B, L, None, 1e-12, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (got.float() - want.float()).abs().max().item()
+    # and the arithmetic itself
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, L, 12, 64).transpose(1, 2) for i in range(3))
+    att = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * L, D)
+    ref = F.layer_norm(att @ wo.float().t() + bo + res.float(), (D,), gamma, beta, 1e-12)
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= 4 * tol, err
+    # unsupported shapes are refused, not mis-computed
+    assert lib.hcm_op_bert_attn_block(_p(qd), _p(wf), _p(bd), _p(got), None, _p(gd), _p(btd), _p(got), None, code, 1, 97, None, 1e-12, None) != 0
+    assert lib.hcm_op_bert_attn_block(_p(qd), _p(wf), _p(bd), _p(got), None, _p(gd), _p(btd), _p(got), None, 0, B, L, None, 1e-12, None) != 0
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("D", [768, 256])
 def test_layernorm(prec, D):
@@ -695,3 +743,47 @@ def test_depth_conv8x8s4_direct(prec, cfg):
     err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), err
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(3, 256), (1, 128), (5, 64), (2, 100), (2, 36), (7, 192)])
+def test_simplecnn3_equals_the_three_launches(prec, cfg):
+    """hcm_op_simplecnn3 (SimpleDepthCNN's Conv 8x8/4 + ReLU -> Conv 4x4/2 + ReLU -> Conv 3x3/1 in ONE launch, both intermediate maps in LDS:
+    csrc/simplecnn.hip) against hcm_op_depth_conv8x8s4 + hcm_op_conv2d x 2 -- bit for bit, full bands and a ragged last band, frames of several
+    sizes -- and against torch's fp32 convolutions (models/encoders/simple_cnns.py:76-100)."""
+    lib, L_ = _lib()
+    code, tdt, tol = DT[prec]
+    B, H = cfg
+    dev = "cuda"
+    h1 = (H - 8) // 4 + 1
+    h2 = (h1 - 4) // 2 + 1
+    h3 = h2 - 2
+    x = (_rnd(B, H, H, 1) * 0.5 + 0.5)
+    w0 = (_rnd(32, 1, 8, 8, seed=1) * (3.0 / 64) ** 0.5).to(tdt)
+    w1 = (_rnd(64, 32, 4, 4, seed=2) * (3.0 / 512) ** 0.5).to(tdt)
+    w2 = (_rnd(32, 64, 3, 3, seed=3) * (3.0 / 576) ** 0.5).to(tdt)
+    b0, b1, b2 = _rnd(32, seed=4) * 0.1, _rnd(64, seed=5) * 0.1, _rnd(32, seed=6) * 0.1
+    xd = x.to(dev)
+    w0d = w0.reshape(32, 64).to(dev)
+    w1d = w1.permute(0, 2, 3, 1).contiguous().to(dev)              # OHWI
+    w2d = w2.permute(0, 2, 3, 1).contiguous().to(dev)
+    b0d, b1d, b2d = b0.to(dev), b1.to(dev), b2.to(dev)
+    y0 = torch.empty(B, h1, h1, 32, device=dev, dtype=tdt)
+    scratch = torch.empty(B * H * H + 64, device=dev, dtype=tdt)
+    assert lib.hcm_op_depth_conv8x8s4(_p(xd), _p(w0d), _p(b0d), _p(y0), code, B, H, 1, _p(scratch), None) == 0
+    y1 = torch.empty(B, h2, h2, 64, device=dev, dtype=tdt)
+    assert lib.hcm_op_conv2d(_p(y0), _p(w1d), _p(b1d), None, _p(y1), code, B, h1, h1, 32, 64, 4, 4, 2, 0, 1, None) == 0
+    want = torch.empty(B, h3, h3, 32, device=dev, dtype=tdt)
+    assert lib.hcm_op_conv2d(_p(y1), _p(w2d), _p(b2d), None, _p(want), code, B, h2, h2, 64, 32, 3, 3, 1, 0, 0, None) == 0
+    w1f, w2f = torch.empty_like(w1d), torch.empty_like(w2d)
+    assert lib.hcm_op_pack_frag(_p(w1d), _p(w1f), code, 64, 512, None) == 0
+    assert lib.hcm_op_pack_frag(_p(w2d), _p(w2f), code, 32, 576, None) == 0
+    got = torch.full((B, h3, h3, 32), float("nan"), device=dev, dtype=tdt)
+    assert lib.hcm_op_simplecnn3(_p(xd), _p(w0d), _p(b0d), _p(w1f), _p(b1d), _p(w2f), _p(b2d), _p(got), code, B, H, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (got.float() - want.float()).abs().max().item()
+    xr = x.permute(0, 3, 1, 2).to(tdt).float()
+    ref = F.conv2d(F.relu(F.conv2d(F.relu(F.conv2d(xr, w0.float(), b0, stride=4)), w1.float(), b1, stride=2)), w2.float(), b2)
+    err = (got.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 3 * tol, err
+    assert lib.hcm_op_simplecnn3(_p(xd), _p(w0d), _p(b0d), _p(w1f), _p(b1d), _p(w2f), _p(b2d), _p(got), 0, B, H, None) != 0      # f32: refused
