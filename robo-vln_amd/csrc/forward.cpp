@@ -558,7 +558,7 @@ struct Fwd {
         // to the launches below; HCM_NO_CNN3=1 of the development build: the launches)
         static const bool no_cnn3 = dev_env("HCM_NO_CNN3") != nullptr;
         if (!no_cnn3 && w.cin == 1 && x_dt == DT_F32 && H == W && w.c1_frag && w.c2_frag && w.c0_packed.w && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 &&
-            simplecnn3_ok(dt, H) && !ctx->taps_on) {
+            simplecnn3_ok(dt, H)) {
             void* y2f = alloc_t((size_t)B * h3 * w3 * 32);
             if (!dry) ck(launch_simplecnn3((const float*)x, w.c0_packed.w, w.c0_packed.bias, w.c1_frag, w.c1.bias, w.c2_frag, w.c2.bias, y2f, dt, B, H, s),
                          "simple cnn (three convolutions, one launch)");
