@@ -6,7 +6,7 @@ active_cycles = GRBM_GUI_ACTIVE / 8 XCDs MINUS the per-dispatch idle offset of t
 Why the offset (round-4 review, item 9): under per-dispatch counter collection GRBM_GUI_ACTIVE also counts the time the profiler holds the
 queue around the kernel (counter start / stop, ~10 us), so `busy / GUI` under-read every SHORT kernel (gemm256f: 23 % reported, 32 % from the
 exact MFMA count over the kernel's own duration) while long kernels were right.  The offset is not a constant of the chip, so it is FITTED from
-the file itself: GUI/8 = clock x duration + offset over all dispatches (least squares, two passes with outlier rejection); every dispatch then
+the file itself: GUI/8 = clock x duration + offset, the clock from the long dispatches and the offset from the short ones (medians, iterated); every dispatch then
 uses its OWN clock, (GUI/8 - offset) / duration, so DVFS differences between kernels stay in.  The fit is printed; `--selfcheck` asserts that a
 `mfma_only<8>` dispatch of tools/mfma_calib.py in the same file (a kernel of nothing but back-to-back MFMAs: 16 busy cycles per 16.8-cycle issue
 slot = 95 %) reads 90-100 %.
@@ -26,29 +26,27 @@ steps = int(args[1]) if len(args) > 1 else 4
 pts = [(d["t"], d["GRBM_GUI_ACTIVE"] / 8.0) for d in disp.values() if d.get("GRBM_GUI_ACTIVE", 0) > 0 and d["t"] > 0]
 
 
-def fit(p):
-    n = len(p)
-    sx = sum(x for x, _ in p); sy = sum(y for _, y in p); sxx = sum(x * x for x, _ in p); sxy = sum(x * y for x, y in p)
-    den = n * sxx - sx * sx
-    if n < 2 or den == 0:
-        return (sy / sx if sx else 2000.0), 0.0
-    slope = (n * sxy - sx * sy) / den
-    return slope, (sy - slope * sx) / n
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else None
 
 
-slope, off = fit(pts)                                     # cycles per us (= MHz), cycles
-keep = [(x, y) for x, y in pts if abs(y - (slope * x + off)) <= 0.25 * (slope * x + off)]
-if len(keep) >= max(8, len(pts) // 2):
-    slope, off = fit(keep)
-off = max(off, 0.0)
+# clock from the LONG dispatches (>= 100 us: the hold is a few per cent of them), offset from the SHORT ones (< 30 us: mostly hold), iterated; a plain
+# least-squares line through everything is pulled around by the few long kernels of a calibration run
+longs = [(x, y) for x, y in pts if x >= 100.0] or pts
+shorts = [(x, y) for x, y in pts if x < 30.0]
+slope, off = 2000.0, 0.0
+for _ in range(4):
+    slope = median([(y - off) / x for x, y in longs]) or slope
+    off = max(median([y - slope * x for x, y in shorts]) or 0.0, 0.0)
 rows = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0, 0.0])
 for d in disp.values():
-    n = d["name"].replace("void hcm::", "").replace("hcm::", "").split("(")[0][:64]
+    n = d["name"].replace("void ", "").replace("hcm::", "").replace("(anonymous namespace)::", "").split("(")[0][:64]
     gui = d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     act = max(gui - off, 0.5 * slope * d["t"])            # never below half the fitted clock x duration (a dispatch the fit does not describe)
     a = rows[n]
     a[0] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0); a[1] += act; a[2] += 1; a[3] += d["t"]; a[4] += gui
-print(f"fit over {len(pts)} dispatches: GRBM_GUI_ACTIVE/8 = {slope:.0f} cycles/us x duration + {off:.0f} cycles "
+print(f"fit over {len(pts)} dispatches ({len(longs)} long, {len(shorts)} short): GRBM_GUI_ACTIVE/8 = {slope:.0f} cycles/us x duration + {off:.0f} cycles "
       f"(= {off / slope:.1f} us of profiler hold per dispatch at {slope / 1e3:.2f} GHz)\n")
 print("| kernel | launches/step | us/launch (under counters) | MFMA busy % of SIMD-cycles (offset-corrected) | uncorrected busy / GUI % | clock GHz |\n|---|---|---|---|---|---|")
 tot_b = tot_c = 0.0
