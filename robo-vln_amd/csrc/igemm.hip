@@ -3209,9 +3209,14 @@ static hipError_t launch_igemm_impl(const IGemm& g, int dt, hipStream_t s) {
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
 #endif
     if ((g.impl & 15) == 2) return launch_gemm256(g, dt, s);
+    if ((g.impl & 15) == 3) return launch_skinny(g, dt, s);
     if (g.impl == 0) {
         static const bool no256 = dev_env("HCM_NO_GEMM256") != nullptr;
         if (!no256 && gemm256_applicable(g, dt)) return launch_gemm256(g, dt, s);
+        // few rows (round 5): a wave per 16 x 16 output tile, operands straight into registers (skinny.hip; bit-identical).  HCM_NO_SKINNY=1
+        // (development build): the implicit-GEMM tiles, for the A/B and the toggle test
+        static const bool no_skinny = dev_env("HCM_NO_SKINNY") != nullptr;
+        if (!no_skinny && g.force_choice < 0 && skinny_applicable(g, dt)) return launch_skinny(g, dt, s);
     }
     IGemmDev d;
     d.x = (const char*)g.x; d.w = (const char*)g.w; d.bias = g.bias; d.res = (const char*)g.res; d.y = (char*)g.y;

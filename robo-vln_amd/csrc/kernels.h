@@ -91,12 +91,15 @@ struct IGemm {
     int force_gemm256 = 0;       // 1: gemm256f_kernel whatever the row count (layout constraints only; the folded-LayerNorm consumers)
     int force_choice = -1;       // >= 0: launch_igemm's (tile, staging variant) choice for this launch (the folded-LayerNorm producers)
     const float* rln_stats = nullptr; const float* rln_gamma = nullptr; const float* rln_beta = nullptr;
-    int impl = 0;                // 0: launch_igemm chooses; 1: igemm_dma_kernel / igemm_kernel only; 2: the 256 x 256-tile kernel of gemm256.hip only
+    int impl = 0;                // 0: launch_igemm chooses; 1: igemm_dma_kernel / igemm_kernel only; 2: the 256 x 256-tile kernel of gemm256.hip only; 3: the few-row kernel of skinny.hip only
 };
 hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s);
 bool igemm_gnin_ok(const IGemm& g, int dt);          // can launch_igemm take this conv with a GroupNorm-on-load operand (gi_*)?
 // 256 x 256-tile, 8-phase GEMM for wide token-major linear layers (gemm256.hip); bit-identical to launch_igemm's kernels
 bool gemm256_applicable(const IGemm& g, int dt);
+// few-row GEMM, a wave per 16 x 16 output tile with its operands straight from L2 into registers (skinny.hip); bit-identical to launch_igemm's kernels
+bool skinny_applicable(const IGemm& g, int dt);
+hipError_t launch_skinny(const IGemm& g, int dt, hipStream_t s);
 hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s);
 hipError_t gemm256_prof_read(unsigned long long* host, bool reset);   // phase counters of the profiled 256 x 256 GEMM builds: [16 workgroups][8 waves][8]
 // Fused 3x3 conv (C1 -> C1, bias, ReLU) + 1x1 expansion (C1 -> 4*C1, bias, + identity, ReLU) of a BN-folded bottleneck, 16-bit types,

@@ -193,6 +193,26 @@ def test_fused_bert_block_equals_the_three_launches(env):
     assert np.isfinite(fused["rec"]).all()
 
 
+@pytest.mark.parametrize("env", [
+    {},                                                            # B = 3, L = 20: 60 token rows, every linear layer of the step is a few-row launch
+    {"HCMT_L": "80"},                                              # 240 rows: four row fragments per wave
+    {"HCMT_L": "37", "HCMT_RAGGED": "1"},
+    {"HCMT_L": "80", "HCMT_PREC": "bf16"},                         # f32 residual stream: f32 residual in, f32 sum out
+    {"HCMT_L": "80", "HCMT_PREC": "fp32"},
+    {"HCMT_DEPTH_HW": "256", "HCMT_L": "80", "HCMT_VLA_LAYERS": "2"},
+])
+def test_few_row_gemm_equals_the_implicit_gemm_tiles(env):
+    """Round 5: linear layers and 1 x 1 convolutions of at most 320 rows run on skinny_kernel (csrc/skinny.hip: a wave per 16 x 16 output tile, operands
+    straight into registers) instead of the 64-row implicit-GEMM tiles -- the same MFMA instruction over the same k order and the same epilogue
+    operations, so a whole step must equal the step with HCM_NO_SKINNY=1 to the bit."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_SKINNY="1"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+    assert np.isfinite(a["rec"]).all()
+
+
 def test_probe_with_the_three_convolutions_in_one_launch_equals_the_launch_per_conv_form():
     """configs[3]'s probe (robo-vln_amd/probe.py) with SimpleDepthCNN's three convolutions as ONE launch (hcm_op_simplecnn3, the default) against
     the launch-per-conv form: the same bits, at the BASELINE frame size and at a small one."""

@@ -643,6 +643,73 @@ def test_gemm256_bit_identical_to_igemm(prec, shape, act, with_res):
         assert torch.equal(y, outs[1])
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape,act,with_res,out_f32", [
+    ((80, 2304, 768), 0, False, 0),      # BERT QKV of one environment (L = 80): one row fragment per wave, two request rounds
+    ((80, 3072, 768), 2, False, 0),      # FFN1 + GELU
+    ((80, 768, 3072), 0, True, 0),       # FFN2: eight rounds, residual
+    ((20, 768, 768), 0, True, 0),        # configs[0] instruction length: ragged row fragment
+    ((7, 36, 40), 1, False, 0),          # everything ragged: 7 rows, N = 36 (the third channel fragment is a quarter wide), K = 40
+    ((160, 768, 768), 0, True, 0),       # two environments: two row fragments per wave
+    ((320, 3072, 768), 2, False, 0),     # four environments: four row fragments per wave
+    ((300, 260, 1064), 1, True, 0),      # ragged at four fragments per wave, K not a multiple of the k step
+    ((64, 2048, 896), 0, False, 1),      # the LSTM gate product of a 64-environment step (f32 out)
+    ((64, 2048, 512), 0, True, 1),       # its late half: accumulates onto the early half
+    ((1, 2048, 896), 0, False, 1),       # one environment
+])
+def test_skinny_bit_identical_to_igemm(prec, shape, act, with_res, out_f32):
+    """The few-row kernel (csrc/skinny.hip: a wave per 16 x 16 output tile, operands straight from L2 into registers) against the implicit-GEMM
+    tiles it replaces for M <= 320: same MFMA instruction, same k order, same epilogue operations -- equal bit for bit, so a row's value does not
+    depend on the row count of the call that computed it; and right, vs torch fp32."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    M, N, K = shape
+    if out_f32 and prec != "fp32":
+        pytest.skip("f32 output with a 16-bit residual is not a combination the step uses")
+    x = _rnd(M, K, seed=5).to(tdt)
+    w = (_rnd(N, K, seed=6) * (3.0 / K) ** 0.5).to(tdt)
+    bias = _rnd(N, seed=7)
+    res = _rnd(M, N, seed=8).to(tdt) if with_res else None
+    ref = x.float() @ w.float().t() + bias + (res.float() if with_res else 0.0)
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    rd = res.cuda() if with_res else None
+    odt = torch.float32 if out_f32 else tdt
+    outs = []
+    for impl in (1, 3):
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=odt)
+        rc = lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, M, N, K, act, out_f32, impl, None)
+        assert rc == 0, (impl, rc)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]), (outs[0].float() - outs[1].float()).abs().max().item()
+    err = (outs[1].float().cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+    # the library's own choice for this row count is the few-row kernel (bit-identical either way), and repeated launches do not flicker
+    for _ in range(3):
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=odt)
+        assert lib.hcm_op_linear_impl(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), code, M, N, K, act, out_f32, 0, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, outs[1])
+
+
+def test_skinny_row_value_does_not_depend_on_the_batch():
+    """A row computed in a 80-row call (few-row kernel), in a 5120-row call (256 x 256 tiles) and in a 400-row call (implicit-GEMM tiles) has the
+    same bits: hcm_refresh_instruction's contract (BERT recomputed for two environments must reproduce what the full batch computed)."""
+    lib, L = _lib()
+    N, K = 2304, 768
+    x = _rnd(5120, K, seed=5).half().cuda()
+    w = (_rnd(N, K, seed=6) * (3.0 / K) ** 0.5).half().cuda()
+    b = _rnd(N, seed=7).cuda()
+    ys = []
+    for M in (80, 400, 5120):
+        y = torch.empty((M, N), device="cuda", dtype=torch.float16)
+        assert lib.hcm_op_linear_impl(_p(x), _p(w), _p(b), None, _p(y), 5, M, N, K, 2, 0, 0, None) == 0
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert torch.equal(ys[0], ys[2][:80]) and torch.equal(ys[1], ys[2][:400])
+
+
 def test_gemm256_rejects_shapes_it_does_not_cover():
     lib, L = _lib()
     x = torch.zeros(64, 768, device="cuda", dtype=torch.float16)
