@@ -9,11 +9,11 @@ namespace hcm {
 struct bf16 { uint16_t v; };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);     // round to nearest even (inputs are finite)
-    return (uint16_t)(u >> 16);
-}
+// round to nearest even: v_cvt_pk_bf16_f32 (gfx950).  Round 5: rounds 1-4 did this in integer arithmetic (u + 0x7FFF + lsb, >> 16: three VALU
+// operations per element, exact for finite inputs) -- the same bits for every finite value, a quiet NaN for a NaN (the integer form could carry
+// into the sign), and every bf16 epilogue of the library one conversion per element PAIR instead of six operations.
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+typedef __bf16 dev_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct f16 { uint16_t v; };
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -55,10 +55,10 @@ __device__ __forceinline__ void ld_chunk(const bf16* p, float (&o)[8]) {
     }
 }
 __device__ __forceinline__ void st_chunk(bf16* p, const float (&o)[8]) {
-    uint32_t w[4];
+    float8_t f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int i = 0; i < 8; ++i) f[i] = o[i];
+    *reinterpret_cast<dev_bf16x8*>(p) = __builtin_convertvector(f, dev_bf16x8);
 }
 
 __device__ __forceinline__ void ld_chunk(const f16* p, float (&o)[8]) {
@@ -93,10 +93,10 @@ __device__ __forceinline__ void st_chunk(f16* p, const float (&o)[8]) {
 // 8 floats -> 16 bytes of T in registers (one rounding each, as st_chunk)
 template <typename T> __device__ __forceinline__ uint4 pack_chunk(const float (&o)[8]);
 template <> __device__ __forceinline__ uint4 pack_chunk<bf16>(const float (&o)[8]) {
-    uint32_t w[4];
+    float8_t f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    for (int i = 0; i < 8; ++i) f[i] = o[i];
+    return __builtin_bit_cast(uint4, __builtin_convertvector(f, dev_bf16x8));
 }
 template <> __device__ __forceinline__ uint4 pack_chunk<f16>(const float (&o)[8]) {
     float8_t f;
