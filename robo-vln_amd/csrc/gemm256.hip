@@ -34,12 +34,13 @@ namespace hcm {
 typedef float g_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
 typedef int g_v4i __attribute__((ext_vector_type(4)));
+typedef unsigned g_u32x4 __attribute__((ext_vector_type(4)));
 
 struct G256Dev {
     const char* x; const char* w; const float* bias; char* y;
     const char* res; int ldr;        // optional residual [M][ldr] (T), added in f32 before the activation and the one rounding
     int M, N, K, ldx, ldw, ldy, act;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes;
     int tilesM, tilesN, gm, gn;      // XCD grid: the 8 XCDs own gm x gn rectangles of the tile grid (each has a private L2)
     // folded LayerNorm (IGemm::ln_*): x holds the pre-LayerNorm rows u, w = W diag(gamma)
     const float* ln_s; const float* ln_t; float* ln_stats_out; float ln_eps;
@@ -705,6 +706,205 @@ __global__ __launch_bounds__(512) void gemm256f_kernel(G256Dev p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm256f_kernel for tile grids of MORE than one tile per CU -- an EXPERIMENT of round 5 (the review's "give gemm256f_kernel
+// something to overlap its store with"), compiled into `make DEV=1` builds only (HCM_GEMM256_PERSIST=1), bit-identical and SLOWER.
+// The idea: gemm256f_kernel spends ~2.5 us of prologue (one HBM / L2 latency: the first K tile) per TILE with the matrix pipes of its CU idle, and the
+// CU's next workgroup cannot start before this one has released its LDS.  Here a workgroup keeps its CU and walks its XCD's share of the tile grid:
+// BEHIND the K loop of a tile -- both operand buffers are free then -- it requests K tiles 0 and 1 of its NEXT tile and only then runs the epilogue,
+// so the next tile's first operand round trip and the store burst of this one overlap.  That needs the epilogue to stay out of LDS: the register
+// epilogue (igemm_epilogue_regs' swap_pair form: 8 consecutive channels of one token per lane, one 16-byte store; the same f32 operations as
+// g_epilogue).  Counted waits across the two kinds of vector-memory operation: a thread issues EXACTLY 16 epilogue stores (buffer stores; rows /
+// channels past M / N present an offset beyond num_records and are dropped by the hardware instead of being branched around), so behind the epilogue
+// the queue holds [8 + 8 requests of the next tile | 16 stores] and `vmcnt(16)` means "my requests have landed" (vmcnt retires in issue order).
+// MEASURED (tools/gemm256_persist_bench.py, one box, fp16): FFN1 at 20480 rows (960 tiles, four per CU) 126.7 us against 122.3 for the one-tile
+// workgroups, QKV 82.6 against 76.7, 10240 rows 61.1 / 61.3 and 50.1 / 46.0; configs[4] 8.95 against 8.86 ms per step (two interleaved runs each).
+// Why: 122.3 us for four rounds is 30.6 us per round -- what ONE round costs as a launch of its own (31.4 us at 5120 rows).  The dispatcher already
+// refills a CU the moment its workgroup exits, and inside a multi-round launch the rounds of different CUs drift apart, so a tile's prologue
+// latency and store drain already overlap OTHER CUs' loops at the memory system; what the persistent form adds is the register epilogue's
+// half-line stores and a request burst in front of them.  The per-tile cost is not idle-CU time that a longer-lived workgroup could reclaim.
+#ifdef HCM_DEV_KNOBS
+template <typename T, int OPT>
+__global__ __launch_bounds__(512) void gemm256p_kernel(G256Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+    const int m_lo = xm * p.tilesM / p.gm, m_hi = (xm + 1) * p.tilesM / p.gm;
+    const int n_lo = xn * p.tilesN / p.gn, n_hi = (xn + 1) * p.tilesN / p.gn;
+    const int nn = n_hi - n_lo;
+    const int ntl = nn > 0 ? (m_hi - m_lo) * nn : 0;
+    if (slot >= ntl) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int rin = lane >> 3;
+    const int csrc = (lane & 7) ^ rin;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const g_v4i rx = g_make_rsrc(p.x, p.x_bytes);
+    const g_v4i rw = g_make_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+    const unsigned pdst = lds_base + (unsigned)(wave * 32) * 128u;
+
+    // the wave's 8 DMA pieces per K tile: X rows {wave*32 + i*8 .. +8}, W rows likewise (i = 0..3).  ONE offset register per operand (the kernel has
+    // none to spare): piece i adds i * 8 rows; rows past M / N lie beyond the buffers' num_records by themselves (x_bytes <= M * ldx * 2), so the
+    // hardware zero-fills them without the sentinel gemm256f_kernel selects per piece
+    unsigned xsrc = 0, wsrc = 0;
+    const unsigned xstep = (unsigned)(8 * p.ldx * 2), wstep = (unsigned)(8 * p.ldw * 2);
+    int m0 = 0, n0 = 0;
+    auto setup = [&](int local, unsigned& xs, unsigned& ws, int& mm, int& nb) {
+        mm = (m_lo + local / nn) * G_BM;
+        nb = (n_lo + local % nn) * G_BN;
+        const int row = wave * 32 + rin;
+        xs = (unsigned)((mm + row) * p.ldx + csrc * 8) * 2u;
+        ws = (unsigned)((nb + row) * p.ldw + csrc * 8) * 2u;
+    };
+    auto piece_of = [&](unsigned xs, unsigned ws, int q, unsigned buf, unsigned kbyte) {
+        if (q < 4) g_dma16(pdst + buf + (unsigned)q * 1024u, xs + (unsigned)q * xstep + kbyte, rx);
+        else g_dma16(pdst + buf + G_WOFF + (unsigned)(q - 4) * 1024u, ws + (unsigned)(q - 4) * wstep + kbyte, rw);
+    };
+    const int nk = p.K / 64;                          // >= 2 (launcher)
+    int local = slot;
+    setup(local, xsrc, wsrc, m0, n0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piece_of(xsrc, wsrc, q, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piece_of(xsrc, wsrc, q, G_BUF, 128u);
+    bool first = true;
+    for (;;) {
+        g_f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+        uint4 wfa[4], xfa[8], wfb[4], xfb[8];
+        // (the lane id is made opaque once per output tile: the 24 fragment addresses below are invariant across the WHOLE kernel, and hoisted out of
+        //  the tile loop they cost 43 spilled registers; hoisted out of the K loop only, they are what gemm256f_kernel carries)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int fr = lane_o & 15, fg = lane_o >> 4;
+        auto rd_frag = [&](uint4 (&wf)[4], uint4 (&xf)[8], int f, int ks, unsigned buf) {
+            if (f < 4) {
+                const int r = wc * 64 + f * 16 + fr;
+                wf[f] = *reinterpret_cast<const uint4*>(smem + buf + G_WOFF + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            } else {
+                const int r = wr * 128 + (f - 4) * 16 + fr;
+                xf[f - 4] = *reinterpret_cast<const uint4*>(smem + buf + r * 128 + (((ks * 4 + fg) ^ (r & 7)) << 4));
+            }
+        };
+        // K tile 0 has landed: the first tile waits for everything but K tile 1's 8 requests; a later tile's 16 requests sit in FRONT of the previous
+        // epilogue's 16 stores
+        if (first) g_wait_vmcnt<8>(); else g_wait_vmcnt<16>();
+        G_BAR();
+#pragma unroll
+        for (int f = 0; f < 12; ++f) rd_frag(wfa, xfa, f, 0, 0);
+
+        auto tile_body = [&](int t, auto MORE1, auto MORE2) {
+            constexpr bool more1 = decltype(MORE1)::value, more2 = decltype(MORE2)::value;
+            const unsigned cur = (t & 1) ? G_BUF : 0u, nxt = cur ^ G_BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    GMma<T>::run(acc[i][j], wfa[i], xfa[j]);
+                    const int m = i * 8 + j;
+                    if (m < 12) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd_frag(wfb, xfb, m, 1, cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // K tile t + 1 has landed (this wave's pieces; the barrier makes it everybody's).  MID16: tile 0 of a later output tile -- the previous
+            // epilogue's 16 stores may still be in flight behind those pieces
+            if (!first && t == 0) g_wait_vmcnt<16>(); else g_wait_vmcnt<0>();      // (a scalar branch around the wait)
+            G_BAR();
+            const unsigned kb2 = (unsigned)(t + 2) * 128u;
+            if constexpr (OPT & 2) {
+                if (more2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) piece_of(xsrc, wsrc, q, cur, kb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    GMma<T>::run(acc[i][j], wfb[i], xfb[j]);
+                    const int m = i * 8 + j;
+                    if (!(OPT & 2) && more2 && m < 16 && (m & 1) == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece_of(xsrc, wsrc, m >> 1, cur, kb2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (more1 && m >= 16 && m < 28) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd_frag(wfa, xfa, m - 16, 0, nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        };
+        {
+            int t = 0;
+            for (; t + 2 < nk; ++t) tile_body(t, std::true_type{}, std::true_type{});
+            if (t + 1 < nk) { tile_body(t, std::true_type{}, std::false_type{}); ++t; }
+            tile_body(t, std::false_type{}, std::false_type{});
+        }
+        __syncthreads();                               // every wave is past its last fragment read: both operand buffers are free
+        // ---- the next output tile's first two K tiles, requested in front of this tile's epilogue
+        const int nlocal = local + nslots;
+        const bool more = nlocal < ntl;
+        int em0 = m0, en0 = n0;
+        // (opaque to the optimiser: the epilogue's 16 store offsets depend only on these and the lane, and LICM would otherwise park them in
+        //  registers across the K loop, which has none to spare: 43 spilled registers without this)
+        asm volatile("" : "+s"(em0), "+s"(en0));
+        if (more) {
+            setup(nlocal, xsrc, wsrc, m0, n0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) piece_of(xsrc, wsrc, q, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) piece_of(xsrc, wsrc, q, G_BUF, 128u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- register epilogue: acc + bias, activation, one rounding; 16 buffer stores per thread, always issued
+        {
+            const int coff = (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const int n = en0 + wc * 64 + ip * 32 + coff;
+                const bool n_ok = n + 8 <= p.N;
+                float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n_ok) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+                    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v[8];
+                    swap_pair(acc[2 * ip][j], acc[2 * ip + 1][j], v);
+                    const int m = em0 + wr * 128 + j * 16 + fr;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
+                    } else if (p.act == ACT_GELU) {
+                        gelu_vec<T, 8>(v);
+                    }
+                    const uint4 o = pack_chunk<T>(v);
+                    const unsigned off = (n_ok && m < p.M) ? (unsigned)(((size_t)m * p.ldy + n) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g_u32x4, o), ry, (int)off, 0, 0);
+                }
+            }
+        }
+        if (!more) break;
+        local = nlocal;
+        first = false;
+    }
+}
+#endif  // HCM_DEV_KNOBS (gemm256p_kernel)
+
 hipError_t gemm256_prof_read(unsigned long long* host, bool reset) {
     hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256_prof), sizeof(unsigned long long) * kG256ProfWgs * 64);
     if (e != hipSuccess) return e;
@@ -1058,6 +1258,21 @@ hipError_t launch_gemm256(const IGemm& g, int dt, hipStream_t s) {
     }
 #else
     if (g.impl >> 4) return hipErrorInvalidValue;          // experiment variants exist in `make DEV=1` builds only
+#endif
+#ifdef HCM_DEV_KNOBS
+    // round-5 experiment (development build, HCM_GEMM256_PERSIST=1): more than one tile per CU on the busiest XCD -> the persistent form
+    // (gemm256p_kernel; bit-identical, measured SLOWER: see its header).  Plain layers only.
+    static const bool persist = dev_env("HCM_GEMM256_PERSIST") != nullptr && atoi(dev_env("HCM_GEMM256_PERSIST")) != 0;
+    const size_t y_bytes = ((size_t)(g.M - 1) * d.ldy + g.N) * 2;
+    if (persist && !eight_phase && !g.res && !g.ln_s && (g.impl >> 4) == 0 && threads == 512 && best_cnt > 32 && g.K >= 128 && y_bytes < 0x7FFFFFF0ull) {
+        d.y_bytes = (unsigned)y_bytes;
+        const void* pf = g.K <= 1024 ? (dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256p_kernel<bf16, 2>) : reinterpret_cast<const void*>(gemm256p_kernel<f16, 2>))
+                                     : (dt == DT_BF16 ? reinterpret_cast<const void*>(gemm256p_kernel<bf16, 0>) : reinterpret_cast<const void*>(gemm256p_kernel<f16, 0>));
+        hipError_t e = hipFuncSetAttribute(pf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        void* pargs[] = {&d};
+        return hipLaunchKernel(pf, dim3(8 * 32), dim3(512), pargs, 2 * G_BUF, s);
+    }
 #endif
     {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
