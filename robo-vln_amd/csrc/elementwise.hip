@@ -151,6 +151,83 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int
     return hipGetLastError();
 }
 
+// MaxPool2d(3, 2, 1) over relu(GroupNorm(x)) with the normalisation applied ON LOAD (round 5: the depth trunk's stem -- conv -> GroupNorm -> ReLU ->
+// max-pool, habitat's ResNet stem as used at resnet_encoders.py:27-33).  x is the UN-normalised conv output, `part` the (sum, sum of squares) partials its
+// epilogue left per (sample, 64-pixel block, group) -- what gn_apply_kernel would have consumed: the stand-alone apply pass (one read and one write of the
+// largest map of the trunk) and its launch disappear.  The per-channel scale / shift and the expression v * sc - sh are gn_apply_kernel's; rounding is
+// monotone and ReLU commutes with it, so max(round(relu(.))) == round(max(relu(.))): BIT-IDENTICAL to the apply pass followed by maxpool_kernel.
+// grid (blocks per sample, B): a workgroup rebuilds its sample's scale / shift table (G <= 256 groups, C <= 512 channels) and pools a slice of its pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_gn_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ part, int PS, float eps, int G, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CH = Tr<T>::CH;
+    __shared__ float s_scale[512], s_shift[512];
+    __shared__ float s_mean[256], s_rstd[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Cg = C / G, HW = H * W;
+    for (int g = tid; g < G; g += 256) {
+        float a = 0.f, q = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < PS; ++i) {
+            const float* o = part + (((size_t)b * PS + i) * G + g) * 2;
+            a += o[0]; q += o[1];
+        }
+        const float inv_n = 1.0f / ((float)HW * (float)Cg);
+        const float mean = a * inv_n;
+        const float var = relu_f(q * inv_n - mean * mean);
+        s_mean[g] = mean;
+        s_rstd[g] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {
+        const int g = ch / Cg;
+        const float sc = s_rstd[g] * gamma[ch];
+        s_scale[ch] = sc;
+        s_shift[ch] = s_mean[g] * sc - beta[ch];
+    }
+    __syncthreads();
+    const int cv = C / CH;
+    const int total = Ho * Wo * cv;
+    const T* xb = x + (size_t)b * HW * C;
+    T* yb = y + (size_t)b * Ho * Wo * C;
+    for (int e = blockIdx.x * 256 + tid; e < total; e += gridDim.x * 256) {
+        const int c = (e % cv) * CH;
+        const int pix = e / cv;
+        const int ox = pix % Wo, oy = pix / Wo;
+        int iy[3], ix[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            iy[d] = min(max(2 * oy - 1 + d, 0), H - 1);
+            ix[d] = min(max(2 * ox - 1 + d, 0), W - 1);
+        }
+        float v[9][CH];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) ld_chunk(xb + ((size_t)iy[dy] * W + ix[dx]) * C + c, v[dy * 3 + dx]);
+        float m[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float sc = s_scale[c + j], sh = s_shift[c + j];
+            m[j] = relu_f(v[0][j] * sc - sh);
+#pragma unroll
+            for (int t = 1; t < 9; ++t) m[j] = max_nan(m[j], relu_f(v[t][j] * sc - sh));
+        }
+        st_chunk(yb + (size_t)pix * C + c, m);
+    }
+}
+bool maxpool_gn_ok(int dt, int C, int G) { return dt != DT_F32 && C % dt_chunk(dt) == 0 && C <= 512 && G >= 1 && G <= 256 && C % G == 0; }
+hipError_t launch_maxpool3x3s2_gn(const void* x, void* y, const float* gamma, const float* beta, const float* part, int PS, float eps, int G, int dt, int B, int H,
+                                  int W, int C, int Ho, int Wo, hipStream_t s) {
+    if (!maxpool_gn_ok(dt, C, G) || PS < 1 || !part || !gamma || !beta) return hipErrorInvalidValue;
+    const int total = Ho * Wo * (C / dt_chunk(dt));
+    int bps = (total + 256 * 4 - 1) / (256 * 4);          // ~4 output chunks per thread
+    if (bps < 1) bps = 1;
+    if (bps > 64) bps = 64;
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(maxpool_gn_kernel<T>, dim3(bps, B), dim3(256), 0, s, (const T*)x, (T*)y, gamma, beta, part, PS, eps, G, H, W, C, Ho, Wo));
+    return hipGetLastError();
+}
+
 // vertical half of MaxPool2d(3, 2, 1) (the horizontal half is fused into the stem conv's epilogue, igemm.hip)
 template <typename T>
 __global__ void vpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho) {

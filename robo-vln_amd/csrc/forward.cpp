@@ -295,7 +295,13 @@ struct Fwd {
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
         const float stem_eps = 1e-5f * t.conv1.fold * t.conv1.fold;      // (conv1 and conv1_packed carry the same fold)
-        if (t.gn && stem_stats) {
+        // round 5: the stem's GroupNorm + ReLU applied ON LOAD by the max-pool (maxpool_gn_kernel: the apply pass over the trunk's largest map and its
+        // launch disappear; bit-identical).  Not while taps are captured (`_conv1` is the normalised map).  HCM_NO_GN_POOL=1 (development build): the A/B.
+        static const bool no_gn_pool = dev_env("HCM_NO_GN_POOL") != nullptr;
+        const bool gn_pool = t.gn && stem_stats && !no_gn_pool && !ctx->taps_on && !hpool && maxpool_gn_ok(t.conv1_packed.dt, c1, G);
+        if (gn_pool) {
+            // (nothing here: the pool below normalises)
+        } else if (t.gn && stem_stats) {
             if (!dry) ck(launch_groupnorm_apply(slot[0], nullptr, t.n_conv1.gamma, t.n_conv1.beta, stem_stats, Ho * Wo / 64, t.conv1_packed.dt, B, Ho * Wo, c1, G,
                                                 stem_eps, 1, s), "groupnorm apply (stem)");
         } else if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true, 0, stem_eps);
@@ -303,6 +309,9 @@ struct Fwd {
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
         if (hpool) {
             if (!dry) ck(launch_vpool3s2(slot[0], slot[1], dt, B, Ho, Wo / 2, c1, s), "maxpool (vertical half)");
+        } else if (gn_pool) {
+            if (!dry) ck(launch_maxpool3x3s2_gn(slot[0], slot[1], t.n_conv1.gamma, t.n_conv1.beta, stem_stats, Ho * Wo / 64, stem_eps, G, t.conv1_packed.dt, B, Ho, Wo, c1,
+                                                Hp, Wp, s), "maxpool over GroupNorm on load (stem)");
         } else if (!dry) ck(launch_maxpool3x3s2(slot[0], slot[1], dt, B, Ho, Wo, c1, Hp, Wp, s), "maxpool");
         Act x{slot[1], B, Hp, Wp, c1};
         mark(tapname + ".stem_end");

@@ -168,6 +168,10 @@ hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, in
 // vertical half of MaxPool2d(3, 2, 1): x [B][H][W][C] -> y [B][(H+1)/2][W][C] (rows 2p-1, 2p, 2p+1)
 hipError_t launch_vpool3s2(const void* x, void* y, int dt, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int dt, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// ... over relu(GroupNorm(x)) with the normalisation applied on load from the producing conv's epilogue statistics (bit-identical to the apply pass + the pool)
+bool maxpool_gn_ok(int dt, int C, int G);
+hipError_t launch_maxpool3x3s2_gn(const void* x, void* y, const float* gamma, const float* beta, const float* part, int PS, float eps, int G, int dt, int B, int H,
+                                  int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pool NHWC [B,H,W,C] -> [B,OH,OW,*] written with row stride ldy (elements) per output pixel
 hipError_t launch_adaptive_avgpool(const void* x, void* y, int dt, int B, int H, int W, int C, int OH, int OW, int ldy, hipStream_t s,
                                    int ldx = 0 /* input pixel stride in elements, 0 = C */);

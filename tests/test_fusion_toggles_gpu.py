@@ -124,6 +124,19 @@ def test_groupnorm_on_load_equals_the_apply_launches(env):
     assert np.isfinite(a["rec"]).all()
 
 
+@pytest.mark.parametrize("env", [{}, {"HCMT_DEPTH_HW": "256", "HCMT_L": "32"}, {"HCMT_DEPTH_HW": "384"}, {"HCMT_DEPTH_HW": "256", "HCMT_PREC": "bf16"}])
+def test_stem_groupnorm_applied_by_the_max_pool_equals_the_apply_launch(env):
+    """Round 5: the depth stem's GroupNorm + ReLU is applied ON LOAD by the 3 x 3 / 2 max-pool (maxpool_gn_kernel: the same per-channel scale / shift and
+    the same expression as gn_apply_kernel; rounding is monotone and commutes with ReLU, so the pooled value is the same) instead of by an apply pass
+    over the trunk's largest map: the whole step must equal the step with HCM_NO_GN_POOL=1 bit for bit."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_GN_POOL="1"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    assert np.isfinite(a["rec"]).all()
+
+
 @pytest.mark.parametrize("env", [{"HCMT_DEPTH_HW": "256", "HCMT_L": "20"}, {"HCMT_DEPTH_HW": "128", "HCMT_L": "20"}])
 def test_depth_layer12_runs_equal_the_launch_per_conv_form(env):
     """depth_blk_kernel (depth_blk.hip, round 4): the identity bottlenecks of the depth trunk's layer1 (32 x 32 maps) and layer2 (16 x 16) with a whole
