@@ -632,6 +632,76 @@ hipError_t launch_groupnorm_apply(void* x, const void* res, const float* gamma, 
     return hipGetLastError();
 }
 
+// gn_apply_kernel with an UN-normalised residual (round 5): x = relu?(GN(x) + round_T(GN2(res))) where res is the raw output of the block's down-sample
+// conv and part2 / gamma2 / beta2 its GroupNorm -- the stage-first bottlenecks of the GroupNorm trunk (habitat's ResNet: `out = relu(bn3(conv3) +
+// downsample(x))`, resnet_encoders.py:27-33).  The down-sample branch's own apply pass (a read and a write of its map, one launch) disappears; its
+// normalised value is rounded to the storage type exactly as that pass stored it before it is added: BIT-IDENTICAL to the two apply passes.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply2_kernel(T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ part, const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                         const float* __restrict__ part2, int HW, int C, int G, int P, float eps, float eps2, int relu, int PS) {
+    constexpr int CH = Tr<T>::CH;
+    __shared__ float s_scale[2][512], s_shift[2][512];
+    __shared__ float s_mean[2][256], s_rstd[2][256];
+    const int b = blockIdx.y, pc = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int Cg = C / G;
+    for (int g2 = tid; g2 < 2 * G; g2 += 256) {
+        const int which = g2 >= G, g = which ? g2 - G : g2;
+        const float* pp = which ? part2 : part;
+        float a = 0.f, q = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < PS; ++i) {
+            const float* o = pp + (((size_t)b * PS + i) * G + g) * 2;
+            a += o[0]; q += o[1];
+        }
+        const float inv_n = 1.0f / ((float)HW * (float)Cg);
+        const float mean = a * inv_n;
+        const float var = relu_f(q * inv_n - mean * mean);
+        s_mean[which][g] = mean;
+        s_rstd[which][g] = rsqrtf(var + (which ? eps2 : eps));
+    }
+    __syncthreads();
+    for (int c2 = tid; c2 < 2 * C; c2 += 256) {
+        const int which = c2 >= C, ch = which ? c2 - C : c2;
+        const int g = ch / Cg;
+        const float sc = s_rstd[which][g] * (which ? gamma2 : gamma)[ch];
+        s_scale[which][ch] = sc;
+        s_shift[which][ch] = s_mean[which][g] * sc - (which ? beta2 : beta)[ch];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const int cc = tid % cpr, prow = tid / cpr, pstep = 256 / cpr;
+    const int chunk = HW / P;
+    const size_t base = ((size_t)b * HW + (size_t)pc * chunk) * C + cc * CH;
+    float sc[CH], sh[CH], sc2[CH], sh2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sc[j] = s_scale[0][cc * CH + j]; sh[j] = s_shift[0][cc * CH + j]; sc2[j] = s_scale[1][cc * CH + j]; sh2[j] = s_shift[1][cc * CH + j]; }
+    for (int p = prow; p < chunk; p += pstep) {
+        float v[CH], r[CH];
+        ld_chunk(x + base + (size_t)p * C, v);
+        ld_chunk(res + base + (size_t)p * C, r);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            T rt;
+            Tr<T>::st(&rt, r[j] * sc2[j] - sh2[j]);          // what the down-sample branch's apply pass stored (no ReLU on that branch)
+            float o = v[j] * sc[j] - sh[j];
+            o += Tr<T>::ld(&rt);
+            if (relu) o = relu_f(o);
+            v[j] = o;
+        }
+        st_chunk(x + base + (size_t)p * C, v);
+    }
+}
+hipError_t launch_groupnorm_apply2(void* x, const void* res, const float* gamma, const float* beta, const float* part, const float* gamma2, const float* beta2,
+                                   const float* part2, int PS, int dt, int B, int HW, int C, int G, float eps, float eps2, int relu, hipStream_t s) {
+    if (!groupnorm_apply_ok(dt, HW, C, G) || PS < 1 || !res || !part2) return hipErrorInvalidValue;
+    const int P = gn_partials(HW);
+    HCM_DISPATCH_T(dt, hipLaunchKernelGGL(gn_apply2_kernel<T>, dim3(P, B), dim3(256), 0, s, (T*)x, (const T*)res, gamma, beta, part, gamma2, beta2, part2, HW, C, G, P,
+                                          eps, eps2, relu, PS));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
 // nn.LayerNorm / BertLayerNorm: biased variance, eps inside the sqrt; two-pass in registers.
 template <typename T, int D>

@@ -72,12 +72,31 @@ struct Fwd {
         void* x = nullptr; const void* res = nullptr; const float* stats = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
         int B = 0, hw = 0, C = 0, G = 0, ps = 0, relu = 0, dt = 0; float eps = 1e-5f;
         bool writeback = false;          // the consumer also stores the normalised tensor (a block output: the next residual add reads it)
+        // round 5: `res` itself is still UN-normalised (the down-sample branch of a stage-first bottleneck: its own GroupNorm, no ReLU); flush() then
+        // normalises both in ONE pass (gn_apply2_kernel), a consumer that normalises on load has the residual materialised first
+        const float* res_stats = nullptr; const float* res_gamma = nullptr; const float* res_beta = nullptr; float res_eps = 1e-5f;
     };
     Pending pend_in;
     Pending* defer_out = nullptr;
+    Pending* res_pending = nullptr;      // conv_gn: the residual passed to THIS call is the x of this record (consumed by the call)
+    void materialise_res(Pending& q) {   // the pending residual of q -> normalised in place (the apply pass of rounds 1-4)
+        if (!q.res_stats) return;
+        const float* st = q.res_stats;
+        q.res_stats = nullptr;
+        if (dry) return;
+        ck(launch_groupnorm_apply(const_cast<void*>(q.res), nullptr, q.res_gamma, q.res_beta, st, q.ps, q.dt, q.B, q.hw, q.C, q.G, q.res_eps, 0, s), "groupnorm apply (residual)");
+    }
     void flush(Pending& q) {
         if (!q.valid) return;
         q.valid = false;
+        if (q.res_stats) {
+            const float* st = q.res_stats;
+            q.res_stats = nullptr;
+            if (dry) return;
+            ck(launch_groupnorm_apply2(q.x, q.res, q.gamma, q.beta, q.stats, q.res_gamma, q.res_beta, st, q.ps, q.dt, q.B, q.hw, q.C, q.G, q.eps, q.res_eps, q.relu, s),
+               "groupnorm apply (flush, pending residual)");
+            return;
+        }
         if (dry) return;
         ck(launch_groupnorm_apply(q.x, q.res, q.gamma, q.beta, q.stats, q.ps, q.dt, q.B, q.hw, q.C, q.G, q.eps, q.relu, s), "groupnorm apply (flush)");
     }
@@ -94,10 +113,18 @@ struct Fwd {
         static const bool no_fuse = dev_env("HCM_NO_GN_FUSE") != nullptr;
         const int C = w.groups * w.Cout, cg = C / G, hw = Ho * Wo;
         struct ClearDefer { Pending*& p; ~ClearDefer() { p = nullptr; } } clear_defer{defer_out};     // a request is for THIS call only
+        Pending* rp = res_pending;       // `res` is this record's un-normalised tensor: taken over by the deferral below, else materialised first
+        res_pending = nullptr;
+        auto settle_res = [&]() {
+            if (!rp || !rp->valid) return;
+            rp->valid = false;
+            if (!dry) ck(launch_groupnorm_apply(rp->x, nullptr, rp->gamma, rp->beta, rp->stats, rp->ps, rp->dt, rp->B, rp->hw, rp->C, rp->G, rp->eps, rp->relu, s), "groupnorm apply (residual)");
+        };
         const float eps = 1e-5f * w.fold * w.fold;          // range-folded conv (ConvW::fold): GroupNorm((fold * x), eps * fold^2) == GroupNorm(x, eps)
         if (cg_true) {
             // zero-padded output channels (compression conv of 64*k-pixel frames, k not a power of two): the statistics count the real
             // channels of each group only -- the stand-alone slab kernel knows how
+            settle_res();
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
             gn(out, res, n, in.B, hw, C, G, relu, cg_true, eps);
             return;
@@ -108,6 +135,7 @@ struct Fwd {
         const bool fuse = !no_fuse && hw <= 64 && 64 % hw == 0 && cg % 8 == 0 && 128 % cg == 0 && w.Cout % cg == 0 && !w.bias &&
                           (blocks >= 64 || w.K < 4096);
         if (fuse) {
+            settle_res();
             conv(w, in, out, stride, pad, res, relu ? ACT_RELU : ACT_NONE, Ho, Wo, &n, cg, nullptr, 0, 0, 0, eps);
         } else {
             // large maps: the statistics come out of the conv's epilogue (column sums of the f32 tile image per 64-row block and
@@ -121,13 +149,21 @@ struct Fwd {
                     Pending& q = *defer_out;
                     q.valid = true; q.x = out; q.res = res; q.stats = stats; q.gamma = n.gamma; q.beta = n.beta;
                     q.B = in.B; q.hw = hw; q.C = C; q.G = G; q.ps = hw / 64; q.relu = relu ? 1 : 0; q.dt = w.dt; q.eps = eps; q.writeback = false;
+                    q.res_stats = nullptr;
+                    if (rp && rp->valid && rp->x == res && rp->hw == hw && rp->C == C && rp->G == G && rp->ps == q.ps && !rp->res && !rp->relu) {
+                        // the residual stays un-normalised too: whoever materialises this tensor normalises both in one pass
+                        q.res_stats = rp->stats; q.res_gamma = rp->gamma; q.res_beta = rp->beta; q.res_eps = rp->eps;
+                        rp->valid = false;
+                    } else settle_res();
                     defer_out = nullptr;
                     return;
                 }
+                settle_res();
                 static const bool skip_apply = dev_env("HCM_SKIP_GN_APPLY") != nullptr;
                 if (!dry && !skip_apply) ck(launch_groupnorm_apply(out, res, n.gamma, n.beta, stats, hw / 64, w.dt, in.B, hw, C, G, eps, relu ? 1 : 0, s), "groupnorm apply");
                 return;
             }
+            settle_res();
             conv(w, in, out, stride, pad, nullptr, ACT_NONE, Ho, Wo);
             gn(out, res, n, in.B, hw, C, G, relu, 0, eps);
         }
@@ -137,6 +173,7 @@ struct Fwd {
         Pending pin = pend_in;
         pend_in.valid = false;
         if (pin.valid && pin.x != in.p) { flush(pin); }             // (a record for another tensor: cannot happen in the trunk loop; be safe)
+        if (pin.valid) materialise_res(pin);                         // a consumer that normalises on load adds a NORMALISED residual
         if (dry) return;
         IGemm g;
         g.cs_part = cs_part; g.cs_cg = cs_cg; g.cs_hw = cs_hw; g.cs_G = cs_G;
@@ -497,8 +534,15 @@ struct Fwd {
             }
             else conv(b.c2, o1, sb, b.stride, 1, nullptr, ACT_RELU, Ho2, Wo2);
             const void* idt = x.p;
+            Pending pds;
             if (b.has_ds) {
-                if (t.gn) conv_gn(b.ds, x, sa, b.stride, 0, nullptr, b.nds, G, false, Ho2, Wo2);   // o1 is dead: reuse its slot
+                if (t.gn) {
+                    // round 5: the down-sample branch's GroupNorm stays pending as well when the block output does (gn_apply2_kernel normalises both in
+                    // one pass; HCM_NO_GN_RES2=1, development build: its own apply pass as in rounds 1-4)
+                    static const bool no_res2 = dev_env("HCM_NO_GN_RES2") != nullptr;
+                    if (!no_res2 && bi + 1 < t.blocks.size()) defer_out = &pds;
+                    conv_gn(b.ds, x, sa, b.stride, 0, nullptr, b.nds, G, false, Ho2, Wo2);   // o1 is dead: reuse its slot
+                }
                 else conv(b.ds, x, sa, b.stride, 0, nullptr, ACT_NONE, Ho2, Wo2);
                 idt = sa;
             }
@@ -506,6 +550,7 @@ struct Fwd {
                 pend_in = p2; p2.valid = false;
                 // the block output stays pending when another bottleneck follows: its c1 normalises, adds the identity and stores it
                 if (bi + 1 < t.blocks.size()) defer_out = &xpend;
+                if (pds.valid) res_pending = &pds;
                 conv_gn(b.c3, o2, sc, 1, 0, idt, b.n3, G, true, Ho2, Wo2);          // relu(GN(conv) + identity)
             } else {
                 conv(b.c3, o2, sc, 1, 0, idt, ACT_RELU, Ho2, Wo2);                  // relu(bn(conv) + identity), fused

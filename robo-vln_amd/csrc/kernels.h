@@ -193,6 +193,9 @@ inline size_t gn_stats_floats(int B, int HW, int G) {
 // second half of the two-launch GroupNorm alone: statistics come from `part` = PS partial sums per (sample, group) (launch_igemm's cs_part)
 hipError_t launch_groupnorm_apply(void* x, const void* res, const float* gamma, const float* beta, const float* part, int PS, int dt, int B,
                                   int HW, int C, int G, float eps, int relu, hipStream_t s);
+// ... with an UN-normalised residual: x = relu?(GN(x) + round_T(GN2(res))) (the stage-first bottlenecks' down-sample branch; bit-identical to two apply passes)
+hipError_t launch_groupnorm_apply2(void* x, const void* res, const float* gamma, const float* beta, const float* part, const float* gamma2, const float* beta2,
+                                   const float* part2, int PS, int dt, int B, int HW, int C, int G, float eps, float eps2, int relu, hipStream_t s);
 bool groupnorm_apply_ok(int dt, int HW, int C, int G);
 hipError_t launch_groupnorm(void* x, const void* res, const float* gamma, const float* beta, float* stats,
                             int dt, int B, int HW, int C, int G, float eps, int relu, hipStream_t s, int cg_true = 0);   // cg_true > 0: real channels per group, the rest are zero padding

@@ -137,6 +137,22 @@ def test_stem_groupnorm_applied_by_the_max_pool_equals_the_apply_launch(env):
     assert np.isfinite(a["rec"]).all()
 
 
+@pytest.mark.parametrize("env", [{}, {"HCMT_DEPTH_HW": "256", "HCMT_L": "32"}, {"HCMT_DEPTH_HW": "384"}, {"HCMT_DEPTH_HW": "192"},
+                                 {"HCMT_DEPTH_HW": "256", "HCM_NO_DEPTH_BLK": "1"}, {"HCMT_DEPTH_HW": "256", "HCMT_PREC": "bf16"}])
+def test_pending_downsample_groupnorm_equals_its_apply_launch(env):
+    """Round 5: in the stage-first bottlenecks of the GroupNorm trunk the down-sample branch's GroupNorm stays pending together with the block output
+    and gn_apply2_kernel normalises both in one pass (x = relu(GN(conv3) + round(GN_ds(downsample)))) -- or, where the next block's first conv
+    normalises the block output on load, the residual is materialised just in front of it.  The same expressions and the same rounding of the
+    residual as its own apply pass: the whole step must equal the step with HCM_NO_GN_RES2=1 bit for bit, at every depth frame size class
+    (256: depth_blk_kernel consumes the block output; 128 / 192 / 384 and HCM_NO_DEPTH_BLK: the on-load consumer)."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_GN_RES2="1"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    assert np.isfinite(a["rec"]).all()
+
+
 @pytest.mark.parametrize("env", [{"HCMT_DEPTH_HW": "256", "HCMT_L": "20"}, {"HCMT_DEPTH_HW": "128", "HCMT_L": "20"}])
 def test_depth_layer12_runs_equal_the_launch_per_conv_form(env):
     """depth_blk_kernel (depth_blk.hip, round 4): the identity bottlenecks of the depth trunk's layer1 (32 x 32 maps) and layer2 (16 x 16) with a whole
