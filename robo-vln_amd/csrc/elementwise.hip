@@ -166,12 +166,19 @@ __global__ __launch_bounds__(256) void maxpool_gn_kernel(const T* __restrict__ x
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Cg = C / G, HW = H * W;
     for (int g = tid; g < G; g += 256) {
+        // (the partials are added in index order -- gn_apply_kernel's order -- but REQUESTED 16 at a time: the stem map has 256 of them per group, and
+        //  four per round trip made this prologue 64 dependent round trips, ~40 us of a 44 us launch)
         float a = 0.f, q = 0.f;
-#pragma unroll 4
-        for (int i = 0; i < PS; ++i) {
-            const float* o = part + (((size_t)b * PS + i) * G + g) * 2;
-            a += o[0]; q += o[1];
+        const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)b * PS * G + g;
+        int i = 0;
+        for (; i + 16 <= PS; i += 16) {
+            float2 t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = pp[(size_t)(i + u) * G];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { a += t[u].x; q += t[u].y; }
         }
+        for (; i < PS; ++i) { const float2 t = pp[(size_t)i * G]; a += t.x; q += t.y; }
         const float inv_n = 1.0f / ((float)HW * (float)Cg);
         const float mean = a * inv_n;
         const float var = relu_f(q * inv_n - mean * mean);
@@ -221,9 +228,9 @@ hipError_t launch_maxpool3x3s2_gn(const void* x, void* y, const float* gamma, co
                                   int W, int C, int Ho, int Wo, hipStream_t s) {
     if (!maxpool_gn_ok(dt, C, G) || PS < 1 || !part || !gamma || !beta) return hipErrorInvalidValue;
     const int total = Ho * Wo * (C / dt_chunk(dt));
-    int bps = (total + 256 * 4 - 1) / (256 * 4);          // ~4 output chunks per thread
+    int bps = (total + 256 * 16 - 1) / (256 * 16);        // ~16 output chunks per thread: every workgroup rebuilds its sample's scale / shift table
     if (bps < 1) bps = 1;
-    if (bps > 64) bps = 64;
+    if (bps > 16) bps = 16;
     HCM_DISPATCH_T(dt, hipLaunchKernelGGL(maxpool_gn_kernel<T>, dim3(bps, B), dim3(256), 0, s, (const T*)x, (T*)y, gamma, beta, part, PS, eps, G, H, W, C, Ho, Wo));
     return hipGetLastError();
 }
@@ -504,10 +511,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
     // PS partial sums per (sample, group): P of them from gn_stats_kernel, or HW / 64 from the producing conv's epilogue
     for (int g = tid; g < G; g += 256) {
         float a = 0.f, q = 0.f;
-#pragma unroll 4
-        for (int i = 0; i < PS; ++i) {
-            const float* o = part + (((size_t)b * PS + i) * G + g) * 2;
-            a += o[0]; q += o[1];
+        {   // index order, requested 16 at a time (see maxpool_gn_kernel)
+            const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)b * PS * G + g;
+            int i = 0;
+            for (; i + 16 <= PS; i += 16) {
+                float2 t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = pp[(size_t)(i + u) * G];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { a += t[u].x; q += t[u].y; }
+            }
+            for (; i < PS; ++i) { const float2 t = pp[(size_t)i * G]; a += t.x; q += t.y; }
         }
         const float inv_n = 1.0f / ((float)HW * (float)Cg);
         const float mean = a * inv_n;
@@ -650,10 +664,17 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(T* __restrict__ x, const
         const int which = g2 >= G, g = which ? g2 - G : g2;
         const float* pp = which ? part2 : part;
         float a = 0.f, q = 0.f;
-#pragma unroll 4
-        for (int i = 0; i < PS; ++i) {
-            const float* o = pp + (((size_t)b * PS + i) * G + g) * 2;
-            a += o[0]; q += o[1];
+        {   // index order, requested 16 at a time (see maxpool_gn_kernel)
+            const float2* p2 = reinterpret_cast<const float2*>(pp) + (size_t)b * PS * G + g;
+            int i = 0;
+            for (; i + 16 <= PS; i += 16) {
+                float2 t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = p2[(size_t)(i + u) * G];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { a += t[u].x; q += t[u].y; }
+            }
+            for (; i < PS; ++i) { const float2 t = p2[(size_t)i * G]; a += t.x; q += t.y; }
         }
         const float inv_n = 1.0f / ((float)HW * (float)Cg);
         const float mean = a * inv_n;
