@@ -387,7 +387,9 @@ int hcm_op_vla_layer(const void* q, const void* I, const void* const* kv, const 
                      const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
                      void* stream);
 /* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,
- * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify).  The two must agree bit for bit.
+ * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify), 3 = the few-row kernel (csrc/skinny.hip:
+ * a wave per 16 x 16 output tile, operands straight into registers; any row count here, the library's own choice takes it up to 160 rows where its
+ * cost model says so).  All three must agree bit for bit.
  * (impl values >= 16 select timing-experiment builds of the 256-wide kernel that exist in `make DEV=1` libraries only: HCM_ERR_HIP otherwise.) */
 int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const void* residual, void* y,
                        int dtype, int M, int N, int K, int act, int out_f32, int impl, void* stream);
