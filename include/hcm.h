@@ -413,6 +413,16 @@ int hcm_op_layernorm_post(const void* x, const void* residual, const float* gamm
                           void* y, int dtype, int rows, int D, float eps, void* stream);
 int hcm_op_groupnorm(void* x_inplace, const void* residual, const float* gamma, const float* beta,
                      int dtype, int B, int HW, int C, int groups, float eps, int relu, void* stream);
+/* conv (bias-free, statistics from its epilogue) -> MaxPool2d(3, 2, 1) over relu(GroupNorm(conv)) with the normalisation applied on load by the pool
+ * (the depth stem of the GroupNorm trunk as the step runs it since round 5; replaces habitat's ResNet stem conv1 = Sequential(conv, GroupNorm, ReLU) +
+ * maxpool as used at resnet_encoders.py:27-33).  y is [B][Hp][Wp][Cout]; 16-bit types, the conv's map a multiple of 64 pixels per sample. */
+int hcm_op_conv2d_gn_pool(const void* x, const void* w_ohwi, const float* gamma, const float* beta, void* y, int dtype, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int groups, float eps, void* stream);
+/* y = relu?(GN(conv1x1(x, w)) + round(GN2(conv1x1_stride2(x2, w2)))) normalised in ONE pass over both un-normalised maps: the end of a stage-first
+ * bottleneck of the GroupNorm trunk, `out = relu(bn3(conv3(.)) + downsample(x))`; x is [B][H][W][Cin], x2 [B][H*stride2][W*stride2][Cin2]. */
+int hcm_op_conv2d_gn_res2(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* x2, const void* w2_ohwi, const float* gamma2,
+                          const float* beta2, void* y, int dtype, int B, int H, int W, int Cin, int Cin2, int stride2, int Cout, int groups, float eps,
+                          int relu, void* stream);
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
 
 #ifdef __cplusplus

@@ -100,6 +100,8 @@ EXPORTS = {
     "hcm_op_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "hcm_op_layernorm_post": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p] + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "hcm_op_groupnorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p]),
+    "hcm_op_conv2d_gn_pool": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 11 + [C.c_float, C.c_void_p]),
+    "hcm_op_conv2d_gn_res2": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 9 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_maxpool3x3s2": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
 }
 

@@ -1284,6 +1284,55 @@ int hcm_op_conv2d_gn_large(const void* x, const void* w_ohwi, const float* gamma
     if (rc != HCM_OK) return rc;
     return op_rc(launch_groupnorm_apply(y, residual, gamma, beta, scratch, hw / 64, dt, B, hw, Cout, groups, eps, relu, (hipStream_t)stream));
 }
+// conv (statistics from its epilogue) -> max-pool over relu(GroupNorm(.)) applied on load (maxpool_gn_kernel): the depth stem as forward.cpp runs it
+int hcm_op_conv2d_gn_pool(const void* x, const void* w_ohwi, const float* gamma, const float* beta, void* y, int dtype, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int groups, float eps, void* stream) {
+    if (groups < 1 || Cout % groups) return HCM_ERR_ARG;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1, hw = Ho * Wo, dt = op_dt(dtype);
+    if (!groupnorm_apply_ok(dt, hw, Cout, groups) || !maxpool_gn_ok(dt, Cout, groups)) return HCM_ERR_ARG;
+    const size_t stats_bytes = (gn_stats_floats(B, hw, groups) * 4 + 255) / 256 * 256, map_bytes = (size_t)B * hw * Cout * 2;
+    char* sc = (char*)op_scratch(stats_bytes + map_bytes);
+    if (!sc) return HCM_ERR_NOMEM;
+    float* stats = (float*)sc;
+    void* raw = sc + stats_bytes;
+    IGemm g;
+    g.x = x; g.w = w_ohwi; g.y = raw;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.xC = Cin; g.Ho = Ho; g.Wo = Wo;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.M = B * hw; g.N = Cout; g.K = KH * KW * Cin; g.Kp = g.K; g.ldy = Cout; g.ldr = Cout; g.act = ACT_NONE;
+    g.cs_part = stats; g.cs_cg = Cout / groups; g.cs_hw = hw; g.cs_G = groups;
+    int rc = op_rc(launch_igemm(g, dt, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+    return op_rc(launch_maxpool3x3s2_gn(raw, y, gamma, beta, stats, hw / 64, eps, groups, dt, B, Ho, Wo, Cout, Hp, Wp, (hipStream_t)stream));
+}
+// y = relu(GN(conv(x, w)) + round(GN2(conv(x2, w2)))) in ONE normalisation pass over both un-normalised maps (gn_apply2_kernel): the end of a stage-first
+// bottleneck of the GroupNorm trunk (the second conv is the down-sample branch); both convs 1x1 / same output map
+int hcm_op_conv2d_gn_res2(const void* x, const void* w_ohwi, const float* gamma, const float* beta, const void* x2, const void* w2_ohwi, const float* gamma2,
+                          const float* beta2, void* y, int dtype, int B, int H, int W, int Cin, int Cin2, int stride2, int Cout, int groups, float eps,
+                          int relu, void* stream) {
+    if (groups < 1 || Cout % groups || stride2 < 1) return HCM_ERR_ARG;
+    const int hw = H * W, dt = op_dt(dtype);
+    if (!groupnorm_apply_ok(dt, hw, Cout, groups)) return HCM_ERR_ARG;
+    const size_t stats_bytes = (gn_stats_floats(B, hw, groups) * 4 + 255) / 256 * 256, map_bytes = (size_t)B * hw * Cout * 2;
+    char* sc = (char*)op_scratch(2 * stats_bytes + map_bytes);
+    if (!sc) return HCM_ERR_NOMEM;
+    float* st1 = (float*)sc;
+    float* st2 = (float*)(sc + stats_bytes);
+    void* raw2 = sc + 2 * stats_bytes;
+    for (int which = 0; which < 2; ++which) {
+        IGemm g;
+        g.x = which ? x2 : x; g.w = which ? w2_ohwi : w_ohwi; g.y = which ? raw2 : y;
+        const int st = which ? stride2 : 1, ci = which ? Cin2 : Cin;
+        g.B = B; g.H = H * st; g.W = W * st; g.Cin = ci; g.xC = ci; g.Ho = H; g.Wo = W;
+        g.KH = 1; g.KW = 1; g.stride = st; g.pad = 0;
+        g.M = B * hw; g.N = Cout; g.K = ci; g.Kp = ci; g.ldy = Cout; g.ldr = Cout; g.act = ACT_NONE;
+        g.cs_part = which ? st2 : st1; g.cs_cg = Cout / groups; g.cs_hw = hw; g.cs_G = groups;
+        const int rc = op_rc(launch_igemm(g, dt, (hipStream_t)stream));
+        if (rc != HCM_OK) return rc;
+    }
+    return op_rc(launch_groupnorm_apply2(y, raw2, gamma, beta, st1, gamma2, beta2, st2, hw / 64, dt, B, hw, Cout, groups, eps, eps, relu, (hipStream_t)stream));
+}
 int hcm_op_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     return op_rc(launch_maxpool3x3s2(x, y, op_dt(dtype), B, H, W, C, Ho, Wo, (hipStream_t)stream));

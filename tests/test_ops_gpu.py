@@ -239,6 +239,74 @@ def test_groupnorm(prec, cfg):
     assert err <= tol * 3, err
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, K, stride, pad, groups
+    (2, 32, 32, 8, 64, 3, 1, 1, 32),          # the depth stem's channel / group shape (hi|lo pair: 64 channels, 32 groups) on a 32 x 32 map
+    (3, 16, 16, 32, 64, 1, 1, 0, 16),         # 1 x 1 producer, 4 channels per group
+    (1, 64, 64, 8, 32, 3, 1, 1, 16),          # 64 partial-sum blocks per sample: the 16-at-a-time request batches of the statistics prologue
+    (2, 34, 34, 8, 64, 3, 2, 1, 32),          # 17 x 17 ... not a multiple of 64 pixels: refused (the step falls back to the apply pass)
+])
+def test_conv_groupnorm_maxpool_on_load(prec, cfg):
+    """maxpool_gn_kernel through hcm_op_conv2d_gn_pool (conv with epilogue statistics -> MaxPool2d(3, 2, 1) over relu(GroupNorm(.)) applied on load) against
+    torch fp32: habitat's ResNet stem, conv1 = Sequential(conv, GroupNorm, ReLU) + maxpool (resnet_encoders.py:27-33)."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cin, Cout, K, stride, pad, G = cfg
+    x = _rnd(B, Cin, H, W).to(tdt).float()
+    w = (_rnd(Cout, Cin, K, K, seed=1) * (3.0 / (Cin * K * K)) ** 0.5).to(tdt).float()
+    g, b = _rnd(Cout, seed=2) * 0.5 + 1.0, _rnd(Cout, seed=3) * 0.3
+    conv = F.conv2d(x, w, None, stride=stride, padding=pad)
+    ref = F.max_pool2d(F.relu(F.group_norm(conv, G, g, b, 1e-5)), 3, 2, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+    gd, bd = g.cuda(), b.cuda()
+    y = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device="cuda", dtype=tdt)
+    rc = lib.hcm_op_conv2d_gn_pool(_p(xd), _p(wd), _p(gd), _p(bd), _p(y), code, B, H, W, Cin, Cout, K, K, stride, pad, G, 1e-5, None)
+    if (conv.shape[2] * conv.shape[3]) % 64:
+        assert rc == -1
+        return
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 4 * tol * max(1.0, ref.abs().max().item()), err        # (the conv output is rounded to 16 bits before it is normalised, as in the step)
+    # and bit for bit what the apply pass + the plain pool give
+    y2 = torch.empty((B, conv.shape[2], conv.shape[3], Cout), device="cuda", dtype=tdt)
+    assert lib.hcm_op_conv2d_gn_large(_p(xd), _p(wd), _p(gd), _p(bd), None, _p(y2), code, B, H, W, Cin, Cout, K, K, stride, pad, G, 1e-5, 1, None) == 0
+    y3 = torch.empty_like(y)
+    assert lib.hcm_op_maxpool3x3s2(_p(y2), _p(y3), code, B, conv.shape[2], conv.shape[3], Cout, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 32, 64, 2, 128, 16, 1), (3, 16, 16, 64, 128, 2, 256, 32, 1), (2, 16, 16, 64, 64, 1, 256, 16, 0)])
+def test_two_groupnorms_one_pass(prec, cfg):
+    """gn_apply2_kernel through hcm_op_conv2d_gn_res2: relu(GN(conv3(x)) + round(GN_ds(downsample(x2)))) normalised in one pass over the two un-normalised
+    maps, against torch fp32 -- the end of a stage-first bottleneck of habitat's GroupNorm ResNet (resnet_encoders.py:27-33)."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, W, Cin, Cin2, s2, Cout, G, relu = cfg
+    x = _rnd(B, Cin, H, W).to(tdt).float()
+    x2 = _rnd(B, Cin2, H * s2, W * s2, seed=4).to(tdt).float()
+    w = (_rnd(Cout, Cin, 1, 1, seed=1) * (3.0 / Cin) ** 0.5).to(tdt).float()
+    w2 = (_rnd(Cout, Cin2, 1, 1, seed=5) * (3.0 / Cin2) ** 0.5).to(tdt).float()
+    g, b = _rnd(Cout, seed=2) * 0.5 + 1.0, _rnd(Cout, seed=3) * 0.3
+    g2, b2 = _rnd(Cout, seed=6) * 0.5 + 1.0, _rnd(Cout, seed=7) * 0.3
+    ref = F.group_norm(F.conv2d(x, w), G, g, b, 1e-5) + F.group_norm(F.conv2d(x2, w2, stride=s2), G, g2, b2, 1e-5)
+    if relu:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+    xd, wd, x2d, w2d, gd, bd, g2d, b2d = nhwc(x), nhwc(w), nhwc(x2), nhwc(w2), g.cuda(), b.cuda(), g2.cuda(), b2.cuda()      # (kept alive across the launches)
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=tdt)
+    rc = lib.hcm_op_conv2d_gn_res2(_p(xd), _p(wd), _p(gd), _p(bd), _p(x2d), _p(w2d), _p(g2d), _p(b2d), _p(y), code,
+                                   B, H, W, Cin, Cin2, s2, Cout, G, 1e-5, relu, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 4 * tol * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_maxpool(prec):
     lib, L = _lib()
