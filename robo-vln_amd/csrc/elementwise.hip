@@ -855,7 +855,7 @@ hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, 
 // 16-bit operand, y32 = the stream itself.  32 lanes per row, float4 chunks.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void layernorm_f32in_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               T* __restrict__ y16, float* __restrict__ y32, int rows, float eps) {
+                                                               T* __restrict__ y16, float* __restrict__ y32, float* __restrict__ stats, int rows, float eps) {
     constexpr int CPL = D / 4 / 32;
     static_assert(CPL >= 1 && D % 128 == 0, "row must split into 32 x 16-byte chunks");
     const int sub = threadIdx.x & 31;
@@ -880,13 +880,16 @@ __global__ __launch_bounds__(256) void layernorm_f32in_kernel(const float* __res
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
     const float rstd = rsqrtf(sq * (1.0f / D) + eps);
+    // round 5: y32 == nullptr -- the f32 stream is not materialised; (mean, rstd) go to `stats` and the next projection's epilogue rebuilds the stream
+    // value from the pre-LayerNorm sum (igemm.hip rln_apply on an f32 residual)
+    if (stats && sub == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)row) = make_float2(mean, rstd);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int c = (i * 32 + sub) * 4;
         const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
         float o[4] = {(v[i][0] - mean) * rstd * g4.x + b4.x, (v[i][1] - mean) * rstd * g4.y + b4.y,
                       (v[i][2] - mean) * rstd * g4.z + b4.z, (v[i][3] - mean) * rstd * g4.w + b4.w};
-        st_chunk(y32 + (size_t)row * D + c, o);
+        if (y32) st_chunk(y32 + (size_t)row * D + c, o);
         T o4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Tr<T>::st(&o4[j], o[j]);
@@ -894,11 +897,11 @@ __global__ __launch_bounds__(256) void layernorm_f32in_kernel(const float* __res
     }
 }
 hipError_t launch_layernorm_f32in(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int dt, int rows, int D, float eps,
-                                  hipStream_t s) {
+                                  hipStream_t s, float* stats) {
     if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
     constexpr int rpb = 8;
     const dim3 grid((rows + rpb - 1) / rpb), block(32 * rpb);
-#define LF(T, DD) hipLaunchKernelGGL((layernorm_f32in_kernel<T, DD>), grid, block, 0, s, x, gamma, beta, (T*)y16, y32, rows, eps)
+#define LF(T, DD) hipLaunchKernelGGL((layernorm_f32in_kernel<T, DD>), grid, block, 0, s, x, gamma, beta, (T*)y16, y32, stats, rows, eps)
     if (D == 768) { if (dt == DT_BF16) LF(bf16, 768); else LF(f16, 768); }
     else if (D == 256) { if (dt == DT_BF16) LF(bf16, 256); else LF(f16, 256); }
     else if (D == 512) { if (dt == DT_BF16) LF(bf16, 512); else LF(f16, 512); }

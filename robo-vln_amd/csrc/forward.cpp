@@ -674,12 +674,30 @@ struct Fwd {
         float* xf = f32_stream ? alloc_f(rmax * D) : nullptr;       // the stream
         float* sumf = f32_stream ? alloc_f(rmax * D) : nullptr;     // branch + stream, in front of a LayerNorm
         if (f32_stream && !dry) ck(launch_convert_to_f32(x, dt, xf, (size_t)rows * D, s), "bert stream init");
-        auto linear_res_f32 = [&](const LinW& lw, const void* a, int lda) {     // sumf = a @ W^T + b + xf
-            if (dry) return;
-            IGemm g;
-            g.x = a; g.w = lw.w; g.bias = lw.bias; g.res = xf; g.res_f32 = 1; g.y = sumf; g.out_f32 = 1;
-            g.B = rows; g.Cin = lw.K; g.xC = lda; g.M = rows; g.N = lw.N; g.K = lw.K; g.Kp = lw.Kp; g.ldy = D; g.ldr = D; g.act = ACT_NONE;
-            ck(launch_igemm(g, lw.dt, s), "bert linear (f32 stream)");
+        // round 5: the stream value is not materialised by the LayerNorm launches any more.  Two f32 buffers alternate as "the pre-LayerNorm sum": a
+        // projection reads the PREVIOUS sum, rebuilds the stream value from it with the statistics its LayerNorm left (rln_apply in the epilogue: the
+        // LayerNorm kernel's own expression) and writes the next sum into the other buffer; the LayerNorm writes the bf16 operand + (mean, rstd) only
+        // (a 15.7 MB f32 write per LayerNorm gone at B = 64).  HCM_BERT_STREAM_MAT=1 (development build): the materialised stream of round 4.
+        static const bool stream_mat = dev_env("HCM_BERT_STREAM_MAT") != nullptr;
+        float* lnst = (f32_stream && !stream_mat && dev_env("HCM_BERT_FUSE") == nullptr) ? alloc_f(rmax * 2) : nullptr;        // (mean, rstd) per row of the latest LayerNorm (the fused-block experiment keeps the materialised stream)
+        float* cur_sum = nullptr;           // buffer holding the latest pre-LayerNorm sum (nullptr: xf holds the stream itself, as after the embedding)
+        const NormW* cur_ln = nullptr;      // ... and the LayerNorm that turns it into the stream
+        auto linear_res_f32 = [&](const LinW& lw, const void* a, int lda) {     // sum = a @ W^T + b + stream
+            float* dst = lnst ? ((cur_sum == sumf) ? xf : sumf) : sumf;
+            if (!dry) {
+                IGemm g;
+                g.x = a; g.w = lw.w; g.bias = lw.bias; g.res = lnst && cur_sum ? cur_sum : xf; g.res_f32 = 1; g.y = dst; g.out_f32 = 1;
+                if (lnst && cur_sum) { g.rln_stats = lnst; g.rln_gamma = cur_ln->gamma; g.rln_beta = cur_ln->beta; }
+                g.B = rows; g.Cin = lw.K; g.xC = lda; g.M = rows; g.N = lw.N; g.K = lw.K; g.Kp = lw.Kp; g.ldy = D; g.ldr = D; g.act = ACT_NONE;
+                ck(launch_igemm(g, lw.dt, s), "bert linear (f32 stream)");
+            }
+            cur_sum = dst;
+        };
+        auto ln_stream = [&](const NormW& n) {                                   // x (16-bit operand) = LayerNorm(latest sum); the stream stays implicit
+            if (lnst) {
+                if (!dry) ck(launch_layernorm_f32in(cur_sum, n.gamma, n.beta, x, nullptr, dt, rows, D, 1e-12f, s, lnst), "bert layernorm (f32 stream, statistics)");
+                cur_ln = &n;
+            } else if (!dry) ck(launch_layernorm_f32in(sumf, n.gamma, n.beta, x, xf, dt, rows, D, 1e-12f, s), "bert layernorm (f32 stream)");
         };
         int li = 0;
         mark("bert.embed");
@@ -760,7 +778,7 @@ struct Fwd {
                                           L, L, 3 * D, 3 * D, 3 * D, D, B, s, lens), "bert attention");
             if (f32_stream) {
                 linear_res_f32(l.o, ctxb, D);
-                if (!dry) ck(launch_layernorm_f32in(sumf, l.ln1.gamma, l.ln1.beta, x, xf, dt, rows, D, 1e-12f, s), "bert layernorm (f32 stream)");
+                ln_stream(l.ln1);
             } else {
                 linear(l.o, ctxb, rows, D, tmp, D, ACT_NONE, false, x, D);
                 ln(tmp, nullptr, l.ln1, nullptr, 0, x, rows, D, 1e-12f);
@@ -769,7 +787,7 @@ struct Fwd {
             linear(l.ff1, x, rows, D, hbuf, c.bert_inter, ACT_GELU, false);
             if (f32_stream) {
                 linear_res_f32(l.ff2, hbuf, c.bert_inter);
-                if (!dry) ck(launch_layernorm_f32in(sumf, l.ln2.gamma, l.ln2.beta, x, xf, dt, rows, D, 1e-12f, s), "bert layernorm (f32 stream)");
+                ln_stream(l.ln2);
             } else {
                 linear(l.ff2, hbuf, rows, c.bert_inter, tmp, D, ACT_NONE, false, x, D);
                 ln(tmp, nullptr, l.ln2, nullptr, 0, x, rows, D, 1e-12f);

@@ -274,7 +274,16 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmDev& p, f32x4 (&acc)[B
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
         }
-        if (p.res && p.res_f32) {
+        if (p.res && p.res_f32 && p.rln_stats) {
+            // round 5 (the "bf16" mode's f32 residual stream): res holds the PRE-LayerNorm f32 sum, the stream value is rebuilt here from the row
+            // statistics the LayerNorm launch left -- that launch no longer writes the f32 stream (N % 8 == 0: checked by the launcher)
+            const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldr + n;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+            float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            rln_apply(p, m, n, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        } else if (p.res && p.res_f32) {
             const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.ldr + n;
             const float4 r0 = *reinterpret_cast<const float4*>(rp);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
@@ -3275,7 +3284,7 @@ hipError_t launch_igemm(const IGemm& g, int dt, hipStream_t s) {
     if (d.cs_part && (d.gn_cg || d.bias || g.x_src_dt >= 0 || d.cs_cg < 1 || 32 % d.cs_cg || d.N % d.cs_cg || d.cs_hw % 64 || d.M % d.cs_hw))
         return hipErrorInvalidValue;
     d.rln_stats = g.rln_stats; d.rln_gamma = g.rln_gamma; d.rln_beta = g.rln_beta;
-    if (g.rln_stats && (!g.res || g.res_f32 || dt == DT_F32 || !g.rln_gamma || !g.rln_beta || (d.N % 8) || (d.ldr % 8) || g.groups > 1 || d.gn_cg || d.cs_part))
+    if (g.rln_stats && (!g.res || (g.res_f32 && !g.out_f32) || dt == DT_F32 || !g.rln_gamma || !g.rln_beta || (d.N % 8) || (d.ldr % 8) || g.groups > 1 || d.gn_cg || d.cs_part))
         return hipErrorInvalidValue;              // the LayerNorm-on-the-fly residual exists in the 16-byte residual paths of the 16-bit epilogues only
     if (g.ln_s) return hipErrorInvalidValue;      // the folded-LayerNorm consumer is gemm256f_kernel only (launch_gemm256)
     d.ln_part = g.ln_part_out; d.ln_part_P = g.ln_part_P;

@@ -204,7 +204,7 @@ hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, 
                             const float* post, int post_rows, void* y, int dt, int rows, int D, float eps, hipStream_t s);
 // LayerNorm of an f32 tensor with two outputs: y16 (T: the next GEMM's operand) and y32 (f32: the residual stream); D = 768 / 256 / 512
 hipError_t launch_layernorm_f32in(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int dt, int rows, int D, float eps,
-                                  hipStream_t s);
+                                  hipStream_t s, float* stats = nullptr);   // stats: (mean, rstd) per row out; y32 may be null then
 // BERT embeddings: y[b,l,:] = LN(word[id] + pos[l] + type0) ; tables f32
 hipError_t launch_bert_embed(const void* ids, int ids_dt, const float* word, const float* pos, const float* type0,
                              const float* gamma, const float* beta, void* y, int dt, int B, int L, int D, int vocab,
