@@ -855,7 +855,7 @@ hipError_t launch_layernorm(const void* x, const void* res, const float* gamma, 
 // 16-bit operand, y32 = the stream itself.  32 lanes per row, float4 chunks.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void layernorm_f32in_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               T* __restrict__ y16, float* __restrict__ y32, float* __restrict__ stats, int rows, float eps) {
+                                                               T* __restrict__ y16, float* __restrict__ y32, int rows, float eps) {
     constexpr int CPL = D / 4 / 32;
     static_assert(CPL >= 1 && D % 128 == 0, "row must split into 32 x 16-byte chunks");
     const int sub = threadIdx.x & 31;
@@ -880,28 +880,78 @@ __global__ __launch_bounds__(256) void layernorm_f32in_kernel(const float* __res
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
     const float rstd = rsqrtf(sq * (1.0f / D) + eps);
-    // round 5: y32 == nullptr -- the f32 stream is not materialised; (mean, rstd) go to `stats` and the next projection's epilogue rebuilds the stream
-    // value from the pre-LayerNorm sum (igemm.hip rln_apply on an f32 residual)
-    if (stats && sub == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)row) = make_float2(mean, rstd);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int c = (i * 32 + sub) * 4;
         const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
         float o[4] = {(v[i][0] - mean) * rstd * g4.x + b4.x, (v[i][1] - mean) * rstd * g4.y + b4.y,
                       (v[i][2] - mean) * rstd * g4.z + b4.z, (v[i][3] - mean) * rstd * g4.w + b4.w};
-        if (y32) st_chunk(y32 + (size_t)row * D + c, o);
+        st_chunk(y32 + (size_t)row * D + c, o);
         T o4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Tr<T>::st(&o4[j], o[j]);
         *reinterpret_cast<uint2*>(y16 + (size_t)row * D + c) = *reinterpret_cast<const uint2*>(o4);
     }
 }
+// ... and its round-5 sibling for the implicit stream: the 16-bit operand + (mean, rstd) per row, NO f32 output (forward.cpp bert(): the next projection's
+// epilogue rebuilds the stream value from the sum and these statistics).  A kernel of its own: layernorm_f32in_kernel's instruction stream is what the
+// goldens of the "bf16" mode and the fused-block experiment are pinned to, and adding two conditional stores to it changed its floating-point
+// contraction (1.6e-5 on the record).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void layernorm_f32in_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     T* __restrict__ y16, float* __restrict__ stats, int rows, float eps) {
+    constexpr int CPL = D / 4 / 32;
+    const int sub = threadIdx.x & 31;
+    const int row = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float v[CPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        ld_chunk(xr + (i * 32 + sub) * 4, v[i]);
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq * (1.0f / D) + eps);
+    if (sub == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)row) = make_float2(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (i * 32 + sub) * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+        T o4[4];
+        Tr<T>::st(&o4[0], (v[i][0] - mean) * rstd * g4.x + b4.x); Tr<T>::st(&o4[1], (v[i][1] - mean) * rstd * g4.y + b4.y);
+        Tr<T>::st(&o4[2], (v[i][2] - mean) * rstd * g4.z + b4.z); Tr<T>::st(&o4[3], (v[i][3] - mean) * rstd * g4.w + b4.w);
+        *reinterpret_cast<uint2*>(y16 + (size_t)row * D + c) = *reinterpret_cast<const uint2*>(o4);
+    }
+}
 hipError_t launch_layernorm_f32in(const float* x, const float* gamma, const float* beta, void* y16, float* y32, int dt, int rows, int D, float eps,
                                   hipStream_t s, float* stats) {
     if (dt != DT_BF16 && dt != DT_F16) return hipErrorInvalidValue;
+    if (stats) {                                   // the statistics form: no f32 output
+        if (y32) return hipErrorInvalidValue;
+        constexpr int rpb2 = 8;
+        const dim3 grid2((rows + rpb2 - 1) / rpb2), block2(32 * rpb2);
+#define LS(T, DD) hipLaunchKernelGGL((layernorm_f32in_stats_kernel<T, DD>), grid2, block2, 0, s, x, gamma, beta, (T*)y16, stats, rows, eps)
+        if (D == 768) { if (dt == DT_BF16) LS(bf16, 768); else LS(f16, 768); }
+        else if (D == 256) { if (dt == DT_BF16) LS(bf16, 256); else LS(f16, 256); }
+        else if (D == 512) { if (dt == DT_BF16) LS(bf16, 512); else LS(f16, 512); }
+        else return hipErrorInvalidValue;
+#undef LS
+        return hipGetLastError();
+    }
     constexpr int rpb = 8;
     const dim3 grid((rows + rpb - 1) / rpb), block(32 * rpb);
-#define LF(T, DD) hipLaunchKernelGGL((layernorm_f32in_kernel<T, DD>), grid, block, 0, s, x, gamma, beta, (T*)y16, y32, stats, rows, eps)
+#define LF(T, DD) hipLaunchKernelGGL((layernorm_f32in_kernel<T, DD>), grid, block, 0, s, x, gamma, beta, (T*)y16, y32, rows, eps)
     if (D == 768) { if (dt == DT_BF16) LF(bf16, 768); else LF(f16, 768); }
     else if (D == 256) { if (dt == DT_BF16) LF(bf16, 256); else LF(f16, 256); }
     else if (D == 512) { if (dt == DT_BF16) LF(bf16, 512); else LF(f16, 512); }
