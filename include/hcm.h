@@ -60,6 +60,9 @@ enum hcm_query_what {
     HCM_STEP_NONFINITE = 15,       /* overflow guard: (sample, recurrent step) pairs since hcm_finalize whose gate pre-activations were not all
                                       finite -- an fp16 overflow or a NaN anywhere upstream of the state encoder lands there, and the squashing
                                       cell would otherwise turn it into finite garbage.  0 on a healthy engine.  Synchronises the device. */
+    HCM_GATHER_JOINED = 17,        /* 1 when the handle's LAST hcm_act_gather / hcm_gather_poison call enqueued its ncclAllGather, 0 when it returned in
+                                      front of the collective (argument error, no communicator): a caller whose peers are about to enter the step's
+                                      all-gather must then join it itself (hcm_gather_poison) -- robo-vln_amd/policy.py act(gather=True) */
     HCM_RANGE_FOLD = 16            /* bit 1: a power-of-two scale was folded into convs of the GroupNorm depth trunks, bit 2: into the RGB trunks
                                       (the exact alternative to a bf16 fall-back where the network is scale-invariant; hcm_calibrate below) */
 };
@@ -362,6 +365,10 @@ int hcm_op_stem_conv_packed(const void* x, int x_dtype, const void* w, const flo
  * B * (H/2) * (W/4) * Cout elements of `dtype`. */
 int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                                  int Cout, float scale, void* scratch, void* half_map, void* stream);
+/* Round 6: the same three modules as ONE launch behind the frame packing (csrc/stem.hip: weights in registers, the packed frame streamed through
+ * an LDS ring, both pool halves in LDS).  W == 256, H % 4 == 0, Cout % 64 == 0, 16-bit dtypes; bit-identical to hcm_op_stem_conv_packed_pool. */
+int hcm_op_stem_pool_fused(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                           int Cout, float scale, void* scratch, void* stream);
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
 /* SimpleDepthCNN's first layer, Conv2d(1, 32, 8, stride 4) (+ bias, activation) straight from a raw f32 depth frame (B,H,H,1) in one pass
  * (csrc/simplecnn.hip; H a multiple of 4, <= 1024); w is the OHWI weight [32][64] in `dtype` (16-bit), scratch holds B*H*H + 64 elements of

@@ -13,7 +13,7 @@ HCM_ENC_RESNET, HCM_ENC_SIMPLECNN = 0, 1
 HCM_LSTM, HCM_GRU = 0, 1
 (HCM_NUM_RECURRENT_LAYERS, HCM_HIDDEN_SIZE, HCM_NUM_ACTIONS, HCM_RECORD_WIDTH, HCM_WORKSPACE_BYTES,
  HCM_WEIGHT_BYTES, HCM_MAX_BATCH, HCM_GRAPH_LAUNCHES, HCM_EAGER_LAUNCHES, HCM_FP16_FALLBACK, HCM_CALIB_MAX_BERT, HCM_CALIB_MAX_DEPTH,
- HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE, HCM_RANGE_FOLD) = range(17)
+ HCM_CALIB_NONFINITE, HCM_CALIB_MAX_RGB, HCM_CALIB_MAX_VLA, HCM_STEP_NONFINITE, HCM_RANGE_FOLD, HCM_GATHER_JOINED) = range(18)
 # `precision` of HCMEngine / CMAEngine -> hcm_config.precision (include/hcm.h): "fp16" is the measured 16-bit mode
 PRECISIONS = {"fp32": HCM_F32, "fp16": HCM_F16, "bf16": HCM_BF16}
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -87,6 +87,7 @@ EXPORTS = {
     "hcm_op_conv2d_gn_large": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 11 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_stem_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_stem_conv_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "hcm_op_stem_pool_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p]),
     "hcm_op_stem_conv_packed_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_op_depth_conv8x8s4": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "hcm_op_stem_scratch_bytes": (C.c_int64, [C.c_int] * 3),

@@ -916,6 +916,7 @@ int hcm_query(hcm_handle h, int what, int64_t* out) {
         case HCM_EAGER_LAUNCHES: *out = h->eager_launches; break;
         case HCM_FP16_FALLBACK: *out = h->fp16_fallback; break;
         case HCM_RANGE_FOLD: *out = h->range_fold; break;
+        case HCM_GATHER_JOINED: *out = h->gather_joined; break;
         case HCM_CALIB_MAX_BERT: *out = (int64_t)h->calib_max[0]; break;
         case HCM_CALIB_MAX_DEPTH: *out = (int64_t)h->calib_max[1]; break;
         case HCM_CALIB_NONFINITE: *out = (int64_t)h->calib_bad[0] + (int64_t)h->calib_bad[1] + (int64_t)h->calib_bad[2] + (int64_t)h->calib_bad[3]; break;
@@ -1158,6 +1159,16 @@ int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, cons
     rc = op_rc(launch_igemm(g, dt, (hipStream_t)stream));
     if (rc != HCM_OK) return rc;
     return op_rc(launch_vpool3s2(half_map, y, dt, B, g.Ho, g.Wo / 2, Cout, (hipStream_t)stream));
+}
+int hcm_op_stem_pool_fused(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                           int Cout, float scale, void* scratch, void* stream) {
+    const int dt = op_dt(dtype);
+    if (!scratch || !rgb_stem_pool_ok(dt, H, W, Cout, 224)) return HCM_ERR_ARG;
+    const int sdt = x_dtype == HCM_U8 ? DT_U8 : x_dtype == HCM_F32 ? DT_F32 : -1;
+    if (sdt < 0) return HCM_ERR_ARG;
+    const int rc = op_rc(launch_pack_frame(x, sdt, scratch, dt, B, H, W, scale, (hipStream_t)stream));
+    if (rc != HCM_OK) return rc;
+    return op_rc(launch_rgb_stem_pool(scratch, w, bias, y, dt, B, H, W, Cout, (hipStream_t)stream));
 }
 // scratch of the operator entry points that need a temporary (split-K partials, converted frames): grown on demand, test / probe use only
 static void* op_scratch(size_t bytes) {

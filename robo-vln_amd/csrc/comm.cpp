@@ -126,10 +126,13 @@ int hcm_comm_abort(hcm_handle h) {
 
 int hcm_gather_poison(hcm_handle h, int B, float* record, float* gathered, void* stream) {
     if (!h) return HCM_ERR_ARG;
+    h->gather_joined = 0;
     if (!h->comm) return fail(h, HCM_ERR_STATE, "hcm_gather_poison: no communicator (hcm_comm_init)");
-    if (!record || !gathered || B < 1 || B > h->cfg.max_batch) return fail(h, HCM_ERR_ARG, "hcm_gather_poison: bad buffer / batch");
+    // (no engine buffer is involved: any B >= 1 is accepted, also one beyond max_batch -- the peers' count is what has to be matched)
+    if (!record || !gathered || B < 1) return fail(h, HCM_ERR_ARG, "hcm_gather_poison: bad buffer / batch");
     (void)hipMemsetAsync(record, 0xFF, (size_t)B * 7 * sizeof(float), (hipStream_t)stream);
     Rccl& r = rccl();
+    h->gather_joined = 1;
     const int nrc = r.AllGather(record, gathered, (size_t)B * 7, kNcclFloat32, (Comm)h->comm, (hipStream_t)stream);
     if (nrc != kNcclSuccess) return fail(h, HCM_ERR_HIP, nccl_msg(r, "ncclAllGather", nrc));
     return HCM_OK;
@@ -139,6 +142,7 @@ int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* de
                    int B, int L, const float* hi_h_in, const float* lo_h_in, const float* mask, float* record, float* hi_h_out, float* lo_h_out,
                    int flags, float* gathered, void* stream) {
     if (!h) return HCM_ERR_ARG;
+    h->gather_joined = 0;       // hcm_query(HCM_GATHER_JOINED): the caller's way to tell "refused in front of the collective" from "failed inside the step"
     if (!h->comm) return fail(h, HCM_ERR_STATE, "hcm_act_gather: no communicator (hcm_comm_init)");
     if (!gathered) return fail(h, HCM_ERR_ARG, "hcm_act_gather: null gather buffer");
     // Pure argument errors return WITHOUT joining the collective: every rank passes the same B (the collective's element count must agree across
@@ -154,6 +158,7 @@ int hcm_act_gather(hcm_handle h, const void* rgb, int rgb_dtype, const float* de
     if (rc != HCM_OK) (void)hipMemsetAsync(record, 0xFF, (size_t)B * 7 * sizeof(float), (hipStream_t)stream);
     // stream order makes the record complete before the collective reads it; every rank contributes B rows of 7 floats
     Rccl& r = rccl();
+    h->gather_joined = 1;
     const int nrc = r.AllGather(record, gathered, (size_t)B * 7, kNcclFloat32, (Comm)h->comm, (hipStream_t)stream);
     if (rc != HCM_OK) return fail(h, rc, step_err + " [this rank still contributed a NaN record to the step's all-gather]");
     if (nrc != kNcclSuccess) return fail(h, HCM_ERR_HIP, nccl_msg(r, "ncclAllGather", nrc));

@@ -309,6 +309,8 @@ struct Fwd {
         // half width), a vertical-only pool follows; exact.  Not while taps are captured: `_conv1` is the full-width map.
         static const bool no_hpool = dev_env("HCM_NO_STEM_HPOOL") != nullptr;
         const bool hpool = packed && !no_hpool && !ctx->taps_on && Wo >= 2 && Wo <= 128 && !(Wo & (Wo - 1)) && (c1 % 64) == 0;
+        static const bool no_stem_fuse = dev_env("HCM_NO_STEM_FUSE") != nullptr;
+        const bool fused_stem = packed && hpool && !no_stem_fuse && t.conv1_packed.groups == 1 && rgb_stem_pool_ok(t.conv1_packed.dt, st.H, st.W, c1, t.conv1_packed.Kp);
         // GroupNorm statistics of the packed depth stem from its conv's epilogue (see conv_gn)
         static const bool no_cs_stem = dev_env("HCM_NO_GN_EPISTATS") != nullptr;
         float* stem_stats = nullptr;
@@ -328,6 +330,15 @@ struct Fwd {
                 ck(launch_igemm(g, w.dt, s), "depth stem conv (packed)");
                 calib_check(slot[0], w.dt, g.M, w.Cout, w.Cout, w.calib_pos);
             }
+        } else if (fused_stem) {
+            // round 6: pack -> ONE launch for conv1 + ReLU + both halves of the max-pool (stem.hip); the pooled map lands in slot[1]
+            void* pk = alloc_t(pack_frame_elems(B, st.H, st.W));
+            if (!dry) {
+                ck(launch_pack_frame(st.x, st.x_dt, pk, t.conv1_packed.dt, B, st.H, st.W, st.scale, s), "pack frame");
+                ck(launch_rgb_stem_pool(pk, t.conv1_packed.w, t.conv1_packed.bias, slot[1], t.conv1_packed.dt, B, st.H, st.W, c1, s), "stem conv + max-pool (one launch)");
+                // (the pooled map has the conv map's maximum: ReLU'd values, max-pooled)
+                calib_check(slot[1], t.conv1_packed.dt, B * (Ho / 2) * (Wo / 2), c1, c1);
+            }
         } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
         else stem_conv(fast ? t.conv1_rowrun : t.conv1, st, B, 7, 2, 3, slot[0], Ho, Wo, t.gn ? ACT_NONE : ACT_RELU);
@@ -344,7 +355,9 @@ struct Fwd {
         } else if (t.gn) gn(slot[0], nullptr, t.n_conv1, B, Ho * Wo, c1, G, true, 0, stem_eps);
         if (!hpool) tap(tapname + "_conv1", slot[0], true, {B, Ho, Wo, c1});
         const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
-        if (hpool) {
+        if (fused_stem) {
+            // (pooled by the stem launch)
+        } else if (hpool) {
             if (!dry) ck(launch_vpool3s2(slot[0], slot[1], dt, B, Ho, Wo / 2, c1, s), "maxpool (vertical half)");
         } else if (gn_pool) {
             if (!dry) ck(launch_maxpool3x3s2_gn(slot[0], slot[1], t.n_conv1.gamma, t.n_conv1.beta, stem_stats, Ho * Wo / 64, stem_eps, G, t.conv1_packed.dt, B, Ho, Wo, c1,
@@ -611,9 +624,16 @@ struct Fwd {
         // Round 5: the three convolutions of the depth CNN in ONE launch, both intermediate maps in LDS (simplecnn.hip: simplecnn3_kernel; bit-identical
         // to the launches below; HCM_NO_CNN3=1 of the development build: the launches)
         static const bool no_cnn3 = dev_env("HCM_NO_CNN3") != nullptr;
-        if (!no_cnn3 && w.cin == 1 && x_dt == DT_F32 && H == W && w.c1_frag && w.c2_frag && w.c0_packed.w && w.c0_packed.K == 64 && w.c0_packed.Kp == 64 &&
-            simplecnn3_ok(dt, H)) {
+        // (the fp16 calibration forward takes the launch-per-conv form: both intermediate maps of the fused launch live in LDS only, so their
+        //  range would otherwise never reach calib_check and an overflow in conv1 / conv2 could not trigger the bf16 re-build or a range fold)
+        const bool calibrating = ctx->calib && dt == DT_F16;
+        if (!no_cnn3 && !calibrating && w.cin == 1 && x_dt == DT_F32 && H == W && w.c1_frag && w.c2_frag && w.c0_packed.w && w.c0_packed.K == 64 &&
+            w.c0_packed.Kp == 64 && simplecnn3_ok(dt, H)) {
             void* y2f = alloc_t((size_t)B * h3 * w3 * 32);
+            if (dry && dt == DT_F16) {
+                // the sizing pass also reserves what the calibration forward's launch-per-conv form allocates beyond y2f
+                (void)alloc_t((size_t)B * h1 * w1 * 32); (void)alloc_t((size_t)B * H * W + 64); (void)alloc_t((size_t)B * h2 * w2 * 64);
+            }
             if (!dry) ck(launch_simplecnn3((const float*)x, w.c0_packed.w, w.c0_packed.bias, w.c1_frag, w.c1.bias, w.c2_frag, w.c2.bias, y2f, dt, B, H, s),
                          "simple cnn (three convolutions, one launch)");
             linear(w.fc, y2f, B, h3 * w3 * 32, out, ld, ACT_RELU, true);
@@ -642,6 +662,7 @@ struct Fwd {
                 g.M = B * h1 * w1; g.N = 32; g.K = w.c0_packed.K; g.Kp = w.c0_packed.Kp; g.ldy = 32; g.ldr = 32; g.act = ACT_RELU;
                 ck(launch_igemm(g, dt, s), "simple cnn conv0 (packed)");
             }
+            calib_check(y0, dt, B * h1 * w1, 32, 32);
         } else {
             stem_conv(w.c0, Stem{x, x_dt, scale, H, W, w.cin}, B, 8, 4, 0, y0, h1, w1, ACT_RELU);
         }

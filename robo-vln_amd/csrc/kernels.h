@@ -163,6 +163,11 @@ hipError_t launch_pack_frame(const void* x, int src_dt, void* y, int dt, int B, 
 // border = 0: plain [B][H][W][4] packing (SimpleCNN's un-padded 8x8/4 first conv: a kernel row is 8 px x 4 ch = 32 elements,
 // a "virtual pixel" of the GEMM the 4-pixel stride = 16 elements)
 inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
+// round 6 (stem.hip): conv1 (7x7/2, BN folded) + ReLU + MaxPool2d(3, 2, 1) on the packed frame as ONE launch, weights in registers, the frame
+// streamed through an LDS ring; y = pooled map [B][H/4][W/4][C].  W == 256, H % 4 == 0, C % 64 == 0; bit-identical to the packed stem conv
+// with the horizontal pool epilogue + launch_vpool3s2.
+bool rgb_stem_pool_ok(int dt, int H, int W, int C, int Kp);
+hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias, void* y, int dt, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);   // -> [B][H/2+6][W/2+8]
 // vertical half of MaxPool2d(3, 2, 1): x [B][H][W][C] -> y [B][(H+1)/2][W][C] (rows 2p-1, 2p, 2p+1)

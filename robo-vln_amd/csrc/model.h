@@ -185,6 +185,7 @@ struct hcm_ctx {
     // hcm_guard_poll: the overflow-guard word travels to a pinned host word behind the caller's stream; read back without a synchronisation
     unsigned* guard_host = nullptr; hipEvent_t guard_ev = nullptr; bool guard_pending = false; unsigned guard_last = 0u;
     void* comm = nullptr; int comm_world = 1, comm_rank = 0;      // RCCL communicator of hcm_comm_init (comm.cpp)
+    int gather_joined = 0;      // the LAST hcm_act_gather / hcm_gather_poison call enqueued its ncclAllGather (hcm_query(HCM_GATHER_JOINED))
     bool unusable = false;          // a re-build after calibration could not get its workspace back
     std::vector<void*> dev_allocs;
     size_t weight_bytes = 0;

@@ -110,7 +110,7 @@ class HCMEngine:
         self._guard_tick = 0
         self._guard_seen = 0
         self._gather_B = 0                              # per-rank batch of the library collective (act(gather=True)), 0 before the first such call
-        self._gather_entered = False
+        self._gather_called = False
         self.guard_alarm = 0                            # deferred alarms of act(gather=True) steps, see guard_check()
         self._gstream = None
         self._static = None
@@ -364,6 +364,8 @@ class HCMEngine:
         host_frames = bool(flags & _lib.HCM_ACT_HOST_FRAMES)
         with torch.cuda.device(self.device):
             rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
+            if gather:
+                self._gather_B = B
             L = ids.shape[1]
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             if self._gstream is None:
@@ -408,7 +410,7 @@ class HCMEngine:
                 if gather:
                     if "gat" not in st:
                         st["gat"] = [torch.empty(self.comm_world * B, 7, device=self.device) for _ in range(2)]
-                    self._gather_entered = True
+                    self._gather_called = True
                     _lib.check(self._lib.hcm_act_gather(self._h, g_rgb.data_ptr(), _TORCH_DT[rgb.dtype], g_depth.data_ptr(),
                                                         g_ids.data_ptr(), _TORCH_DT[ids.dtype], _ptr(g_lens), B, L, st["hh"][1 - i].data_ptr(),
                                                         st["lh"][1 - i].data_ptr(), g_m.data_ptr(), st["rec"][i].data_ptr(),
@@ -474,11 +476,14 @@ class HCMEngine:
         # env-sharded ranks: whatever fails on THIS rank in front of the library (a malformed observation, a shape error) must not leave the peers
         # alone inside this step's all-gather -- the rank joins it with an all-NaN block (hcm_gather_poison) and raises afterwards; the peers see
         # its NaN rows and leave at the same step (rollout()).  Failures inside hcm_act_gather take the same path in the library itself.
-        self._gather_entered = False
+        self._gather_called = False
         try:
             return self._act_impl(observations, hi_hidden, lo_hidden, masks, out, reuse_instruction, host_frames, True)
         except Exception:
-            if not self._gather_entered and self._gather_B:
+            # did this rank's all-gather go out?  Only the library knows: hcm_act_gather returns pure argument errors (a batch beyond this engine's
+            # max_batch, a communicator aborted locally) WITHOUT joining, and such a cause can be rank-local (round-5 advisor)
+            joined = self._gather_called and self.query(_lib.HCM_GATHER_JOINED) == 1
+            if not joined and self._gather_B and self.comm_world:
                 with torch.cuda.device(self.device):
                     B = self._gather_B
                     scratch = torch.empty((1 + self.comm_world) * B, 7, device=self.device, dtype=torch.float32)
@@ -487,13 +492,9 @@ class HCMEngine:
             raise
 
     def _act_impl(self, observations, hi_hidden, lo_hidden, masks, out, reuse_instruction, host_frames, gather):
-        if gather and not self._gather_B:
-            # the per-rank batch of the collective (every rank passes the same B): known from the first call on, so that a later call that
-            # cannot even read its observations still knows how many rows its peers expect
-            try:
-                self._gather_B = int(observations["rgb"].shape[0])
-            except Exception:
-                self._gather_B = 0
+        # (the per-rank batch of the collective -- every rank passes the same B -- is recorded from the VALIDATED observation of every gather call,
+        #  _obs() below, so that a later call that cannot even read its observations still knows how many rows its peers expect, and a job that
+        #  changes its agreed B between steps does not poison with a stale count: round-5 advisor)
         flags = (_lib.HCM_ACT_REUSE_INSTRUCTION if reuse_instruction else 0) | (_lib.HCM_ACT_HOST_FRAMES if host_frames else 0)
         if self._graph:
             cg = self._chain_graphs
@@ -515,12 +516,14 @@ class HCMEngine:
             return rec, hh2, lh2
         with torch.cuda.device(self.device):
             rgb, depth, ids, lens, B = self._obs(observations, True, host_frames)
+            if gather:
+                self._gather_B = B
             hh, lh, m = self._hidden(hi_hidden, B), self._hidden(lo_hidden, B), self._mask(masks, B)
             hh2, lh2 = torch.empty_like(hh), torch.empty_like(lh)
             if gather:
                 local = torch.empty(B, 7, device=self.device, dtype=torch.float32)
                 rec = out if out is not None else torch.empty(self.comm_world * B, 7, device=self.device, dtype=torch.float32)
-                self._gather_entered = True
+                self._gather_called = True
                 _lib.check(self._lib.hcm_act_gather(self._h, rgb.data_ptr(), _TORCH_DT[rgb.dtype], depth.data_ptr(), ids.data_ptr(),
                                                     _TORCH_DT[ids.dtype], _ptr(lens), B, ids.shape[1], hh.data_ptr(), lh.data_ptr(), m.data_ptr(),
                                                     local.data_ptr(), hh2.data_ptr(), lh2.data_ptr(), flags, rec.data_ptr(), self._stream()), self._h)

@@ -68,8 +68,23 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
     # the library's own collective (hcm_act_gather, after engine.comm_init()) when there is one; torch.distributed otherwise (gloo CPU tests,
     # engines without a communicator)
     lib_gather = world > 1 and getattr(getattr(policy, "engine", None), "comm_world", 0) == world
+    nan_flag = None
+
+    def leave_if_poisoned(flag):
+        rows, at = flag
+        rows = rows.cpu()                       # waits for step `at` only; every rank reads the same gathered record, hence the same answer
+        if bool(rows.any()):
+            per = rows.numel() // world         # rows per rank of the gathered record (not num_envs: the caller's obs_fn decides the batch)
+            bad_ranks = sorted({int(r) // per for r in torch.nonzero(rows).flatten()})
+            policy.engine.comm_abort()
+            raise RuntimeError(f"rollout step {at}: rank(s) {bad_ranks} contributed a NaN action record to the all-gather (their step failed, "
+                               "or their activations left the arithmetic range); communicator aborted on this rank")
+
     for t in range(steps):
         obs = obs_fn(t, lo, hi)
+        if nan_flag is not None:                # in front of this step's collective: did every rank survive the previous one?
+            leave_if_poisoned(nan_flag)
+            nan_flag = None
         reuse = cache_instruction and t > 0
         if reuse and prev_done is not None and bool(prev_done.any()):
             idx = torch.nonzero(prev_done).flatten().cpu().numpy()
@@ -83,14 +98,12 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
         if lib_gather:
             full = rec
             # A peer whose step failed contributed an all-NaN block (hcm_act_gather) and is about to raise out of its own act(): it will never
-            # enter the next step's collective.  Every rank sees the same gathered record, so every healthy rank leaves HERE, at the same step,
-            # and tears its communicator down (no watchdog on it) instead of blocking one step later (round-4 advisor).  The env loop reads
-            # the record on the host every step anyway (actions go to the simulators), so the test costs no extra synchronisation there.
-            if bool(torch.isnan(full).any()):
-                bad_ranks = sorted({int(r) for r in torch.nonzero(torch.isnan(full).any(1)).flatten().cpu() // num_envs})
-                policy.engine.comm_abort()
-                raise RuntimeError(f"rollout step {t}: rank(s) {bad_ranks} contributed a NaN action record to the all-gather (their step failed, "
-                                   "or their activations left the arithmetic range); communicator aborted on this rank")
+            # enter the next step's collective.  Every rank sees the same gathered record, so every healthy rank leaves at the same point --
+            # in front of the NEXT step's act() (or at the end of the rollout) -- and tears its communicator down (no watchdog on it) instead
+            # of blocking inside that collective (round-4 advisor).  The test itself is enqueued here and READ there: one flag copied to pinned
+            # host memory behind the step, so the host is free to run done_fn / obs_fn / after_step while the device finishes the step
+            # (round-5 advisor: the blocking `.any()` read sat in front of all of that).
+            nan_flag = (torch.isnan(full).any(1).to(torch.int32), t)
         elif world > 1:
             full = torch.empty(global_envs, RECORD_WIDTH, device=rec.device, dtype=rec.dtype)
             gather_records(rec, full)
@@ -107,6 +120,8 @@ def rollout(policy, obs_fn, done_fn, num_envs, steps, num_recurrent_layers, hidd
             every = getattr(eng, "_guard_every", 0)
             if every > 0 and (t + 1) % every == 0:
                 eng.guard_check()
+    if nan_flag is not None:
+        leave_if_poisoned(nan_flag)
     # overflow guard of the HIP engine (hcm_query(HCM_STEP_NONFINITE)): a NaN / inf anywhere upstream of the state encoders would
     # otherwise leave the squashing cells as a finite, wrong action -- checked once per rollout (it synchronises), loudly
     if guard is not None:

@@ -23,7 +23,7 @@ from robo_vln_amd import synth
 from robo_vln_amd.config import HCMConfig
 from robo_vln_amd.policy import HCMEngine
 import os
-cfg = HCMConfig(rgb_hw=128, depth_hw=int(os.environ.get("HCMT_DEPTH_HW", "128")), instr_len=int(os.environ.get("HCMT_L", "20")),
+cfg = HCMConfig(rgb_hw=int(os.environ.get("HCMT_RGB_HW", "128")), depth_hw=int(os.environ.get("HCMT_DEPTH_HW", "128")), instr_len=int(os.environ.get("HCMT_L", "20")),
                 vla_layers=int(os.environ.get("HCMT_VLA_LAYERS", "1")), bert_layers=1).validate()
 B = 3
 hi_sd, lo_sd = synth.make_weights(cfg, seed=5)
@@ -72,6 +72,19 @@ def test_fused_rgb_trunk_launches_equal_the_separate_ones():
     assert np.isfinite(default["rec"]).all()
     # shipped configuration (down-sample conv folded into the expansion GEMM): one rounding fewer on that path
     assert np.abs(default["rec"] - plain["rec"]).max() <= 1e-2
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_one_launch_stem_equals_conv_and_pool_launches(prec):
+    """Round 6: conv1 + ReLU + max-pool of the 256-pixel RGB frame as one launch (csrc/stem.hip) against the stem conv with the horizontal pool
+    epilogue + the vertical pool kernel (HCM_NO_STEM_FUSE=1): the whole step agrees to the bit (pair trunk: two 64-channel groups per band)."""
+    with tempfile.TemporaryDirectory() as d:
+        env = {"HCMT_RGB_HW": "256", "HCMT_PREC": prec}
+        fused = _run(env, os.path.join(d, "a.npz"))
+        plain = _run(dict(env, HCM_NO_STEM_FUSE="1"), os.path.join(d, "b.npz"))
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(fused[k], plain[k]), k
+    assert np.isfinite(fused["rec"]).all()
 
 
 @pytest.mark.parametrize("env", [

@@ -625,6 +625,43 @@ def test_stem_conv_packed_pool(prec, cfg):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("cfg", [(2, 256, 128, "f32"), (3, 72, 64, "u8"), (1, 8, 64, "f32"), (2, 136, 128, "u8"), (5, 64, 192, "f32")])
+def test_stem_pool_one_launch(prec, cfg):
+    """Round 6 (csrc/stem.hip): conv1 + ReLU + MaxPool2d(3, 2, 1) of a 256-pixel-wide frame as ONE launch -- weights in registers, the packed
+    frame through an LDS ring, both pool halves in LDS -- is BIT-identical to the packed stem + stand-alone pool.  H = 72 / 136: a second band
+    that starts with the recomputed odd row above it; H = 8: two pooled rows."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    B, H, Cout, src = cfg
+    W = 256
+    xf = (_rnd(B, H, W, 3) * 0.5 + 0.5) * 255
+    x = xf.to(torch.uint8).cuda() if src == "u8" else xf.cuda()
+    xcode = L.HCM_U8 if src == "u8" else L.HCM_F32
+    w = _rnd(Cout, 224, scale=0.1, seed=1).cuda().to(tdt)
+    b = _rnd(Cout, scale=0.3, seed=2).cuda()
+    scratch = torch.empty(lib.hcm_op_stem_scratch_bytes(B, H, W), device="cuda", dtype=torch.uint8)
+    full = torch.empty(B, H // 2, W // 2, Cout, device="cuda", dtype=tdt)
+    ref = torch.empty(B, H // 4, W // 4, Cout, device="cuda", dtype=tdt)
+    assert lib.hcm_op_stem_conv_packed(_p(x), xcode, _p(w), _p(b), _p(full), code, B, H, W, Cout, 1 / 255.0, L.ACT_RELU, _p(scratch), None) == 0
+    assert lib.hcm_op_maxpool3x3s2(_p(full), _p(ref), code, B, H // 2, W // 2, Cout, None) == 0
+    y = torch.full((B, H // 4, W // 4, Cout), float("nan"), device="cuda", dtype=tdt)
+    assert lib.hcm_op_stem_pool_fused(_p(x), xcode, _p(w), _p(b), _p(y), code, B, H, W, Cout, 1 / 255.0, _p(scratch), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16))
+    # a NaN pixel poisons exactly the windows torch's max-pool poisons (the unsigned 16-bit maximum ranks NaN patterns above every number)
+    if src == "f32":
+        x2 = x.clone(); x2[0, H // 2, 100, 1] = float("nan")
+        assert lib.hcm_op_stem_conv_packed(_p(x2), xcode, _p(w), _p(b), _p(full), code, B, H, W, Cout, 1 / 255.0, L.ACT_RELU, _p(scratch), None) == 0
+        assert lib.hcm_op_maxpool3x3s2(_p(full), _p(ref), code, B, H // 2, W // 2, Cout, None) == 0
+        assert lib.hcm_op_stem_pool_fused(_p(x2), xcode, _p(w), _p(b), _p(y), code, B, H, W, Cout, 1 / 255.0, _p(scratch), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(torch.isnan(y.float()), torch.isnan(ref.float())) and torch.isnan(ref.float()).any()
+        fin = ~torch.isnan(ref.float())
+        assert torch.equal(y.view(torch.int16)[fin], ref.view(torch.int16)[fin])
+    assert lib.hcm_op_stem_pool_fused(_p(x), xcode, _p(w), _p(b), _p(y), code, B, H, 128, Cout, 1 / 255.0, _p(scratch), None) != 0      # other widths: refused
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("cfg", [
     # B, H, Cin, Cout, K, stride, pad, groups, residual, relu      (output maps of 256 .. 4096 pixels)
     (2, 64, 32, 64, 1, 1, 0, 32, False, True),
