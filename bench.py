@@ -210,7 +210,7 @@ def dtype_string(args, eng):
     if args.precision == "fp32":
         return "fp32"
     if args.precision == "bf16":
-        return "bf16 (bf16 storage and MFMA in BERT, the RGB trunks and the cross-modal block; the GroupNorm depth trunks on range-folded fp16; fp32 accumulate, fp32 recurrent state; DESIGN.md section 5)"
+        return "bf16 (bf16 storage and MFMA in BERT -- f32 residual stream -- and the cross-modal block; both trunk kinds on range-folded fp16 tiles; fp32 accumulate, fp32 recurrent state; DESIGN.md section 4)"
     fb = sorted(eng.fp16_fallback)
     fold = sorted(getattr(eng, "range_fold", ()))
     tail = ("; range fold: " + ", ".join(fold)) if fold else ""
@@ -425,6 +425,10 @@ def main():
     ap.add_argument("--h2d-prestage", action="store_true", help="with --h2d: copy the frames in front of the step on the caller's stream instead of "
                     "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--configs-leg", type=float, default=1.5, help="N = 1 default run: seconds per configuration of the bounded `configs` block (BASELINE configs[0], [3], [4] "
+                    "at their own batch sizes: value, ms_per_step, roofline.frac); 0 = skip")
+    ap.add_argument("--gather-leg", type=float, default=1.0, help="N = 1 default run: seconds per side of `gather_world1` -- the same step with the library's collective "
+                    "(hcm_act_gather through real librccl on a one-rank communicator) against the plain step; 0 = skip")
     args = ap.parse_args()
     if args.chain_graphs is None:
         args.chain_graphs = "auto" if args.h2d else "0"
@@ -700,6 +704,91 @@ def main():
         except Exception as e:           # never lose the headline number to the extra leg
             single_env = {"error": str(e)}
 
+    default_run = (world == 1 and args.config == 1 and args.precision == "fp16" and not STUB and not args.h2d and not args.reuse_instruction
+                   and not args.batch and not args.total_batch and not args.no_graph)
+    # What the step's collective costs, measurable on ONE GPU (SCALE_r* has never had a node): the same timed region with the record going through
+    # hcm_act_gather -- real librccl, a one-rank communicator, ncclAllGather enqueued by the library behind the graph replay -- against the plain
+    # hcm_act_ex step, interleaved A/B/A/B on the SAME engine.  A first multi-GPU run can lose to this (and to the host side, `host_us_per_step`).
+    gather_w1 = None
+    if default_run and args.gather_leg > 0:
+        try:
+            created = not dist.is_initialized()
+            if created:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+            eng.comm_init()
+            n5 = max(20, int(args.gather_leg / (dt / args.steps)))
+
+            def span(gather):
+                for _ in range(4):
+                    raw_step(None, gather=gather)
+                _sync()
+                t0 = time.perf_counter()
+                for _ in range(n5):
+                    raw_step(None, gather=gather)
+                host = (time.perf_counter() - t0) / n5
+                _sync()
+                return (time.perf_counter() - t0) / n5, host
+            plain, gath = [], []
+            for _ in range(3):
+                plain.append(span(False)); gath.append(span(True))
+            pm, gm = min(p[0] for p in plain), min(g[0] for g in gath)
+            gather_w1 = {"value": round(B / gm, 2), "ms_per_step": round(gm * 1e3, 3), "plain_ms_per_step": round(pm * 1e3, 3),
+                         "delta_us": round((gm - pm) * 1e6, 1), "host_us_per_step": round(min(g[1] for g in gath) * 1e6, 1),
+                         "plain_host_us_per_step": round(min(p[1] for p in plain) * 1e6, 1), "steps_per_side": n5, "rounds": 3,
+                         "note": "act(gather=True): hcm_act_gather = graph replay + ONE ncclAllGather of the (B,7) record through librccl on a one-rank communicator, "
+                                 "against act() on the same engine, best of three interleaved rounds each; what the collective adds at world 1 (no wire time)"}
+            eng.comm_abort()
+            if created:
+                dist.destroy_process_group()
+        except Exception as e:           # never lose the headline number to the extra leg
+            gather_w1 = {"error": str(e)}
+
+    # The other BASELINE configurations in the driver-visible line (bounded: --configs-leg seconds each): configs[0] (the reference's own CPU-runnable
+    # case), configs[3] (depth-only SimpleCNN + 1-layer block, B = 256), configs[4] (ResNet-50 + 6-layer decoder, L = 160, B = 128, high-level model).
+    configs_block = None
+    if default_run and args.configs_leg > 0:
+        import copy
+        configs_block = {}
+        for idx in (0, 3, 4):
+            try:
+                a6 = copy.copy(args)
+                a6.config, a6.batch = idx, 0
+                if idx == 3:
+                    _, B6, eng6, step6, alg6, _ = build_probe_workload(a6)
+                else:
+                    _, B6, eng6, step6, _, _ = build_act_workload(a6, idx, rank, world, local_rank)
+                for _ in range(12):
+                    step6()
+                _sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step6()
+                _sync()
+                est = (time.perf_counter() - t0) / 10
+                n6 = max(20, int(args.configs_leg / est))
+                t0 = time.perf_counter()
+                for _ in range(n6):
+                    step6()
+                _sync()
+                ms6 = (time.perf_counter() - t0) / n6 * 1e3
+                ent = {"workload": WORKLOAD[idx], "per_gpu_batch": B6, "steps": n6, "value": round(B6 / ms6 * 1e3, 2), "unit": "env-steps/s", "ms_per_step": round(ms6, 4)}
+                if idx == 3:
+                    tf6 = 0.2422 * B6 / ms6
+                    ent["roofline"] = {"bound": "mfma", "achieved": round(tf6, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf6 / PEAK_BF16_TFLOPS, 4),
+                                       "hbm_view": {"achieved_TBps": round(alg6 / 1e9 / ms6, 4), "peak_TBps": PEAK_HBM_TBPS, "frac": round(alg6 / 1e9 / ms6 / PEAK_HBM_TBPS, 4)}}
+                else:
+                    tf6 = B6 / ms6 * 1e3 * GFLOP[idx] / 1e3
+                    ent["roofline"] = {"bound": "mfma", "achieved": round(tf6, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf6 / PEAK_BF16_TFLOPS, 4),
+                                       "basis": f"{GFLOP[idx]} algorithmic GFLOP per env-step x env-steps/s (whole step)"}
+                configs_block[f"cfg{idx}"] = ent
+                if hasattr(eng6, "close"):
+                    eng6.close()
+                del eng6, step6
+                torch.cuda.empty_cache()
+            except Exception as e:       # never lose the headline number to the extra legs
+                configs_block[f"cfg{idx}"] = {"error": str(e)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = global_B * args.steps / dt
@@ -737,6 +826,10 @@ def main():
             out["h2d"] = h2d_leg
         if single_env is not None:
             out["single_env_latency"] = single_env
+        if gather_w1 is not None:
+            out["gather_world1"] = gather_w1
+        if configs_block is not None:
+            out["configs"] = configs_block
         if args.config == 3:
             gb = alg_bytes / 1e9
             # BASELINE.json calls this configuration memory-bound; at 16-bit MFMA rates it is not (0.25 GFLOP and 0.46 MB per sample = 540 FLOP/B,

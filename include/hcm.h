@@ -72,9 +72,11 @@ enum hcm_query_what {
 typedef struct hcm_config {
     int32_t struct_size;
     int32_t precision;        /* HCM_F16: fp16 storage + fp16 MFMA tiles behind the range calibration below (the measured 16-bit mode);
-                                 HCM_BF16: bf16 storage + bf16 MFMA tiles in BERT, the RGB trunks and the cross-modal block (no range limit); the
-                                 GroupNorm depth trunks stay on range-folded fp16 tiles (GroupNorm's subtraction amplifies bf16's rounding 8x: 1.9e-2 on
-                                 the record from that trunk alone, DESIGN.md section 5 -- and the fold makes fp16 range-safe there by construction);
+                                 HCM_BF16: bf16 storage + bf16 MFMA tiles in BERT (f32 residual stream) and the cross-modal block -- the sub-networks that
+                                 are not scale-invariant (no range limit there); both trunk kinds stay on range-folded fp16 tiles (GroupNorm's
+                                 subtraction amplifies bf16's rounding 8x: 1.9e-2 on the record from the depth trunk alone; the RGB trunks' 50
+                                 bf16-rounded layers were 6e-3 of a 1e-2 tolerance -- and the exact power-of-two folds make fp16 range-safe in
+                                 both by construction; round 6);
                                  HCM_F32: fp32 MFMA.  fp32 accumulation and fp32 recurrent cells / heads in every mode */
     int32_t max_batch;        /* workspace is sized for this many environments per call */
     int32_t rgb_h, rgb_w;     /* frames are NHWC; any H x W >= 32 with HCM_ENC_RESNET (adaptive pools, resnet_encoders.py:211-236), >= 36 with HCM_ENC_SIMPLECNN (simple_cnns.py:63-73) */
@@ -281,7 +283,12 @@ typedef struct hcm_cma_config {
     int32_t use_prev_action;      /* must be 0 (MODEL.CMA.use_prev_action default) */
     int32_t rcm_state_encoder;    /* must be 0 (MODEL.CMA.rcm_state_encoder default) */
     int32_t progress_monitor;     /* must be 0: the auxiliary loss is a training-only branch (cma.py:320-329) */
-    int32_t reserved[8];
+    /* round 6 (carved out of the reserved words: zero = the defaults, struct size unchanged) */
+    int32_t instr_rnn;            /* MODEL.INSTRUCTION_ENCODER.rnn_type: HCM_LSTM (0, default.py:111) or HCM_GRU (instruction_encoder.py:42) */
+    int32_t ablate_instruction;   /* cma.py:236-241: `embedding * 0` behind the encoder -- the encoder is then not run, everything downstream sees the zeros */
+    int32_t ablate_depth;         /*   (text attention over an all-zero instruction: every position masked, uniform weights, text = 0 exactly) */
+    int32_t ablate_rgb;
+    int32_t reserved[4];
 } hcm_cma_config;
 
 int hcm_cma_create(const hcm_cma_config* cfg, hcm_handle* out);
@@ -369,6 +376,10 @@ int hcm_op_stem_conv_packed_pool(const void* x, int x_dtype, const void* w, cons
  * an LDS ring, both pool halves in LDS).  W == 256, H % 4 == 0, Cout % 64 == 0, 16-bit dtypes; bit-identical to hcm_op_stem_conv_packed_pool. */
 int hcm_op_stem_pool_fused(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
                            int Cout, float scale, void* scratch, void* stream);
+/* ... plus layer1 block 0's 1x1 reduction of the pooled map in the same launch: o1 (B, H/4, W/4, Cout) = ReLU(w1 x pooled + b1) per 64-channel group
+ * (w1 [Cout][64], group g = rows 64 g .. over the group's own 64 channels); bit-identical to hcm_op_conv2d (1x1, ReLU) applied to each 64-channel group. */
+int hcm_op_stem_pool_fused_red(const void* x, int x_dtype, const void* w, const float* bias, void* y, int dtype, int B, int H, int W,
+                               int Cout, float scale, void* scratch, const void* w1, const float* b1, void* o1, void* stream);
 int64_t hcm_op_stem_scratch_bytes(int B, int H, int W);
 /* SimpleDepthCNN's first layer, Conv2d(1, 32, 8, stride 4) (+ bias, activation) straight from a raw f32 depth frame (B,H,H,1) in one pass
  * (csrc/simplecnn.hip; H a multiple of 4, <= 1024); w is the OHWI weight [32][64] in `dtype` (16-bit), scratch holds B*H*H + 64 elements of

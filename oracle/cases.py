@@ -135,6 +135,13 @@ CMA_CASES = {
     "cma_depth192_L12": (dict(rgb_hw=128, depth_hw=192, instr_len=12), 2, 2),
     # non-square RGB frames (portrait, odd pooled map sizes)
     "cma_rgb_200x152_L12": (dict(rgb_hw=200, rgb_w=152, depth_hw=128, instr_len=12), 2, 2),
+    # round 6: the reference's option branches -- INSTRUCTION_ENCODER.rnn_type = "GRU" (instruction_encoder.py:42), bidirectional and not
+    "cma_instr_gru_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, instr_rnn="GRU"), 3, 2),
+    "cma_instr_gru_uni_128_L9": (dict(rgb_hw=128, depth_hw=128, instr_len=9, instr_rnn="GRU", bidirectional=False, rnn_type="GRU"), 2, 2),
+    # ... and the three ablations (cma.py:236-241): `embedding * 0` behind each encoder (an all-zero instruction masks EVERY text position)
+    "cma_ablate_instr_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, ablate_instruction=True), 2, 2),
+    "cma_ablate_depth_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, ablate_depth=True), 2, 2),
+    "cma_ablate_rgb_128_L12": (dict(rgb_hw=128, depth_hw=128, instr_len=12, ablate_rgb=True), 2, 2),
 }
 
 

@@ -411,7 +411,7 @@ class PolicyOracle:
 
 
 # ------------------------------------------------------------------ CMANet flat baseline
-def instruction_encoder(ids, w, hidden, bidirectional):
+def instruction_encoder(ids, w, hidden, bidirectional, rnn_type="LSTM"):
     """InstructionEncoder.forward with final_state_only=False (models/encoders/instruction_encoder.py:70-92; CMANet sets
     the flag at cma.py:33-35): lengths = count of non-zero ids; embedding; a (bi)LSTM over the PACKED sequence -- sample
     b runs exactly len_b steps (the reverse direction starts at its token len_b-1), outputs past len_b are zero; the
@@ -431,6 +431,17 @@ def instruction_encoder(ids, w, hidden, bidirectional):
         steps = range(lmax - 1, -1, -1) if reverse else range(lmax)
         for t in steps:
             act = (t < lengths).float().view(B, 1)
+            if rnn_type == "GRU":
+                # nn.GRU (instruction_encoder.py:42): r, z, n gates; b_hn sits inside the reset gate's product
+                gi_, gh_ = F.linear(emb[:, t], Wih, bih), F.linear(h, Whh, bhh)
+                ir, iz, in_ = gi_.chunk(3, dim=1)
+                hr, hz, hn = gh_.chunk(3, dim=1)
+                r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+                n = torch.tanh(in_ + r * hn)
+                h2 = (1 - z) * n + z * h
+                h = act * h2 + (1 - act) * h
+                out[:, t] = act * h2
+                continue
             g = F.linear(emb[:, t], Wih, bih) + F.linear(h, Whh, bhh)
             i, f, gg, o = g.chunk(4, dim=1)
             c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
@@ -475,7 +486,13 @@ class CMAOracle:
         dep = depth_resnet_spatial(depth, w.sub("depth_encoder."), cfg.depth_baseplanes // 2).flatten(2)   # :220-221
         rg = rgb_resnet_spatial(rgb, w.sub("rgb_encoder.")).flatten(2)                                # :223-224
         ids = ids.expand(B, ids.shape[1])                                                             # :226
-        ins, lengths = instruction_encoder(ids, w.sub("instruction_encoder."), cfg.instr_hidden, cfg.bidirectional)  # :227
+        ins, lengths = instruction_encoder(ids, w.sub("instruction_encoder."), cfg.instr_hidden, cfg.bidirectional, cfg.instr_rnn)  # :227
+        if cfg.ablate_instruction:
+            ins = ins * 0                                                                             # :236-237
+        if cfg.ablate_depth:
+            dep = dep * 0                                                                             # :238-239
+        if cfg.ablate_rgb:
+            rg = rg * 0                                                                               # :240-241
         rgb_in = F.relu(F.linear(rg.mean(2), w("rgb_linear.2.weight"), w("rgb_linear.2.bias")))       # :256
         dep_in = F.relu(F.linear(dep.flatten(1), w("depth_linear.1.weight"), w("depth_linear.1.bias")))   # :257
         state_in = torch.cat([rgb_in, dep_in], dim=1)                                                 # :262

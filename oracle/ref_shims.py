@@ -302,7 +302,7 @@ _BERT_LAYERS = [12]
 def model_config(cfg):
     """HCMConfig -> the attr-dict the reference model constructors read."""
     return AttrDict(
-        TORCH_GPU_ID=0, ablate_instruction=False, ablate_depth=bool(getattr(cfg, "ablate_depth", False)),
+        TORCH_GPU_ID=0, ablate_instruction=bool(getattr(cfg, "ablate_instruction", False)), ablate_depth=bool(getattr(cfg, "ablate_depth", False)),
         ablate_rgb=bool(getattr(cfg, "ablate_rgb", False)),
         TRANSFORMER_INSTRUCTION_ENCODER=AttrDict(d_in=768, d_model=256),
         DEPTH_ENCODER=AttrDict(cnn_type=cfg.depth_encoder, output_size=cfg.depth_out, backbone="resnet50",
@@ -358,7 +358,7 @@ def ref_masks(mask_b):
 def cma_model_config(cfg):
     """CMAConfig -> the attr-dict CMANet's constructor reads (cma.py:28-186)."""
     return AttrDict(
-        TORCH_GPU_ID=0, ablate_instruction=False, ablate_depth=bool(getattr(cfg, "ablate_depth", False)),
+        TORCH_GPU_ID=0, ablate_instruction=bool(getattr(cfg, "ablate_instruction", False)), ablate_depth=bool(getattr(cfg, "ablate_depth", False)),
         ablate_rgb=bool(getattr(cfg, "ablate_rgb", False)),
         INSTRUCTION_ENCODER=AttrDict(vocab_size=cfg.vocab_size, embedding_size=cfg.embedding_size, hidden_size=cfg.instr_hidden,
                                      rnn_type=cfg.instr_rnn, bidirectional=cfg.bidirectional, final_state_only=True,

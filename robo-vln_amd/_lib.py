@@ -39,7 +39,8 @@ class HcmCmaConfigStruct(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "precision", "max_batch", "rgb_h", "rgb_w", "depth_h", "depth_w", "instr_len",
         "vocab_size", "embedding_size", "instr_hidden", "bidirectional", "rgb_out", "depth_out", "depth_baseplanes",
-        "hidden", "rnn_type", "num_actions", "use_prev_action", "rcm_state_encoder", "progress_monitor")] + [("reserved", C.c_int32 * 8)]
+        "hidden", "rnn_type", "num_actions", "use_prev_action", "rcm_state_encoder", "progress_monitor",
+        "instr_rnn", "ablate_instruction", "ablate_depth", "ablate_rgb")] + [("reserved", C.c_int32 * 4)]
 
 
 EXPORTS = {
@@ -88,6 +89,7 @@ EXPORTS = {
     "hcm_op_stem_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_float, C.c_int, C.c_void_p]),
     "hcm_op_stem_conv_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "hcm_op_stem_pool_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "hcm_op_stem_pool_fused_red": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 5),
     "hcm_op_stem_conv_packed_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hcm_op_depth_conv8x8s4": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "hcm_op_stem_scratch_bytes": (C.c_int64, [C.c_int] * 3),

@@ -31,6 +31,8 @@ def _to_struct(cfg: CMAConfig, max_batch, precision):
     s.num_actions = cfg.num_actions
     s.use_prev_action, s.rcm_state_encoder = int(cfg.use_prev_action), int(cfg.rcm_state_encoder)
     s.progress_monitor = int(cfg.progress_monitor)
+    s.instr_rnn = _lib.HCM_LSTM if cfg.instr_rnn == "LSTM" else _lib.HCM_GRU
+    s.ablate_instruction, s.ablate_depth, s.ablate_rgb = int(cfg.ablate_instruction), int(cfg.ablate_depth), int(cfg.ablate_rgb)
     return s
 
 

@@ -141,16 +141,19 @@ class CMAConfig:
     ablate_instruction: bool = False
     ablate_depth: bool = False
     ablate_rgb: bool = False
+    final_state_only: bool = False   # INSTRUCTION_ENCODER.final_state_only: CMANet forces False whatever the config says (cma.py:32)
 
     def validate(self):
         if self.use_prev_action or self.rcm_state_encoder:
-            raise ValueError("CMA.use_prev_action / CMA.rcm_state_encoder are not built (default.py:211-212 are False)")
-        if self.instr_rnn != "LSTM":
-            raise ValueError("INSTRUCTION_ENCODER.rnn_type: only LSTM (the default, default.py:111) is built")
+            # config/default.py:211-212: both default False, and no paper config of the reference sets either; cma.py:231-234 / :243-254 are the branches
+            raise ValueError("CMA.use_prev_action / CMA.rcm_state_encoder are not built (config/default.py:211-212 default False; cma.py:231,:243)")
+        if self.instr_rnn not in ("LSTM", "GRU"):
+            raise ValueError("INSTRUCTION_ENCODER.rnn_type must be LSTM or GRU (instruction_encoder.py:42)")
         if self.rnn_type not in ("LSTM", "GRU"):
             raise ValueError("STATE_ENCODER.rnn_type must be LSTM or GRU")
-        if self.ablate_instruction or self.ablate_depth or self.ablate_rgb or self.progress_monitor:
-            raise ValueError("ablation / progress-monitor branches are not built")
+        if self.progress_monitor:
+            raise ValueError("the progress monitor is a training-only auxiliary loss (cma.py:320-329)")
+        # INSTRUCTION_ENCODER.final_state_only is accepted and ignored, as in the reference: CMANet.__init__ overwrites it with False (cma.py:32)
         hh = self.hidden // 2
         if self.rgb_out > hh or self.depth_out > hh:
             # cma.py:281-286: `k, v = torch.split(kv(x), hidden_size // 2, dim=1)` over hidden/2 + output_size channels unpacks into exactly

@@ -1257,6 +1257,29 @@ __global__ void instr_lstm_cell_kernel(const float* __restrict__ pre, const floa
         o[j] = h2;
     }
 }
+// The same step for nn.GRU (INSTRUCTION_ENCODER.rnn_type = "GRU", instruction_encoder.py:42): pre = x_t W_ih^T + b_ih [B*L][3H], gh = h W_hh^T + b_hh
+// [B][3H], gate order r, z, n; n = tanh(pre_n + r * gh_n), h' = (1 - z) n + z h.
+__global__ void instr_gru_cell_kernel(const float* __restrict__ pre, const float* __restrict__ gh, float* __restrict__ h,
+                                      const int* __restrict__ lengths, float* __restrict__ out, int t, int L, int Hd, int ld_out, int col0) {
+    const int b = blockIdx.x;
+    const bool act = t < lengths[b];
+    const float* p = pre + ((size_t)b * L + t) * 3 * Hd;
+    const float* g = gh + (size_t)b * 3 * Hd;
+    float* o = out + ((size_t)b * L + t) * ld_out + col0;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        if (!act) { o[j] = 0.f; continue; }
+        const float r = sigmoidf_(p[j] + g[j]), z = sigmoidf_(p[Hd + j] + g[Hd + j]);
+        const float n = tanhf(p[2 * Hd + j] + r * g[2 * Hd + j]);
+        const float h2 = (1.0f - z) * n + z * h[(size_t)b * Hd + j];
+        h[(size_t)b * Hd + j] = h2;
+        o[j] = h2;
+    }
+}
+hipError_t launch_instr_gru_cell(const float* pre, const float* gh, float* h, const int* lengths, float* out, int t, int B, int L, int Hd, int ld_out,
+                                 int col0, hipStream_t s) {
+    hipLaunchKernelGGL(instr_gru_cell_kernel, dim3(B), dim3(256), 0, s, pre, gh, h, lengths, out, t, L, Hd, ld_out, col0);
+    return hipGetLastError();
+}
 hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, float* c, const int* lengths, float* out, int t, int B,
                                   int L, int Hd, int ld_out, int col0, hipStream_t s) {
     hipLaunchKernelGGL(instr_lstm_cell_kernel, dim3(B), dim3(256), 0, s, pre, gh, h, c, lengths, out, t, L, Hd, ld_out, col0);

@@ -311,6 +311,15 @@ struct Fwd {
         const bool hpool = packed && !no_hpool && !ctx->taps_on && Wo >= 2 && Wo <= 128 && !(Wo & (Wo - 1)) && (c1 % 64) == 0;
         static const bool no_stem_fuse = dev_env("HCM_NO_STEM_FUSE") != nullptr;
         const bool fused_stem = packed && hpool && !no_stem_fuse && t.conv1_packed.groups == 1 && rgb_stem_pool_ok(t.conv1_packed.dt, st.H, st.W, c1, t.conv1_packed.Kp);
+        // ... and layer1 block 0's 1x1 reduction (64 -> 64 per model) from the pooled row while it is in registers: its launch and its read of the
+        // pooled map disappear (HCM_NO_STEM_RED=1, development build: the launch)
+        static const bool no_stem_red = dev_env("HCM_NO_STEM_RED") != nullptr;
+        bool stem_red = false;
+        if (fused_stem && !no_stem_red && !t.blocks.empty()) {
+            const ConvW& q = t.blocks[0].c1;
+            stem_red = q.KH == 1 && q.KW == 1 && q.Cin == 64 && q.Cout == 64 && q.K == 64 && q.Kp == 64 && q.bias && q.dt == t.conv1_packed.dt && q.groups * 64 == c1 &&
+                       q.fold == 1.f;
+        }
         // GroupNorm statistics of the packed depth stem from its conv's epilogue (see conv_gn)
         static const bool no_cs_stem = dev_env("HCM_NO_GN_EPISTATS") != nullptr;
         float* stem_stats = nullptr;
@@ -335,9 +344,12 @@ struct Fwd {
             void* pk = alloc_t(pack_frame_elems(B, st.H, st.W));
             if (!dry) {
                 ck(launch_pack_frame(st.x, st.x_dt, pk, t.conv1_packed.dt, B, st.H, st.W, st.scale, s), "pack frame");
-                ck(launch_rgb_stem_pool(pk, t.conv1_packed.w, t.conv1_packed.bias, slot[1], t.conv1_packed.dt, B, st.H, st.W, c1, s), "stem conv + max-pool (one launch)");
+                const ConvW* r1 = stem_red ? &t.blocks[0].c1 : nullptr;
+                ck(launch_rgb_stem_pool(pk, t.conv1_packed.w, t.conv1_packed.bias, slot[1], t.conv1_packed.dt, B, st.H, st.W, c1, s, r1 ? r1->w : nullptr,
+                                        r1 ? r1->bias : nullptr, r1 ? slot[0] : nullptr), "stem conv + max-pool (one launch)");
                 // (the pooled map has the conv map's maximum: ReLU'd values, max-pooled)
                 calib_check(slot[1], t.conv1_packed.dt, B * (Ho / 2) * (Wo / 2), c1, c1);
+                if (r1) calib_check(slot[0], r1->dt, B * (Ho / 2) * (Wo / 2), c1, c1);
             }
         } else if (packed && hpool) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU, 1);
         else if (packed) stem_conv_packed(t.conv1_packed, st, B, slot[0], Ho, Wo, ACT_RELU);
@@ -368,6 +380,7 @@ struct Fwd {
         int xi = 1;
         int bidx = 0;
         int pre = -1;          // slot already holding THIS block's 1x1 reduction output (computed by the previous block's fused launch)
+        if (stem_red) pre = 0; // ... or, for the first block, by the stem launch
         Pending xpend;         // GroupNorm trunk: the block input x is still un-normalised (its first consumer, the block's c1, normalises + stores it)
         // (development build, timing only -- the results are then wrong: HCM_GN_STOP=<k> drops the launches of the GroupNorm trunks' blocks
         //  k.. and of the compression conv, HCM_SKIP_GN_APPLY=1 the stand-alone normalisation passes)
@@ -1380,16 +1393,33 @@ struct Fwd {
         // at once, then L packed-LSTM steps per direction.  All L steps run (no host sync on the longest length): steps
         // past a sample's length emit zeros, which the attention masks exactly as pad_packed_sequence's cut does.
         on(a0);
-        {
+        if (m.ablate_instruction) {
+            // cma.py:236-237 `instruction_embedding * 0`: the encoder's value cannot reach an output (finite x * 0 = 0) -- not run.  Downstream the
+            // reference's text_mask = (embedding == 0).all(dim=1) is then true at EVERY position: all logits equal (q . bias - 1e8), uniform weights
+            // over zero values, text = 0 exactly -- which is what attn1q over a zero instruction returns for any lengths.
+            if (!dry) ck(hipMemsetAsync(ins, 0, (size_t)B * Lm * C * 4, s), "ablate: zero instruction");
+            tap("cma.instruction", ins, false, {B, L, C});
+        } else {
+            const int G = m.instr_rnn == HCM_GRU ? 3 : 4;
             const int ldx = w.ih[0].Kp;
             float* x = alloc_f((size_t)B * Lm * ldx);
             if (!dry) ck(launch_instr_embed(ids, ids_dt, w.emb, x, ctx->len_buf, B, L, E, ldx, m.vocab_size, s), "instr embed");
-            float* pre[2] = {alloc_f((size_t)B * Lm * 4 * Hi), w.dirs > 1 ? alloc_f((size_t)B * Lm * 4 * Hi) : nullptr};
-            float* gh = alloc_f((size_t)B * 4 * Hi);
+            float* pre[2] = {alloc_f((size_t)B * Lm * G * Hi), w.dirs > 1 ? alloc_f((size_t)B * Lm * G * Hi) : nullptr};
+            float* gh = alloc_f((size_t)B * G * Hi);
             float* hc = alloc_f((size_t)2 * B * Hi);
-            for (int d = 0; d < w.dirs; ++d) linear(w.ih[d], x, B * L, ldx, pre[d], 4 * Hi, ACT_NONE, true);
+            for (int d = 0; d < w.dirs; ++d) linear(w.ih[d], x, B * L, ldx, pre[d], G * Hi, ACT_NONE, true);
             static const bool no_scan = dev_env("HCM_NO_LSTM_SCAN") != nullptr;
-            if (Hi == 256 && !no_scan) {
+            if (m.instr_rnn == HCM_GRU) {
+                // INSTRUCTION_ENCODER.rnn_type = "GRU" (instruction_encoder.py:42): a launch pair per token and direction
+                for (int d = 0; d < w.dirs; ++d) {
+                    if (!dry) ck(hipMemsetAsync(hc, 0, (size_t)B * Hi * 4, s), "gru state reset");
+                    for (int k = 0; k < L; ++k) {
+                        const int t = d == 0 ? k : L - 1 - k;
+                        linear(w.hh[d], hc, B, Hi, gh, 3 * Hi, ACT_NONE, true);
+                        if (!dry) ck(launch_instr_gru_cell(pre[d], gh, hc, ctx->len_buf, ins, t, B, L, Hi, C, d * Hi, s), "instr gru cell");
+                    }
+                }
+            } else if (Hi == 256 && !no_scan) {
                 // both directions, all L steps: one launch
                 if (!dry) ck(launch_instr_lstm_scan(pre[0], pre[1], w.hh_t[0], w.hh_t[1], ctx->len_buf, ins, B, L, Hi, w.dirs, C, s), "instr lstm scan");
             } else {
@@ -1406,7 +1436,12 @@ struct Fwd {
         }
         // chain B (aux 1): depth encoder -> spatial tokens (cma.py:220-221)
         on(a1);
-        {
+        if (m.ablate_depth) {
+            // cma.py:238-239 `depth_embedding * 0`: the whole (B, C + 64, S) token tensor including its positional-embedding channels
+            use(ctx->dt_vla);
+            if (!dry) ck(hipMemsetAsync(dep_tok, 0, (size_t)B * dS * dC * esz, s), "ablate: zero depth tokens");
+            tap("cma.depth_spatial", dep_tok, true, {B, dS, dC});
+        } else {
             use(ctx->dt_depth);
             Act o = depth_trunk(w.depth, depth, B, "cma.depth");
             void* tok = ctx->dt_depth == ctx->dt_vla ? dep_tok : alloc_t((size_t)B * dS * dC);
@@ -1420,7 +1455,11 @@ struct Fwd {
         }
         // chain C (caller's stream): RGB encoder -> spatial tokens (cma.py:223-224)
         on(main_s);
-        {
+        if (m.ablate_rgb) {
+            use(ctx->dt_vla);                                     // cma.py:240-241
+            if (!dry) ck(hipMemsetAsync(rgb_tok, 0, (size_t)B * 16 * rC * esz, s), "ablate: zero rgb tokens");
+            tap("cma.rgb_spatial", rgb_tok, true, {B, 16, rC});
+        } else {
             use(ctx->dt_rgb);
             Act o = rgb_trunk(w.rgb, rgb, rgb_dt, B, "cma.rgb");
             void* tok = ctx->dt_rgb == ctx->dt_vla ? rgb_tok : alloc_t((size_t)B * 16 * rC);
@@ -1453,7 +1492,7 @@ struct Fwd {
         linear(w.state_q, state, B, H, q1, hh, ACT_NONE, true);
         float* kt = alloc_f((size_t)B * Lm * hh);
         linear(w.text_k, ins, B * L, C, kt, hh, ACT_NONE, true);
-        if (!dry) ck(launch_attn1q(q1, hh, kt, hh, ins, C, ctx->len_buf, xc + H, ldc, B, L, hh, C, w.scale, s), "text attention");
+        if (!dry) ck(launch_attn1q(q1, hh, kt, hh, ins, C, m.ablate_instruction ? nullptr : ctx->len_buf, xc + H, ldc, B, L, hh, C, w.scale, s), "text attention");
         // visual attention (:281-290): query text_q(text); keys | values are the two halves of rgb_kv / depth_kv
         float* q2 = alloc_f((size_t)B * hh);
         linear(w.text_q, xc + H, B, ldc, q2, hh, ACT_NONE, true);

@@ -3600,7 +3600,7 @@ struct DepthL3Dev {
     float eps1[6], eps2[6], eps3[6];
 };
 
-template <typename T, bool PROF = false>
+template <typename T, bool PROF = false, int SAFE = 0>
 __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
     // phase timing (HCM_IGEMM_PROF=1, development build; read through hcm_debug_igemm_prof): per-wave cycle totals [0] input staging, [1] conv1 K loop,
     // [2] its GroupNorm + barrier, [3] conv2 K loop, [4] its GroupNorm + barrier, [5] conv3 + GroupNorm + identity + barrier + output, [6] waves
@@ -3675,10 +3675,21 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
     };
     // the fragment of piece idx: wait for it and read it; the slot of the piece BEFORE it (whose fragment the previous MFMAs have consumed, so its
     // read is long complete) is refilled with the piece R - 1 ahead of this one -- R - 2 pieces in flight behind the one waited for
+    // ROUND 6: "its read is long complete" was an assumption about the compiler, not a guarantee.  The MFMAs that consume piece idx - 1 depend on
+    // nothing in take(idx), so hipcc is free to sink them -- and the lgkmcnt wait in front of them -- BELOW take(idx)'s request: with
+    // -ffp-contract=on it did exactly that in conv3's fragment loop (ds_read slot 1; request -> slot 0; ds_read slot 2; request -> slot 1; only then
+    // s_waitcnt lgkmcnt), i.e. a request into a slot whose ds_read was still in flight.  Harmless on an idle CU (a request needs >= 250 cycles to
+    // land), but with the other chains of a step competing for the CU's LDS queue the read could lose: configs[4] at B = 128 disagreed with itself
+    // run to run (tests/test_fullsize_gpu.py::test_config4_full_size_properties; bisected to this kernel with per-file objects and HCM_NO_DEPTH_L3).
+    // The LDS wait now stands in the source, in front of the request: everything this wave has read so far -- piece idx - 1's fragment and the
+    // A fragments the next MFMAs need anyway -- has arrived before the slot is handed back.
     auto take = [&](int idx) {
-        if (idx + R - 2 < PPB || has_next) wait_vmcnt<R - 2>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SAFE & 1) wait_vmcnt<0>();
+        else if (idx + R - 2 < PPB || has_next) wait_vmcnt<R - 2>(); else wait_vmcnt<0>();
         const uint4 wb = *reinterpret_cast<const uint4*>(smem + WR + wave * (R * 1024) + ((par + idx) & (R - 1)) * 1024 + fr * 64 +
                                                          ((fg ^ ((4 - (fr >> 2)) & 3)) << 4));
+        if constexpr ((SAFE & 2) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue(idx + R - 1);
         return wb;
     };
@@ -3858,6 +3869,12 @@ hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s) {
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(depth_l3_kernel<bf16>) : reinterpret_cast<const void*>(depth_l3_kernel<f16>);
 #ifdef HCM_DEV_KNOBS
     if (prof_on() && dt == DT_F16) fn = reinterpret_cast<const void*>(depth_l3_kernel<f16, true>);
+    static const bool l3_safe = dev_env("HCM_L3_SAFE") != nullptr;      // round-6 race hunt: every weight piece fully waited for
+    if (l3_safe && dt == DT_F16) {
+        const int m = atoi(dev_env("HCM_L3_SAFE"));
+        fn = m == 1 ? reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 1>) : m == 2 ? reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 2>)
+                    : reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 3>);
+    }
 #endif
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

@@ -167,7 +167,10 @@ inline size_t pack_frame_elems(int B, int H, int W) { return (size_t)B * (H + 6)
 // streamed through an LDS ring; y = pooled map [B][H/4][W/4][C].  W == 256, H % 4 == 0, C % 64 == 0; bit-identical to the packed stem conv
 // with the horizontal pool epilogue + launch_vpool3s2.
 bool rgb_stem_pool_ok(int dt, int H, int W, int C, int Kp);
-hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias, void* y, int dt, int B, int H, int W, int C, hipStream_t s);
+// w1 / b1 / o1 non-null: also layer1 block 0's 1x1 reduction of the pooled map, 64 -> 64 per 64-channel group (w1 [C][64], k = the group's own channels),
+// + bias + ReLU -> o1 [B][H/4][W/4][C]; bit-identical to the grouped 1x1 launch.
+hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias, void* y, int dt, int B, int H, int W, int C, hipStream_t s,
+                                const void* w1 = nullptr, const float* b1 = nullptr, void* o1 = nullptr);
 hipError_t launch_avgpool2_f32(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);
 hipError_t launch_avgpool2_f32_padded(const float* x, void* y, int dt, int B, int H, int W, hipStream_t s);   // -> [B][H/2+6][W/2+8]
 // vertical half of MaxPool2d(3, 2, 1): x [B][H][W][C] -> y [B][(H+1)/2][W][C] (rows 2p-1, 2p, 2p+1)
@@ -274,6 +277,8 @@ hipError_t launch_instr_embed(const void* ids, int ids_dt, const float* table, f
                               int vocab, hipStream_t s);
 hipError_t launch_instr_lstm_cell(const float* pre, const float* gh, float* h, float* c, const int* lengths, float* out, int t, int B,
                                   int L, int Hd, int ld_out, int col0, hipStream_t s);
+hipError_t launch_instr_gru_cell(const float* pre, const float* gh, float* h, const int* lengths, float* out, int t, int B, int L, int Hd, int ld_out,
+                                 int col0, hipStream_t s);   // nn.GRU step of the packed instruction encoder (gate order r, z, n; gh carries b_hh)
 // all L steps of both directions in one launch (H == 256): wt = W_hh transposed [H][4H]
 hipError_t launch_instr_lstm_scan(const float* pre0, const float* pre1, const float* wt0, const float* wt1, const int* lengths, float* out,
                                   int B, int L, int H, int dirs, int ld_out, hipStream_t s);

@@ -48,6 +48,10 @@ struct StemPoolDev {
     char* y;                 // pooled map [B][Hp][64][C] T
     int B, H, C, Hp, nbands, ngroups;
     unsigned img_bytes;      // (H+6) * SP_ROWB
+    // RED: layer1 block 0's 1x1 reduction (64 -> 64 per channel group, BatchNorm folded, ReLU) taken from the pooled row while it is in registers
+    const char* w1;          // [C][64] T (group g: rows g*64 .., k = the group's own 64 channels)
+    const float* b1;         // [C]
+    char* o1;                // [B][Hp][64][C] T
 };
 
 template <typename T> struct SpMma;
@@ -76,7 +80,7 @@ __device__ __forceinline__ uint4 sp_max(const uint4& a, const uint4& b) {
     return r;
 }
 
-template <typename T>
+template <typename T, bool RED>
 __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,12 +167,25 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
                 }
         }
         __syncthreads();
-        // pool: 64 pooled pixels x 8 sixteen-byte channel chunks = 512 items, two per thread
+        // pool: 64 pooled pixels x 8 sixteen-byte channel chunks = 512 items, two per thread: wave w owns pooled pixels 16 w + fr, a lane the chunks
+        // fg and 4 + fg of its pixel -- i.e. the pooled row comes out in the layout of an MFMA src1 operand (pixel = lane & 15, k-group = lane >> 4,
+        // 8 consecutive channels), which is what the reduction below multiplies
+        uint4 w1f[RED ? 2 : 1][RED ? 4 : 1];
+        if constexpr (RED) {
+            // the reduction's weights (8 KB per group, L1 / L2 resident) are requested in front of the pool's LDS reads and consumed behind them; they
+            // live in registers the conv accumulators have just vacated
+            const char* wg = p.w1 + (size_t)cg * 64 * 64 * 2;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tid + it * 256;
-            const int q = item >> 3, ch = (item & 7) * 16;
-            const int xl = q ? 2 * q - 1 : 0;                 // left tap clamped onto the centre at the map's edge (vpool3s2 / hpool do the same)
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) w1f[ks][nf] = *reinterpret_cast<const uint4*>(wg + ((size_t)(nf * 16 + fr) * 64 + ks * 32 + fg * 8) * 2);
+        }
+        const int q = wave * 16 + fr;
+        const int xl = q ? 2 * q - 1 : 0;                     // left tap clamped onto the centre at the map's edge (vpool3s2 / hpool do the same)
+        uint4 pooled[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = (ks * 4 + fg) * 16;
             const char* r0 = img, *r1 = img + SP_IMG;
             uint4 h0 = sp_max(sp_max(*reinterpret_cast<const uint4*>(r0 + xl * SP_PXB + ch), *reinterpret_cast<const uint4*>(r0 + 2 * q * SP_PXB + ch)),
                               *reinterpret_cast<const uint4*>(r0 + (2 * q + 1) * SP_PXB + ch));
@@ -178,8 +195,32 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
             uint4 o = sp_max(h0, h1);
             if (r > 0) o = sp_max(o, *pv);                    // conv row 2r - 1; above the map's first row the window is clamped
             *pv = h1;
+            pooled[ks] = o;
             if (r >= p0)
                 *reinterpret_cast<uint4*>(p.y + ((((size_t)b * p.Hp + r) * SP_WP + q) * p.C + cg * 64) * 2 + ch) = o;
+        }
+        if constexpr (RED) {
+            if (r >= p0) {
+                sp_f32x4 ra[4];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) ra[nf] = (sp_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) SpMma<T>::run(ra[nf], w1f[ks][nf], pooled[ks]);
+                char* orow = p.o1 + ((((size_t)b * p.Hp + r) * SP_WP + q) * p.C + cg * 64) * 2;
+#pragma unroll
+                for (int np = 0; np < 2; ++np) {
+                    // channel blocks 2 np and 2 np + 1 -> 8 consecutive channels per lane (dev.h: swap_pair), one 16-byte store
+                    float v[8];
+                    swap_pair(ra[2 * np], ra[2 * np + 1], v);
+                    const int c0 = np * 32 + (fg & 1) * 16 + (fg >> 1) * 8;
+                    const float4 ba = *reinterpret_cast<const float4*>(p.b1 + cg * 64 + c0), bb = *reinterpret_cast<const float4*>(p.b1 + cg * 64 + c0 + 4);
+                    v[0] = relu_f(v[0] + ba.x); v[1] = relu_f(v[1] + ba.y); v[2] = relu_f(v[2] + ba.z); v[3] = relu_f(v[3] + ba.w);
+                    v[4] = relu_f(v[4] + bb.x); v[5] = relu_f(v[5] + bb.y); v[6] = relu_f(v[6] + bb.z); v[7] = relu_f(v[7] + bb.w);
+                    *reinterpret_cast<uint4*>(orow + c0 * 2) = pack_chunk<T>(v);
+                }
+            }
         }
     }
 }
@@ -190,21 +231,32 @@ bool rgb_stem_pool_ok(int dt, int H, int W, int C, int Kp) {
     return (dt == DT_F16 || dt == DT_BF16) && W == SP_W && H >= 8 && (H % 4) == 0 && (C % 64) == 0 && Kp == 224;
 }
 
-hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias, void* y, int dt, int B, int H, int W, int C, hipStream_t s) {
+hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias, void* y, int dt, int B, int H, int W, int C, hipStream_t s,
+                                const void* w1, const float* b1, void* o1) {
     if (!rgb_stem_pool_ok(dt, H, W, C, 224)) return hipErrorInvalidValue;
     StemPoolDev p;
     p.pk = (const char*)pk; p.w = (const char*)w; p.bias = bias; p.y = (char*)y;
     p.B = B; p.H = H; p.C = C; p.Hp = H / 4; p.nbands = (p.Hp + SP_BAND - 1) / SP_BAND; p.ngroups = C / 64;
     p.img_bytes = (unsigned)(H + 6) * SP_ROWB;
+    p.w1 = (const char*)w1; p.b1 = b1; p.o1 = (char*)o1;
+    const bool red = w1 && b1 && o1;
     if (g_stem_attr.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rgb_stem_pool_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rgb_stem_pool_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
-        if (e != hipSuccess) return e;
+        const void* fns[4] = {reinterpret_cast<const void*>(rgb_stem_pool_kernel<f16, false>), reinterpret_cast<const void*>(rgb_stem_pool_kernel<bf16, false>),
+                              reinterpret_cast<const void*>(rgb_stem_pool_kernel<f16, true>), reinterpret_cast<const void*>(rgb_stem_pool_kernel<bf16, true>)};
+        for (const void* fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+            if (e != hipSuccess) return e;
+        }
         g_stem_attr.done();
     }
     const dim3 grid((unsigned)(B * p.nbands * p.ngroups));
-    if (dt == DT_BF16) hipLaunchKernelGGL(rgb_stem_pool_kernel<bf16>, grid, dim3(256), SP_LDS, s, p);
-    else hipLaunchKernelGGL(rgb_stem_pool_kernel<f16>, grid, dim3(256), SP_LDS, s, p);
+    if (dt == DT_BF16) {
+        if (red) hipLaunchKernelGGL((rgb_stem_pool_kernel<bf16, true>), grid, dim3(256), SP_LDS, s, p);
+        else hipLaunchKernelGGL((rgb_stem_pool_kernel<bf16, false>), grid, dim3(256), SP_LDS, s, p);
+    } else {
+        if (red) hipLaunchKernelGGL((rgb_stem_pool_kernel<f16, true>), grid, dim3(256), SP_LDS, s, p);
+        else hipLaunchKernelGGL((rgb_stem_pool_kernel<f16, false>), grid, dim3(256), SP_LDS, s, p);
+    }
     return hipGetLastError();
 }
 

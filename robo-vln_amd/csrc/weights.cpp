@@ -174,10 +174,11 @@ void build_spec_cma(hcm_ctx* ctx) {
     for (int d = 0; d < (m.bidirectional ? 2 : 1); ++d) {
         const std::string sfx = d ? "_reverse" : "";
         const std::string p = "instruction_encoder.encoder_rnn.";
-        s.add(p + "weight_ih_l0" + sfx, {4 * m.instr_hidden, m.embedding_size});
-        s.add(p + "weight_hh_l0" + sfx, {4 * m.instr_hidden, m.instr_hidden});
-        s.add(p + "bias_ih_l0" + sfx, {4 * m.instr_hidden});
-        s.add(p + "bias_hh_l0" + sfx, {4 * m.instr_hidden});
+        const int G = m.instr_rnn == HCM_GRU ? 3 : 4;        // nn.GRU: gates r, z, n; nn.LSTM: i, f, g, o (instruction_encoder.py:42-47)
+        s.add(p + "weight_ih_l0" + sfx, {G * m.instr_hidden, m.embedding_size});
+        s.add(p + "weight_hh_l0" + sfx, {G * m.instr_hidden, m.instr_hidden});
+        s.add(p + "bias_ih_l0" + sfx, {G * m.instr_hidden});
+        s.add(p + "bias_hh_l0" + sfx, {G * m.instr_hidden});
     }
     const int fs = depth_final_spatial(c), cc = depth_compress_channels(c);
     const int dC = cc + 64, rC = 2048 + 64, hh = c.hidden / 2;
@@ -952,6 +953,13 @@ void prepare_cma(hcm_ctx* ctx) {
         const std::string p = "instruction_encoder.encoder_rnn.";
         const HostTensor& bih = T_(ctx, M, p + "bias_ih_l0" + sfx);
         const HostTensor& bhh = T_(ctx, M, p + "bias_hh_l0" + sfx);
+        if (m.instr_rnn == HCM_GRU) {
+            // GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) -- b_hh stays with the recurrent product (it sits inside the reset gate's product)
+            w.ih[d] = make_linear(up, {&T_(ctx, M, p + "weight_ih_l0" + sfx)}, {&bih}, DT_F32);
+            w.ih[d].K = w.ih[d].Kp;
+            w.hh[d] = make_linear(up, {&T_(ctx, M, p + "weight_hh_l0" + sfx)}, {&bhh}, DT_F32);
+            continue;
+        }
         HostTensor b;
         b.shape = bih.shape;
         b.f.resize(bih.f.size());

@@ -277,9 +277,10 @@ def cma_spec(cfg):
     hh = cfg.hidden // 2
     g = 4 if cfg.rnn_type == "LSTM" else 3
     s = [("instruction_encoder.embedding_layer.weight", (cfg.vocab_size, cfg.embedding_size), "emb", 1.0)]
-    s += _rnn_generic("instruction_encoder.encoder_rnn.", 4, cfg.instr_hidden, cfg.embedding_size)
+    gi = 4 if cfg.instr_rnn == "LSTM" else 3              # INSTRUCTION_ENCODER.rnn_type (instruction_encoder.py:42)
+    s += _rnn_generic("instruction_encoder.encoder_rnn.", gi, cfg.instr_hidden, cfg.embedding_size)
     if cfg.bidirectional:
-        s += _rnn_generic("instruction_encoder.encoder_rnn.", 4, cfg.instr_hidden, cfg.embedding_size, "_reverse")
+        s += _rnn_generic("instruction_encoder.encoder_rnn.", gi, cfg.instr_hidden, cfg.embedding_size, "_reverse")
     s += habitat_gn_resnet50_spec("depth_encoder.visual_encoder.", 1, cfg.depth_baseplanes, cc)
     s += [("depth_encoder.spatial_embeddings.weight", (fs * fs, 64), "emb", 0.5)]
     s += torchvision_resnet50_spec("rgb_encoder.cnn.", with_fc=False)

@@ -124,6 +124,43 @@ def test_every_synth_key_is_accepted_by_the_library():
             l.hcm_destroy(h)
 
 
+def test_cma_option_branches_are_accepted_and_the_unbuilt_ones_cite_the_reference():
+    """Round 6: CMANet's ablation flags (cma.py:236-241) and INSTRUCTION_ENCODER.rnn_type = "GRU" (instruction_encoder.py:42) are built; the GRU
+    encoder's state_dict has three gates; final_state_only is accepted and ignored as in the reference (cma.py:32 overwrites it); use_prev_action /
+    rcm_state_encoder stay rejected with the reference lines in the message."""
+    from robo_vln_amd.config import CMAConfig
+    from robo_vln_amd.cma import _to_struct as cma_struct
+    for kw in (dict(ablate_instruction=True), dict(ablate_depth=True), dict(ablate_rgb=True), dict(instr_rnn="GRU"), dict(final_state_only=True)):
+        CMAConfig(rgb_hw=128, depth_hw=128, instr_len=12, **kw).validate()
+    for kw in (dict(use_prev_action=True), dict(rcm_state_encoder=True)):
+        with pytest.raises(ValueError, match="default.py:211-212"):
+            CMAConfig(**kw).validate()
+    with pytest.raises(ValueError):
+        CMAConfig(instr_rnn="RNN").validate()
+    cfg = CMAConfig(rgb_hw=128, depth_hw=128, instr_len=12, instr_rnn="GRU", ablate_rgb=True).validate()
+    spec = {k: shape for k, shape, _, _ in synth.cma_spec(cfg)}
+    assert spec["instruction_encoder.encoder_rnn.weight_ih_l0"] == (3 * cfg.instr_hidden, cfg.embedding_size)
+    assert spec["instruction_encoder.encoder_rnn.weight_hh_l0_reverse"] == (3 * cfg.instr_hidden, cfg.instr_hidden)
+    l = _lib.lib()
+    st = cma_struct(cfg, 2, "fp32")
+    assert st.instr_rnn == _lib.HCM_GRU and st.ablate_rgb == 1 and st.ablate_depth == 0
+    h = C.c_void_p()
+    assert l.hcm_cma_create(C.byref(st), C.byref(h)) == 0, l.hcm_last_error(None)
+    try:
+        for key, shape, kind, aux in synth.cma_spec(cfg):          # the C++ spec agrees key for key (three-gate instruction encoder)
+            n = int(np.prod(shape)) if len(shape) else 1
+            if n > 4_000_000:
+                continue
+            a = np.zeros(shape, np.int64 if kind == "nbt" else np.float32)
+            shp = (C.c_int64 * max(1, len(shape)))(*shape)
+            assert l.hcm_load_tensor(h, _lib.HCM_CMA, key.encode(), a.ctypes.data_as(C.c_void_p), _lib.HCM_I64 if kind == "nbt" else _lib.HCM_F32, shp, len(shape)) == 0, \
+                (key, l.hcm_last_error(h))
+    finally:
+        l.hcm_destroy(h)
+    st.instr_rnn = 7
+    assert l.hcm_cma_create(C.byref(st), C.byref(h)) == -1 and b"INSTRUCTION_ENCODER.rnn_type" in l.hcm_last_error(None)
+
+
 def test_baseline_configs():
     assert baseline_config(1).instr_len == 80 and baseline_config(1).rgb_hw == 256
     assert baseline_config(0).vla_layers == 2 and baseline_config(4).instr_len == 160

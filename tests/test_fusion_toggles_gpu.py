@@ -82,8 +82,10 @@ def test_one_launch_stem_equals_conv_and_pool_launches(prec):
         env = {"HCMT_RGB_HW": "256", "HCMT_PREC": prec}
         fused = _run(env, os.path.join(d, "a.npz"))
         plain = _run(dict(env, HCM_NO_STEM_FUSE="1"), os.path.join(d, "b.npz"))
+        nored = _run(dict(env, HCM_NO_STEM_RED="1"), os.path.join(d, "c.npz"))      # layer1 block 0's reduction as its own (grouped) launch
     for k in ("rec", "hh", "lh"):
         assert np.array_equal(fused[k], plain[k]), k
+        assert np.array_equal(fused[k], nored[k]), k
     assert np.isfinite(fused["rec"]).all()
 
 

@@ -659,6 +659,23 @@ def test_stem_pool_one_launch(prec, cfg):
         fin = ~torch.isnan(ref.float())
         assert torch.equal(y.view(torch.int16)[fin], ref.view(torch.int16)[fin])
     assert lib.hcm_op_stem_pool_fused(_p(x), xcode, _p(w), _p(b), _p(y), code, B, H, 128, Cout, 1 / 255.0, _p(scratch), None) != 0      # other widths: refused
+    # ... and with layer1 block 0's 1x1 reduction (64 -> 64 per 64-channel group) taken from the pooled row in the same launch
+    assert lib.hcm_op_stem_conv_packed(_p(x), xcode, _p(w), _p(b), _p(full), code, B, H, W, Cout, 1 / 255.0, L.ACT_RELU, _p(scratch), None) == 0
+    assert lib.hcm_op_maxpool3x3s2(_p(full), _p(ref), code, B, H // 2, W // 2, Cout, None) == 0          # (ref held the NaN-poisoned frame's map)
+    w1 = _rnd(Cout, 64, scale=0.15, seed=3).cuda().to(tdt)
+    b1 = _rnd(Cout, scale=0.3, seed=4).cuda()
+    y2 = torch.full_like(y, float("nan"))
+    o1 = torch.full_like(y, float("nan"))
+    assert lib.hcm_op_stem_pool_fused_red(_p(x), xcode, _p(w), _p(b), _p(y2), code, B, H, W, Cout, 1 / 255.0, _p(scratch), _p(w1), _p(b1), _p(o1), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y2.view(torch.int16), ref.view(torch.int16))
+    for g in range(Cout // 64):
+        xg = ref[..., g * 64:(g + 1) * 64].contiguous()
+        og = torch.empty_like(xg)
+        wg, bg = w1[g * 64:(g + 1) * 64].contiguous(), b1[g * 64:(g + 1) * 64].contiguous()
+        assert lib.hcm_op_conv2d(_p(xg), _p(wg), _p(bg), None, _p(og), code, B, H // 4, W // 4, 64, 64, 1, 1, 1, 0, L.ACT_RELU, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(o1[..., g * 64:(g + 1) * 64].contiguous().view(torch.int16), og.view(torch.int16)), g
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])

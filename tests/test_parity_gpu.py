@@ -188,15 +188,16 @@ def test_baseline_config2_batch64_16bit():
 
 @pytest.mark.parametrize("name,batch", [("cfg1_256_L80_N1", 64), ("gru_128_L20", 64), ("cfg0_128_L20_N2", 16)])
 def test_bf16_mode_batch64_three_steps(name, batch):
-    """precision="bf16": bf16 storage and bf16 MFMA tiles in BERT, the RGB trunks and the cross-modal block (the GroupNorm depth trunks on
-    range-folded fp16 tiles) -- the north_star's bf16 tolerance, 1e-2 on the record, at the full batch over three consecutive steps."""
+    """precision="bf16": bf16 storage and bf16 MFMA tiles in BERT (f32 residual stream) and the cross-modal block; both trunk kinds on range-folded
+    fp16 tiles (round 6: the RGB trunks too -- with them on bf16 the mode sat AT the tolerance, 9.1e-3 ... 1.08e-2 by the luck of the rounding
+    draw) -- the north_star's bf16 tolerance, 1e-2 on the record, at the full batch over three consecutive steps, now with margin: 8.5e-3."""
     from tests import parity_util
     import torch
     torch.set_num_threads(min(16, torch.get_num_threads()))
     rep = parity_util.run_case(name, "bf16", taps=True, batch=batch, steps=3)
     print(parity_util.format_report(rep))
     for s in rep["steps"]:
-        assert s["max_abs"] <= 1e-2, s
+        assert s["max_abs"] <= 8.5e-3, s
     # the intermediates on their own (step 0, whole tensors): an error must not hide behind the recurrent cell's squashing in this mode either
     for k, (mx, mean, ref, rel) in rep["taps"].items():
         assert rel <= TAP_REL["bf16"] or ref == 0.0 and mx == 0.0, f"{name}[bf16] tap {k}: rel-l2 {rel:.3e} > {TAP_REL['bf16']}"
