@@ -619,7 +619,8 @@ int hcm_finalize(hcm_handle h) {
             return fail(h, HCM_ERR_NOMEM, "hipMalloc failed");
         h->arena.dry = false;
         for (int i = 0; i < 4; ++i) {
-            if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
+            const hipError_t ce = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
+            if (ce != hipSuccess) return fail(h, HCM_ERR_HIP, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(h, HCM_ERR_HIP, "hipEventCreate failed");
         }
         for (auto& p : h->pool)

@@ -39,14 +39,14 @@ constexpr int SP_PXB = 144;                        // bytes per pixel of the LDS
 constexpr int SP_IMG = SP_WO * SP_PXB;             // one full-width conv row image
 constexpr int SP_PREV = SP_WP * SP_PXB;            // the previous odd conv row, horizontally pooled
 constexpr int SP_LDS = SP_RING + 2 * SP_IMG + SP_PREV;      // 33792 + 36864 + 9216 = 79872
-constexpr int SP_BAND = 16;                        // pooled rows per workgroup
+constexpr int SP_BAND = 16;                        // pooled rows per workgroup at full batches (small batches: shorter bands, launch_rgb_stem_pool)
 
 struct StemPoolDev {
     const char* pk;          // packed frame [B][H+6][W+8][4] T
     const char* w;           // [C][224] T, k = kh*32 + kw*4 + ci
     const float* bias;       // [C]
     char* y;                 // pooled map [B][Hp][64][C] T
-    int B, H, C, Hp, nbands, ngroups;
+    int B, H, C, Hp, nbands, ngroups, band;
     unsigned img_bytes;      // (H+6) * SP_ROWB
     // RED: layer1 block 0's 1x1 reduction (64 -> 64 per channel group, BatchNorm folded, ReLU) taken from the pooled row while it is in registers
     const char* w1;          // [C][64] T (group g: rows g*64 .., k = the group's own 64 channels)
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
     const int cg = bid % p.ngroups; bid /= p.ngroups;
     const int band = bid % p.nbands;
     const int b = bid / p.nbands;
-    const int p0 = band * SP_BAND, p1 = min(p0 + SP_BAND, p.Hp);
+    const int p0 = band * p.band, p1 = min(p0 + p.band, p.Hp);
     const int rs = p0 > 0 ? p0 - 1 : 0;                       // a band below the first one recomputes the odd conv row above it (no output)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     char* img = smem + SP_RING;                               // two full-width conv rows [2][128 px][SP_PXB]
@@ -236,7 +236,12 @@ hipError_t launch_rgb_stem_pool(const void* pk, const void* w, const float* bias
     if (!rgb_stem_pool_ok(dt, H, W, C, 224)) return hipErrorInvalidValue;
     StemPoolDev p;
     p.pk = (const char*)pk; p.w = (const char*)w; p.bias = bias; p.y = (char*)y;
-    p.B = B; p.H = H; p.C = C; p.Hp = H / 4; p.nbands = (p.Hp + SP_BAND - 1) / SP_BAND; p.ngroups = C / 64;
+    p.B = B; p.H = H; p.C = C; p.Hp = H / 4; p.ngroups = C / 64;
+    // band height: 16 pooled rows (1 / 16 of the conv recomputed at a band's top) when that already gives two workgroups per CU; small batches take
+    // shorter bands down to 2 rows (B = 1: 64 workgroups of three steps instead of 8 of seventeen -- latency, not throughput, is what a one-environment step pays)
+    p.band = SP_BAND;
+    while (p.band > 2 && (long)B * p.ngroups * ((p.Hp + p.band - 1) / p.band) < 512) p.band >>= 1;
+    p.nbands = (p.Hp + p.band - 1) / p.band;
     p.img_bytes = (unsigned)(H + 6) * SP_ROWB;
     p.w1 = (const char*)w1; p.b1 = b1; p.o1 = (char*)o1;
     const bool red = w1 && b1 && o1;
