@@ -487,6 +487,7 @@ class CMAOracle:
         rg = rgb_resnet_spatial(rgb, w.sub("rgb_encoder.")).flatten(2)                                # :223-224
         ids = ids.expand(B, ids.shape[1])                                                             # :226
         ins, lengths = instruction_encoder(ids, w.sub("instruction_encoder."), cfg.instr_hidden, cfg.bidirectional, cfg.instr_rnn)  # :227
+        ins_enc = ins                                      # what a forward hook on the encoder module sees (the golden's `instruction` tap)
         if cfg.ablate_instruction:
             ins = ins * 0                                                                             # :236-237
         if cfg.ablate_depth:
@@ -514,6 +515,6 @@ class CMAOracle:
         out = F.linear(x2, w("linear.weight"), w("linear.bias"))                                      # :331
         stop = F.linear(x2, w("stop_linear.weight"), w("stop_linear.bias"))                           # :332
         if taps is not None:
-            taps.update(depth_spatial=dep, rgb_spatial=rg, instruction=ins, state=state, text=text, rgb_att=rgb_att,
+            taps.update(depth_spatial=dep, rgb_spatial=rg, instruction=ins_enc, state=state, text=text, rgb_att=rgb_att,
                         depth_att=dep_att, compress=x, rnn2_out=x2)
         return out, stop, torch.cat([hid1, hid2], dim=0)

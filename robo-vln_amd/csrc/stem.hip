@@ -150,9 +150,7 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf) SpMma<T>::run(acc[nf][mf], wf[ky][nf], xf[mf]);
         }
-        // (the group requested above has had a whole MFMA phase to land; the barrier makes every wave's pieces everybody's, and it also says
-        //  that every wave is done with the previous step's pool phase: the row images may be overwritten)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (every wave is done with the previous step's pool phase: the row images may be overwritten)
         __syncthreads();
         {
             char* irow = img + crow * SP_IMG;
@@ -166,6 +164,12 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
                     *reinterpret_cast<uint2*>(irow + (px0 + mf * 16 + fr) * SP_PXB + nf * 32 + fg * 8) = *reinterpret_cast<const uint2*>(o4);
                 }
         }
+        // The group requested at the top of the step has had the MFMA phase and the epilogue to land; the barrier makes every wave's pieces
+        // everybody's.  vmcnt counts stores as well, and this is the ONE place in a step where waiting for "everything" costs nothing: the only
+        // other operations in flight are the previous step's pooled / reduced stores, a whole step old.  (First version: the wait stood in front of
+        // the step's first barrier, one MFMA phase behind those stores -- every step stalled on their acknowledgement: 97 us per launch with the
+        // reduction's second store stream against 60 without.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // pool: 64 pooled pixels x 8 sixteen-byte channel chunks = 512 items, two per thread: wave w owns pooled pixels 16 w + fr, a lane the chunks
         // fg and 4 + fg of its pixel -- i.e. the pooled row comes out in the layout of an MFMA src1 operand (pixel = lane & 15, k-group = lane >> 4,

@@ -20,6 +20,11 @@ old = lambda: lib.hcm_op_stem_conv_packed_pool(x.data_ptr(), _lib.HCM_U8, w.data
                                                scratch.data_ptr(), half.data_ptr(), None)
 new = lambda: lib.hcm_op_stem_pool_fused(x.data_ptr(), _lib.HCM_U8, w.data_ptr(), b.data_ptr(), y1.data_ptr(), _lib.HCM_F16, B, H, H, Cout, 1 / 255.0,
                                          scratch.data_ptr(), None)
+w1 = (torch.randn(Cout, 64, device="cuda") * 0.1).half()
+b1 = torch.randn(Cout, device="cuda")
+o1 = torch.empty_like(y0)
+red = lambda: lib.hcm_op_stem_pool_fused_red(x.data_ptr(), _lib.HCM_U8, w.data_ptr(), b.data_ptr(), y1.data_ptr(), _lib.HCM_F16, B, H, H, Cout, 1 / 255.0,
+                                             scratch.data_ptr(), w1.data_ptr(), b1.data_ptr(), o1.data_ptr(), None)
 def t(run, n=50):
     for _ in range(10): assert run() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,5 +33,5 @@ def t(run, n=50):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 for _ in range(2):
-    print(f"B={B}: pack + conv/hpool + vpool {t(old):.1f} us   |   pack + one-launch stem {t(new):.1f} us")
+    print(f"B={B}: pack + conv/hpool + vpool {t(old):.1f} us   |   pack + one-launch stem {t(new):.1f} us   |   ... + layer1 block 0's reduction {t(red):.1f} us")
 print("bit-equal:", torch.equal(y0.view(torch.int16), y1.view(torch.int16)))
