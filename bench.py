@@ -427,6 +427,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--configs-leg", type=float, default=1.5, help="N = 1 default run: seconds per configuration of the bounded `configs` block (BASELINE configs[0], [3], [4] "
                     "at their own batch sizes: value, ms_per_step, roofline.frac); 0 = skip")
+    ap.add_argument("--host-procs-leg", type=int, default=8, help="N = 1 default run: processes of the `host_8proc` leg (tools/host_procs.py: N processes pinned to 2 cores each, "
+                    "every one driving its own engine through the real graph-replay call on the shared GPU: host time inside act()); 0 = skip")
     ap.add_argument("--gather-leg", type=float, default=1.0, help="N = 1 default run: seconds per side of `gather_world1` -- the same step with the library's collective "
                     "(hcm_act_gather through real librccl on a one-rank communicator) against the plain step; 0 = skip")
     args = ap.parse_args()
@@ -744,6 +746,17 @@ def main():
         except Exception as e:           # never lose the headline number to the extra leg
             gather_w1 = {"error": str(e)}
 
+    # The host side of an 8-rank node, as far as one GPU can show it: 8 processes on 2 cores each enqueueing real graph replays (tools/host_procs.py)
+    host_procs = None
+    if default_run and args.host_procs_leg > 0:
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_procs.py"), str(args.host_procs_leg), "8", "2.0"], capture_output=True, timeout=240, cwd=ROOT)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            host_procs = json.loads(lines[-1]) if lines else {"error": "no output: " + r.stderr.decode()[-300:]}
+        except Exception as e:           # never lose the headline number to the extra leg
+            host_procs = {"error": str(e)}
+
     # The other BASELINE configurations in the driver-visible line (bounded: --configs-leg seconds each): configs[0] (the reference's own CPU-runnable
     # case), configs[3] (depth-only SimpleCNN + 1-layer block, B = 256), configs[4] (ResNet-50 + 6-layer decoder, L = 160, B = 128, high-level model).
     configs_block = None
@@ -828,6 +841,8 @@ def main():
             out["single_env_latency"] = single_env
         if gather_w1 is not None:
             out["gather_world1"] = gather_w1
+        if host_procs is not None:
+            out["host_8proc"] = host_procs
         if configs_block is not None:
             out["configs"] = configs_block
         if args.config == 3:

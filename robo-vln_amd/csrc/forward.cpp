@@ -714,6 +714,10 @@ struct Fwd {
         // (a 15.7 MB f32 write per LayerNorm gone at B = 64).  HCM_BERT_STREAM_MAT=1 (development build): the materialised stream of round 4.
         static const bool stream_mat = dev_env("HCM_BERT_STREAM_MAT") != nullptr;
         float* lnst = (f32_stream && !stream_mat && dev_env("HCM_BERT_FUSE") == nullptr) ? alloc_f(rmax * 2) : nullptr;        // (mean, rstd) per row of the latest LayerNorm (the fused-block experiment keeps the materialised stream)
+        // (lnst is ONE (mean, rstd) buffer: the LayerNorm launch that writes it and the projection epilogue that reads it are enqueued on the same stream `s`,
+        //  in that order, every time -- BERT is one chain; nothing here may move onto a second stream without giving each LayerNorm its own statistics.
+        //  With HCM_BERT_FUSE set but the fused block not applicable (`blk` false below) the code takes round 4's materialised stream: correct, and covered by the
+        //  toggle test's HCM_BERT_STREAM_MAT side.)
         float* cur_sum = nullptr;           // buffer holding the latest pre-LayerNorm sum (nullptr: xf holds the stream itself, as after the embedding)
         const NormW* cur_ln = nullptr;      // ... and the LayerNorm that turns it into the stream
         auto linear_res_f32 = [&](const LinW& lw, const void* a, int lda) {     // sum = a @ W^T + b + stream

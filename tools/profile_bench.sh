@@ -13,7 +13,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_${TAG}_cfg${CFG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --steps 4 --warmup 1 --prewarm 0 --sustain 0 --no-cpu-baseline --no-kernel-probe --bf16-leg 0 --latency-leg 0 --h2d-leg 0 --configs-leg 0 --gather-leg 0"
+ARGS="--config $CFG --steps 4 --warmup 1 --prewarm 0 --sustain 0 --no-cpu-baseline --no-kernel-probe --bf16-leg 0 --latency-leg 0 --h2d-leg 0 --configs-leg 0 --gather-leg 0 --host-procs-leg 0"
 STEPS=11       # 1 + 5 untimed + 1 warm-up + 4 timed
 SFX=""; [ "$CFG" != "1" ] && SFX="_cfg${CFG}"
 run() { name=$1; shift; timeout 600 rocprofv3 "$@" -d $OUT/$name -o p --output-format csv -- python $REPO/bench.py $ARGS > $OUT/$name.log 2>&1; }
