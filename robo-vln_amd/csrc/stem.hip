@@ -13,10 +13,10 @@
 //     a step ahead; a kernel row of an output pixel is 64 contiguous bytes of a ring row, so the B operand of `v_mfma_f32_16x16x32` is ONE
 //     ds_read_b128 per lane at byte 16 (pixel + k-group) -- conflict-free, 28 reads per wave for its 112 MFMAs;
 //   * bias + ReLU + one rounding in registers, the two conv rows go to an LDS image, and the pool is taken there: horizontal 3-max of both
-//     rows, vertical max with the previous step's (horizontally pooled) odd row, which stays in LDS.  Values behind the ReLU are >= +0 or NaN,
+//     rows, vertical max with the previous step's (horizontally pooled) odd row, which the same lane keeps in registers.  Values behind the ReLU are >= +0 or NaN,
 //     so the maximum of the 16-bit patterns as UNSIGNED integers is the IEEE maximum (NaN patterns compare above every number: a NaN still
 //     wins, as torch's max-pool and the library's other pools have it) -- v_pk_max_u16, no conversions.
-// Two workgroups per CU (77 KB of LDS, <= 256 VGPRs): while one is in its epilogue / pool phase the other one's MFMAs have the matrix pipe.
+// Two workgroups per CU (77 KB of LDS incl. the reduction's 8 KB of weights, <= 256 VGPRs): while one is in its epilogue / pool phase the other one's MFMAs have the matrix pipe.
 // Same MFMA instruction, operand roles (weights = src0, pixels = src1), k order (kernel rows 0..6) and epilogue operations as the
 // implicit-GEMM form, max is exact: the pooled map is BIT-IDENTICAL to the two launches it replaces (tests/test_ops_gpu.py).
 #include "kernels.h"
@@ -37,8 +37,8 @@ constexpr int SP_GROUPB = 4 * SP_ROWB;             // one ring group = 4 packed 
 constexpr int SP_RING = 4 * SP_GROUPB;             // 16 rows: the 9 rows of a step (3 groups) + the group requested for the next step
 constexpr int SP_PXB = 144;                        // bytes per pixel of the LDS row images (64 channels x 2 + 16: 16-byte aligned chunks)
 constexpr int SP_IMG = SP_WO * SP_PXB;             // one full-width conv row image
-constexpr int SP_PREV = SP_WP * SP_PXB;            // the previous odd conv row, horizontally pooled
-constexpr int SP_LDS = SP_RING + 2 * SP_IMG + SP_PREV;      // 33792 + 36864 + 9216 = 79872
+constexpr int SP_W1 = 64 * 64 * 2, SP_B1 = 64 * 4;         // RED: the reduction's weights in fragment order, and its bias
+constexpr int SP_LDS = SP_RING + 2 * SP_IMG + SP_W1 + SP_B1;   // 33792 + 36864 + 8192 + 256 = 79104 (two workgroups per CU)
 constexpr int SP_BAND = 16;                        // pooled rows per workgroup at full batches (small batches: shorter bands, launch_rgb_stem_pool)
 
 struct StemPoolDev {
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
     const int rs = p0 > 0 ? p0 - 1 : 0;                       // a band below the first one recomputes the odd conv row above it (no output)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     char* img = smem + SP_RING;                               // two full-width conv rows [2][128 px][SP_PXB]
-    char* prev = img + 2 * SP_IMG;                            // the previous odd row, horizontally pooled [64 px][SP_PXB]
+    char* w1s = img + 2 * SP_IMG;                             // RED: W1 of the channel group, [k step][channel fragment][lane] x 16 bytes (a fragment = 1 KB)
+    float* b1s = reinterpret_cast<float*>(w1s + SP_W1);
     sp_v4i rsrc;
     {
         const unsigned long long a = (unsigned long long)(p.pk + (size_t)b * p.img_bytes);
@@ -126,9 +127,19 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + cg * 64 + nf * 16 + fg * 4);
         bias4[nf][0] = bv.x; bias4[nf][1] = bv.y; bias4[nf][2] = bv.z; bias4[nf][3] = bv.w;
     }
+    if constexpr (RED) {
+        const char* wg1 = p.w1 + (size_t)cg * 64 * 64 * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, ks = idx >> 8, nf = (idx >> 6) & 3, l = idx & 63;
+            *reinterpret_cast<uint4*>(w1s + idx * 16) = *reinterpret_cast<const uint4*>(wg1 + ((size_t)(nf * 16 + (l & 15)) * 64 + ks * 32 + (l >> 4) * 8) * 2);
+        }
+        if (tid < 64) b1s[tid] = p.b1[cg * 64 + tid];
+    }
     request_group(rs); request_group(rs + 1); request_group(rs + 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    uint4 prevr[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};      // the previous odd conv row, horizontally pooled: this lane's two chunks
     const int crow = wave >> 1;                               // which of the step's two conv rows this wave computes
     const int px0 = (wave & 1) * 64;                          // ... and which half of it
     for (int r = rs; r < p1; ++r) {
@@ -139,16 +150,24 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = (sp_f32x4){0.f, 0.f, 0.f, 0.f};
         const int y = 2 * r + crow;
+        // (the next kernel row's four fragments are read while this one's sixteen MFMAs issue: two register sets, by hand)
+        uint4 xf[2][4];
+        {
+            const char* rowp = smem + ((2 * y) & 15) * SP_ROWB + (px0 + fr + fg) * 16;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) xf[0][mf] = *reinterpret_cast<const uint4*>(rowp + mf * 256);
+        }
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
-            const char* rowp = smem + ((2 * y + ky) & 15) * SP_ROWB + (px0 + fr + fg) * 16;
-            uint4 xf[4];
+            if (ky + 1 < 7) {
+                const char* rowp = smem + ((2 * y + ky + 1) & 15) * SP_ROWB + (px0 + fr + fg) * 16;
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) xf[mf] = *reinterpret_cast<const uint4*>(rowp + mf * 256);
+                for (int mf = 0; mf < 4; ++mf) xf[(ky + 1) & 1][mf] = *reinterpret_cast<const uint4*>(rowp + mf * 256);
+            }
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf) SpMma<T>::run(acc[nf][mf], wf[ky][nf], xf[mf]);
+                for (int mf = 0; mf < 4; ++mf) SpMma<T>::run(acc[nf][mf], wf[ky][nf], xf[ky & 1][mf]);
         }
         // (every wave is done with the previous step's pool phase: the row images may be overwritten)
         __syncthreads();
@@ -174,16 +193,6 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
         // pool: 64 pooled pixels x 8 sixteen-byte channel chunks = 512 items, two per thread: wave w owns pooled pixels 16 w + fr, a lane the chunks
         // fg and 4 + fg of its pixel -- i.e. the pooled row comes out in the layout of an MFMA src1 operand (pixel = lane & 15, k-group = lane >> 4,
         // 8 consecutive channels), which is what the reduction below multiplies
-        uint4 w1f[RED ? 2 : 1][RED ? 4 : 1];
-        if constexpr (RED) {
-            // the reduction's weights (8 KB per group, L1 / L2 resident) are requested in front of the pool's LDS reads and consumed behind them; they
-            // live in registers the conv accumulators have just vacated
-            const char* wg = p.w1 + (size_t)cg * 64 * 64 * 2;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf) w1f[ks][nf] = *reinterpret_cast<const uint4*>(wg + ((size_t)(nf * 16 + fr) * 64 + ks * 32 + fg * 8) * 2);
-        }
         const int q = wave * 16 + fr;
         const int xl = q ? 2 * q - 1 : 0;                     // left tap clamped onto the centre at the map's edge (vpool3s2 / hpool do the same)
         uint4 pooled[2];
@@ -195,10 +204,9 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
                               *reinterpret_cast<const uint4*>(r0 + (2 * q + 1) * SP_PXB + ch));
             uint4 h1 = sp_max(sp_max(*reinterpret_cast<const uint4*>(r1 + xl * SP_PXB + ch), *reinterpret_cast<const uint4*>(r1 + 2 * q * SP_PXB + ch)),
                               *reinterpret_cast<const uint4*>(r1 + (2 * q + 1) * SP_PXB + ch));
-            uint4* pv = reinterpret_cast<uint4*>(prev + q * SP_PXB + ch);
             uint4 o = sp_max(h0, h1);
-            if (r > 0) o = sp_max(o, *pv);                    // conv row 2r - 1; above the map's first row the window is clamped
-            *pv = h1;
+            if (r > 0) o = sp_max(o, prevr[ks]);              // conv row 2r - 1; above the map's first row the window is clamped
+            prevr[ks] = h1;
             pooled[ks] = o;
             if (r >= p0)
                 *reinterpret_cast<uint4*>(p.y + ((((size_t)b * p.Hp + r) * SP_WP + q) * p.C + cg * 64) * 2 + ch) = o;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int nf = 0; nf < 4; ++nf) SpMma<T>::run(ra[nf], w1f[ks][nf], pooled[ks]);
+                    for (int nf = 0; nf < 4; ++nf) SpMma<T>::run(ra[nf], *reinterpret_cast<const uint4*>(w1s + ((ks * 4 + nf) * 64 + lane) * 16), pooled[ks]);
                 char* orow = p.o1 + ((((size_t)b * p.Hp + r) * SP_WP + q) * p.C + cg * 64) * 2;
 #pragma unroll
                 for (int np = 0; np < 2; ++np) {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void rgb_stem_pool_kernel(StemPoolDev p) {
                     float v[8];
                     swap_pair(ra[2 * np], ra[2 * np + 1], v);
                     const int c0 = np * 32 + (fg & 1) * 16 + (fg >> 1) * 8;
-                    const float4 ba = *reinterpret_cast<const float4*>(p.b1 + cg * 64 + c0), bb = *reinterpret_cast<const float4*>(p.b1 + cg * 64 + c0 + 4);
+                    const float4 ba = *reinterpret_cast<const float4*>(b1s + c0), bb = *reinterpret_cast<const float4*>(b1s + c0 + 4);
                     v[0] = relu_f(v[0] + ba.x); v[1] = relu_f(v[1] + ba.y); v[2] = relu_f(v[2] + ba.z); v[3] = relu_f(v[3] + ba.w);
                     v[4] = relu_f(v[4] + bb.x); v[5] = relu_f(v[5] + bb.y); v[6] = relu_f(v[6] + bb.z); v[7] = relu_f(v[7] + bb.w);
                     *reinterpret_cast<uint4*>(orow + c0 * 2) = pack_chunk<T>(v);
