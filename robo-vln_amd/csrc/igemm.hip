@@ -3600,7 +3600,7 @@ struct DepthL3Dev {
     float eps1[6], eps2[6], eps3[6];
 };
 
-template <typename T, bool PROF = false, int SAFE = 0>
+template <typename T, bool PROF = false>
 __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
     // phase timing (HCM_IGEMM_PROF=1, development build; read through hcm_debug_igemm_prof): per-wave cycle totals [0] input staging, [1] conv1 K loop,
     // [2] its GroupNorm + barrier, [3] conv2 K loop, [4] its GroupNorm + barrier, [5] conv3 + GroupNorm + identity + barrier + output, [6] waves
@@ -3685,11 +3685,9 @@ __global__ __launch_bounds__(512) void depth_l3_kernel(DepthL3Dev p) {
     // A fragments the next MFMAs need anyway -- has arrived before the slot is handed back.
     auto take = [&](int idx) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (SAFE & 1) wait_vmcnt<0>();
-        else if (idx + R - 2 < PPB || has_next) wait_vmcnt<R - 2>(); else wait_vmcnt<0>();
+        if (idx + R - 2 < PPB || has_next) wait_vmcnt<R - 2>(); else wait_vmcnt<0>();
         const uint4 wb = *reinterpret_cast<const uint4*>(smem + WR + wave * (R * 1024) + ((par + idx) & (R - 1)) * 1024 + fr * 64 +
                                                          ((fg ^ ((4 - (fr >> 2)) & 3)) << 4));
-        if constexpr ((SAFE & 2) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue(idx + R - 1);
         return wb;
     };
@@ -3869,12 +3867,6 @@ hipError_t launch_depth_l3(const DepthL3& d, int dt, hipStream_t s) {
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(depth_l3_kernel<bf16>) : reinterpret_cast<const void*>(depth_l3_kernel<f16>);
 #ifdef HCM_DEV_KNOBS
     if (prof_on() && dt == DT_F16) fn = reinterpret_cast<const void*>(depth_l3_kernel<f16, true>);
-    static const bool l3_safe = dev_env("HCM_L3_SAFE") != nullptr;      // round-6 race hunt: every weight piece fully waited for
-    if (l3_safe && dt == DT_F16) {
-        const int m = atoi(dev_env("HCM_L3_SAFE"));
-        fn = m == 1 ? reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 1>) : m == 2 ? reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 2>)
-                    : reinterpret_cast<const void*>(depth_l3_kernel<f16, false, 3>);
-    }
 #endif
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
