@@ -133,3 +133,42 @@ def test_calibration_on_trained_like_weight_distributions(case):
         assert 0 < rep[k] < 16384 or ((k == "bert_max_abs" and "bert" in rep["fp16_fallback"]) or (k == "vla_max_abs" and "vla" in rep["fp16_fallback"])), (k, rep)
     assert bad == 0                                              # hcm_query(HCM_STEP_NONFINITE): nothing non-finite reached a recurrent cell in 16 steps
     assert max(errs) <= 1e-2, errs
+
+
+@pytest.mark.parametrize("where", ["depth.cnn.0", "depth.cnn.2", "rgb.cnn.0", "rgb.cnn.2"])
+def test_simplecnn_overflow_inside_the_one_launch_form_is_seen_by_calibration(where):
+    """Seq2Seq_LowLevel with SimpleDepthCNN / SimpleRGBCNN (simple_cnns.py:51-147; seq2seq_lowlevel.py:116-162): one convolution's weights and
+    bias times 2^18, the next convolution's weights times 2^-18 -- ReLU is positively homogeneous, so the network's function is unchanged, but
+    that convolution's output (an LDS-only intermediate of the one-launch form hcm_op_simplecnn3) is far outside fp16.  SimpleCNN has no
+    normalisation to fold a scale into: the calibration forward (launch-per-conv form, every map range-checked) must move THAT encoder to bf16
+    tiles, say so, and the result must match the fp32 oracle on the same weights at bf16's tolerance with nothing non-finite (round-5 advisor)."""
+    from robo_vln_amd.policy import HCMEngine
+    enc, _, idx = where.split(".")
+    cfg = HCMConfig(rgb_hw=128, depth_hw=128, depth_encoder="SimpleDepthCNN", rgb_encoder="SimpleRGBCNN").validate()
+    B = 3
+    lo_sd = dict(synth.materialize(synth.low_level_spec(cfg), "lo", 5))
+    S = np.float32(2.0 ** 18)
+    a, b = f"{enc}_encoder.cnn.{idx}", f"{enc}_encoder.cnn.{int(idx) + 2}"
+    lo_sd[a + ".weight"] = (np.asarray(lo_sd[a + ".weight"]) * S).astype(np.float32)
+    lo_sd[a + ".bias"] = (np.asarray(lo_sd[a + ".bias"]) * S).astype(np.float32)
+    lo_sd[b + ".weight"] = (np.asarray(lo_sd[b + ".weight"]) / S).astype(np.float32)
+    eng = HCMEngine(cfg, None, lo_sd, max_batch=B, precision="fp16", graph=False)
+    rep = eng.calibration_report()
+    obs_np = synth.make_observations(cfg, B, step=0, seed=5)
+    obs = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in obs_np.items()}
+    R = cfg.num_recurrent_layers
+    h = torch.rand(R, B, cfg.hidden, generator=torch.Generator().manual_seed(7)) - 0.5
+    mask, st = torch.ones(B), torch.tensor([0, 3, 1])
+    vel, stop, h2 = eng.low_forward(obs, h.cuda(), mask.cuda(), st.cuda())
+    torch.cuda.synchronize()
+    bad = eng.nonfinite_steps()
+    eng.close()
+    o_vel, o_stop, o_h = hcm_oracle.LowLevelOracle(cfg, lo_sd).forward({k: torch.from_numpy(np.asarray(v)) for k, v in obs_np.items()}, h, mask, st)
+    e1, e2 = (vel.cpu() - o_vel).abs().max().item(), (stop.cpu() - o_stop).abs().max().item()
+    print(f"simplecnn overflow at {where}: {rep}; errors {e1:.3e} / {e2:.3e}; guard {bad}")
+    assert enc in rep["fp16_fallback"], rep                       # the overflow sits in an LDS-only map of the one-launch form: it must still be seen
+    assert [e for e in ("depth", "rgb") if e != enc][0] not in rep["fp16_fallback"], rep          # ... and only that encoder pays for it
+    assert rep["non_finite"] == 0 and bad == 0, (rep, bad)
+    assert torch.isfinite(vel).all() and torch.isfinite(stop).all() and torch.isfinite(h2).all()
+    assert e1 <= 3e-2 and e2 <= 3e-2, (e1, e2)                    # one encoder on bf16 tiles (8 mantissa bits), everything else as in fp16 mode
+    assert ((h2.cpu() - o_h).norm() / o_h.norm()).item() <= 2e-2
