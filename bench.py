@@ -352,7 +352,7 @@ def build_probe_workload(args):
     vla_sd = synth.materialize(synth.vla_spec("", cfg, vis_in=128), "probe_vla", 0)
     prec = args.precision
     # hipGraph replay over the two input sets in place (a rollout stages observations into fixed device buffers): no input copies
-    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec, graph=not args.no_graph)
+    probe = DepthCnnVlaProbe(cnn_sd, vla_sd, depth_hw=256, instr_len=L, precision=prec, graph=not args.no_graph, frag_weights=not getattr(args, "probe_lds_ring", False))
     tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[prec]
     sets = []
     for k in range(2):
@@ -425,6 +425,7 @@ def main():
     ap.add_argument("--h2d-prestage", action="store_true", help="with --h2d: copy the frames in front of the step on the caller's stream instead of "
                     "handing the pinned host frames to the library (HCM_ACT_HOST_FRAMES: one copy per encoder chain inside the step)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the kernels of a step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--probe-lds-ring", action="store_true", help="configs[3] A/B aid: the cross-modal layer with its weights through the LDS ring (hcm_op_vla_layer) instead of fragment-order weights read into registers")
     ap.add_argument("--configs-leg", type=float, default=1.5, help="N = 1 default run: seconds per configuration of the bounded `configs` block (BASELINE configs[0], [3], [4] "
                     "at their own batch sizes: value, ms_per_step, roofline.frac); 0 = skip")
     ap.add_argument("--host-procs-leg", type=int, default=8, help="N = 1 default run: processes of the `host_8proc` leg (tools/host_procs.py: N processes pinned to 2 cores each, "

@@ -404,6 +404,13 @@ int hcm_op_vla_layer(const void* q, const void* I, const void* const* kv, const 
                      int ld_pool, const void* wo, const float* bo, const void* w1, const float* b1, const void* w2, const float* b2, const float* g1,
                      const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
                      void* stream);
+/* The same layer with its three weight matrices in MFMA-fragment order (hcm_op_pack_frag of the (256, 256), (d_ff, 256) and (256, d_ff) K-contiguous
+ * weights): every wave reads its operand fragments straight from L2 into registers, no weight staging in LDS and no barrier per K tile (round 6;
+ * the form the engine's own step uses).  Bit-identical to hcm_op_vla_layer. */
+int hcm_op_vla_layer_frag(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out,
+                          float* const* pooled, int ld_pool, const void* wo_frag, const float* bo, const void* w1_frag, const float* b1,
+                          const void* w2_frag, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
+                          const int32_t* lens, int dtype, int B, int L, int d_ff, int streams, void* stream);
 /* hcm_op_linear with the kernel family chosen by the caller: impl 0 = the library's choice, 1 = the 128-wide implicit-GEMM kernels,
  * 2 = the 256 x 256-tile 8-phase kernel (csrc/gemm256.hip; HCM_ERR_ARG when the shape does not qualify), 3 = the few-row kernel (csrc/skinny.hip:
  * a wave per 16 x 16 output tile, operands straight into registers; any row count here, the library's own choice takes it up to 160 rows where its

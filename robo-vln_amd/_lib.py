@@ -96,6 +96,7 @@ EXPORTS = {
     "hcm_op_linear": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     "hcm_op_linear_impl": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "hcm_op_vla_layer": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 11 + [C.c_int] * 5 + [C.c_void_p]),
+    "hcm_op_vla_layer_frag": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 11 + [C.c_int] * 5 + [C.c_void_p]),
     "hcm_op_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]),
     "hcm_op_simplecnn3": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p]),
     "hcm_op_pack_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

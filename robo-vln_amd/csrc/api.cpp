@@ -1233,15 +1233,33 @@ int hcm_op_linear_impl(const void* x, const void* w, const float* bias, const vo
     g.impl = impl;
     return op_rc(launch_igemm(g, op_dt(dtype), (hipStream_t)stream));
 }
+static int op_vla_layer(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out, float* const* pooled,
+                        int ld_pool, const void* wo, const float* bo, const void* w1, const float* b1, const void* w2, const float* b2, const float* g1,
+                        const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
+                        void* stream, int wfrag);
 int hcm_op_vla_layer(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out, float* const* pooled,
                      int ld_pool, const void* wo, const float* bo, const void* w1, const float* b1, const void* w2, const float* b2, const float* g1,
                      const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
                      void* stream) {
+    return op_vla_layer(q, I, kv, Lk, att, out, pooled, ld_pool, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, lens, dtype, B, L, d_ff, streams, stream, 0);
+}
+int hcm_op_vla_layer_frag(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out,
+                          float* const* pooled, int ld_pool, const void* wo_frag, const float* bo, const void* w1_frag, const float* b1,
+                          const void* w2_frag, const float* b2, const float* g1, const float* be1, const float* g2, const float* be2,
+                          const int32_t* lens, int dtype, int B, int L, int d_ff, int streams, void* stream) {
+    return op_vla_layer(q, I, kv, Lk, att, out, pooled, ld_pool, wo_frag, bo, w1_frag, b1, w2_frag, b2, g1, be1, g2, be2, lens, dtype, B, L, d_ff, streams,
+                        stream, 1);
+}
+static int op_vla_layer(const void* q, const void* I, const void* const* kv, const int* Lk, const void* const* att, void* const* out, float* const* pooled,
+                        int ld_pool, const void* wo, const float* bo, const void* w1, const float* b1, const void* w2, const float* b2, const float* g1,
+                        const float* be1, const float* g2, const float* be2, const int32_t* lens, int dtype, int B, int L, int d_ff, int streams,
+                        void* stream, int wfrag) {
     if (!I || !out || !wo || !w1 || !w2 || !bo || !b1 || !b2 || !g1 || !be1 || !g2 || !be2 || streams < 1 || streams > 2) return HCM_ERR_ARG;
     if (!vla_post_ok(op_dt(dtype), 256, 4, d_ff)) return HCM_ERR_ARG;
     VlaPost p;
     p.q = q; p.I = I; p.B = B; p.L = L; p.d_ff = d_ff; p.lens = lens; p.streams = streams; p.ld_pool = ld_pool;
     p.wo = wo; p.bo = bo; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.g1 = g1; p.be1 = be1; p.g2 = g2; p.be2 = be2;
+    p.wfrag = wfrag;
     p.fuse_att = kv != nullptr;
     if (p.fuse_att && (!q || !Lk)) return HCM_ERR_ARG;
     if (!p.fuse_att && !att) return HCM_ERR_ARG;

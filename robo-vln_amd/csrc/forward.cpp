@@ -1205,6 +1205,10 @@ struct Fwd {
                 q.q = hb.Q[l]; q.I = I; q.B = B; q.L = L; q.d_ff = c.d_ff; q.lens = ctx->cur_lens;
                 q.wo = ly.o.w; q.bo = ly.o.bias; q.w1 = ly.ff1.w; q.b1 = ly.ff1.bias; q.w2 = ly.ff2.w; q.b2 = ly.ff2.bias;
                 q.g1 = ly.ln_att.gamma; q.be1 = ly.ln_att.beta; q.g2 = ly.ln_ff.gamma; q.be2 = ly.ln_ff.beta;
+                // round 6: the layer's weights in fragment order, read straight into registers (bit-identical; HCM_NO_VLA_WFRAG=1 of the development
+                // build: the LDS weight ring, for the A/B and the toggle test)
+                static const bool no_wfrag = dev_env("HCM_NO_VLA_WFRAG") != nullptr;
+                if (!no_wfrag && ly.o_f && ly.ff1_f && ly.ff2_f) { q.wo = ly.o_f; q.w1 = ly.ff1_f; q.w2 = ly.ff2_f; q.wfrag = 1; }
                 q.fuse_att = l == 0 && S2[0] <= 32 && S2[1] <= 32;
                 for (int st = 0; st < 2; ++st) {
                     const int Lk = l == 0 ? S2[st] : L;

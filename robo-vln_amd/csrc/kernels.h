@@ -242,7 +242,8 @@ struct VlaPost {
     const void* att[2] = {nullptr, nullptr}; // attention output [B][L][256]            (when the attention ran as its own launch)
     void* out[2] = {nullptr, nullptr};       // layer output [B][L][256]
     float* pooled[2] = {nullptr, nullptr};   // mean over the tokens -> pooled[b * ld_pool + c] (only when L <= 80), or null
-    const void *wo = nullptr, *w1 = nullptr, *w2 = nullptr;       // [256][256], [d_ff][256], [256][d_ff]
+    const void *wo = nullptr, *w1 = nullptr, *w2 = nullptr;       // [256][256], [d_ff][256], [256][d_ff] (K contiguous), or all three in fragment order:
+    int wfrag = 0;               // 1: wo / w1 / w2 as launch_pack_frag writes them -- the weights go straight from L2 into registers (vla_post_wf_kernel)
     const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
     const int* lens = nullptr;               // per-environment token counts (ragged batches) or null
     int B = 0, L = 0, Lk[2] = {0, 0}, d_ff = 1024, fuse_att = 0, ld_pool = 0, streams = 2;

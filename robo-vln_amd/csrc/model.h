@@ -83,7 +83,10 @@ struct BertW {
     NormW ln;
     std::vector<BertLayerW> layers;
 };
-struct VlaLayerW { LinW q, kv, o, ff1, ff2; NormW ln_att, ln_ff; };
+struct VlaLayerW {
+    LinW q, kv, o, ff1, ff2; NormW ln_att, ln_ff;
+    void *o_f = nullptr, *ff1_f = nullptr, *ff2_f = nullptr;      // o.w / ff1.w / ff2.w in MFMA-fragment order (16-bit, d_model 256): vla_post_wf_kernel reads its weights straight into registers
+};
 struct VlaW {
     LinW vis_fc, ins_fc;
     NormW ln;

@@ -66,6 +66,11 @@ __device__ __forceinline__ v_v4i v_make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
+// workgroup barrier for the LDS activation buffers only (vla_post_wf_kernel): __syncthreads() would also drain the weight requests in flight
+__device__ __forceinline__ void v_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // (mx: running max |v| of everything this thread rounds to the storage type -- the fp16 range check of the calibration forward; a NaN counts
 //  as +inf.  The x1 rows and the feed-forward intermediate never leave LDS, so no hook outside the kernel can see them.)
 template <typename T> __device__ __forceinline__ void v_st4(char* p, const float (&v)[4], float& mx) {
@@ -108,7 +113,7 @@ __device__ __forceinline__ void v_mma_tile(v_f32x4 (&acc)[2][V_MF], const char* 
 
 // LayerNorm over the 256 channels of every row of the block: a lane holds v[i][j][e] = channel wave*32 + i*16 + fg*4 + e of row j*16 + fr.
 // Per row: sums over the lane's 8 values -> the 4 lane groups (xor 16, 32) -> the 8 waves through sRed; fixed order, no atomics.
-template <typename T>
+template <typename T, bool NB = false>
 __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float4 (&gg)[2], const float4 (&bb)[2], float* sRed, int wave, int fr, int fg) {
 #pragma unroll
     for (int j = 0; j < V_MF; ++j) {
@@ -121,7 +126,7 @@ __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float4
         a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
         if (fg == 0) { sRed[(wave * V_RB + j * 16 + fr) * 2] = a; sRed[(wave * V_RB + j * 16 + fr) * 2 + 1] = q; }
     }
-    __syncthreads();
+    if constexpr (NB) v_lds_barrier(); else __syncthreads();
     float g4[2][4], b4[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -140,7 +145,7 @@ __device__ __forceinline__ void v_layernorm(float (&v)[2][V_MF][4], const float4
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][j][e] = (v[i][j][e] - mean) * rstd * g4[i][e] + b4[i][e];
     }
-    __syncthreads();                 // sRed may be written again
+    if constexpr (NB) v_lds_barrier(); else __syncthreads();                 // sRed may be written again
 }
 
 template <typename T> __device__ __forceinline__ uint32_t v_pack2(float a, float b) {
@@ -450,6 +455,258 @@ __global__ __launch_bounds__(512) void vla_post_kernel(VlaPost p) {
     }
 }
 
+// ---- Round 6: the same layer with its WEIGHTS STRAIGHT FROM L2 INTO REGISTERS (p.wfrag: wo / w1 / w2 in MFMA-fragment order, launch_pack_frag).
+// A wave consumes only ITS 32 output channels of every weight tile, so nothing about the weights is shared between the waves of a workgroup: the
+// LDS ring above was a 32 KB-per-step latency chain behind a workgroup barrier (36 steps of ~0.53 us for 0.15-0.2 us of MFMAs each, every step
+// draining `vmcnt(0)`).  Here a lane reads the 16 bytes of its operand fragment directly (one contiguous 1 KB request per wave and fragment --
+// what a request costs depends on the level it is served from, not on its shape, and these 1.15 MB are L2-resident for every workgroup but the
+// first), half a 256-deep GEMM (8 fragments, 32 VGPRs) per request round into two register sets, the next half requested as soon as the
+// current one's MFMAs are issued; the only barriers left are the ones the ACTIVATION buffers need (2 per FFN slice instead of 8, 12 instead of
+// 40 per launch at d_ff = 1024).  The per-channel vectors of the second half of the layer (b2, LayerNorm 2) wait in LDS instead of 24 VGPRs.
+// Same MFMA instruction over the same k order on the same operands: bit-identical to vla_post_kernel.
+constexpr int V_PV = 3 * V_D * 4;                                   // b2 | g2 | be2 as f32
+constexpr size_t V_LDS_WF = (size_t)2 * V_RB * V_LDA + (size_t)8 * V_RB * 2 * sizeof(float) + V_PV;
+
+typedef uint4 v_half_t[2][2][2];                                    // [k tile of the half][k step][16-channel fragment]
+
+__device__ __forceinline__ uint4 v_ld16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+// fragments (k step ksg0 .. ksg0 + 3) x (two 16-channel tiles from ct0) of a fragment-order matrix with `nct` 16-channel tiles
+__device__ __forceinline__ void v_load_half(v_half_t& R, __amdgpu_buffer_rsrc_t rs, int ksg0, int nct, int ct0, int lane) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned off = (unsigned)((((ksg0 + kt * 2 + ks) * nct + ct0) * 64 + lane) * 16);
+            R[kt][ks][0] = v_ld16(rs, off);
+            R[kt][ks][1] = v_ld16(rs, off + 1024u);
+        }
+}
+template <typename T>
+__device__ __forceinline__ void v_mma_half(v_f32x4 (&acc)[2][V_MF], const v_half_t& R, const char* sAct, int kt0, int fr, int fg) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xf[V_MF];
+#pragma unroll
+            for (int j = 0; j < V_MF; ++j) xf[j] = *reinterpret_cast<const uint4*>(sAct + (j * 16 + fr) * V_LDA + ((kt0 + kt) * 64 + ks * 32 + fg * 8) * 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < V_MF; ++j) VMma<T>::run(acc[i][j], R[kt][ks][i], xf[j]);
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void vla_post_wf_kernel(VlaPost p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                   // attention output, later the FFN intermediate slice, last the output image
+    char* sX = smem + V_RB * V_LDA;                    // x1 = LayerNorm(I + att Wo^T)
+    char* sKV = sX;                                    // K | V of the in-kernel attention (dead before x1 is written)
+    float* sRed = reinterpret_cast<float*>(sX + V_RB * V_LDA);
+    float* sPV = sRed + 8 * V_RB * 2;                  // b2 | g2 | be2
+    const int st = blockIdx.y;
+    const int nblk = (p.L + V_RB - 1) / V_RB;
+    const int b = blockIdx.x / nblk, r0 = (blockIdx.x - b * nblk) * V_RB;
+    const int nrow = p.L - r0 < V_RB ? p.L - r0 : V_RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float cmax = 0.f;
+    const T* q = reinterpret_cast<const T*>(p.q) + ((size_t)b * p.L + r0) * V_D;
+    const T* I = reinterpret_cast<const T*>(p.I) + ((size_t)b * p.L + r0) * V_D;
+    T* out = reinterpret_cast<T*>(p.out[st]) + ((size_t)b * p.L + r0) * V_D;
+    const int nb = wave * 32;
+    const int nslice = p.d_ff / 256;
+    const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wo), 0, 256 * 256 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, p.d_ff * 256 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, 256 * p.d_ff * 2, 0x00020000);
+    const int nct1 = p.d_ff / 16;
+
+    v_half_t R0, R1;
+    v_load_half(R0, r_o, 0, 16, 2 * wave, lane);       // fc_o travels while the attention runs
+    v_load_half(R1, r_o, 4, 16, 2 * wave, lane);
+    float4 p_bo[2], p_g1[2], p_be1[2], p_b1[2];
+    uint2 p_res[2][V_MF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = nb + i * 16 + fg * 4;
+        p_bo[i] = *reinterpret_cast<const float4*>(p.bo + n);
+        p_g1[i] = *reinterpret_cast<const float4*>(p.g1 + n); p_be1[i] = *reinterpret_cast<const float4*>(p.be1 + n);
+        p_b1[i] = *reinterpret_cast<const float4*>(p.b1 + n);
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) {
+            const int row = j * 16 + fr;
+            p_res[i][j] = make_uint2(0u, 0u);
+            if (row < nrow) p_res[i][j] = *reinterpret_cast<const uint2*>(I + (size_t)row * V_D + n);
+        }
+    }
+    if (tid < 192) {
+        const float* src = tid < 64 ? p.b2 + tid * 4 : tid < 128 ? p.g2 + (tid - 64) * 4 : p.be2 + (tid - 128) * 4;
+        *reinterpret_cast<float4*>(sPV + tid * 4) = *reinterpret_cast<const float4*>(src);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- attention output of the block into sA (rows >= nrow: zeros)
+    if (p.fuse_att) {
+        const int Lk = p.Lk[st];
+        const T* kv = reinterpret_cast<const T*>(p.kv[st]) + (size_t)b * Lk * 512;
+        v_attention_mfma<T>(q, kv, Lk, nrow, sKV, reinterpret_cast<T*>(sKV + 4 * 32 * 128), sA, tid);
+    } else {
+        const T* att = reinterpret_cast<const T*>(p.att[st]) + ((size_t)b * p.L + r0) * V_D;
+        for (int e = tid; e < V_RB * 32; e += 512) {
+            const int row = e >> 5, c = e & 31;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < nrow) v = *reinterpret_cast<const uint4*>(att + (size_t)row * V_D + c * 8);
+            *reinterpret_cast<uint4*>(sA + row * V_LDA + c * 16) = v;
+        }
+    }
+    v_lds_barrier();
+
+    float v[2][V_MF][4];
+    // ---- x1 = LayerNorm(I + att Wo^T + bo)
+    {
+        v_f32x4 acc[2][V_MF];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < V_MF; ++j) acc[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
+        v_mma_half<T>(acc, R0, sA, 0, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R0, r_1, 0, nct1, 2 * wave, lane);                 // fc1 of slice 0
+        __builtin_amdgcn_sched_barrier(0);
+        v_mma_half<T>(acc, R1, sA, 2, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R1, r_1, 4, nct1, 2 * wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 bb = p_bo[i];
+#pragma unroll
+            for (int j = 0; j < V_MF; ++j) {
+                float r4[4];
+                v_ld4<T>(reinterpret_cast<const char*>(&p_res[i][j]), r4);
+                v[i][j][0] = acc[i][j][0] + bb.x + r4[0]; v[i][j][1] = acc[i][j][1] + bb.y + r4[1];
+                v[i][j][2] = acc[i][j][2] + bb.z + r4[2]; v[i][j][3] = acc[i][j][3] + bb.w + r4[3];
+            }
+        }
+    }
+    v_layernorm<T, true>(v, p_g1, p_be1, sRed, wave, fr, fg);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) v_st4<T>(sX + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, v[i][j], cmax);
+    v_lds_barrier();                                   // x1 complete; every wave is past its reads of sA (the LayerNorm's barriers)
+
+    // ---- FFN in 256-column slices of the intermediate: H_c = relu(x1 W1[c]^T + b1[c]) (-> sA), acc2 += H_c W2[:, c]^T
+    v_f32x4 acc2[2][V_MF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) acc2[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nslice; ++c) {
+        v_f32x4 acc1[2][V_MF];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < V_MF; ++j) acc1[i][j] = (v_f32x4){0.f, 0.f, 0.f, 0.f};
+        v_mma_half<T>(acc1, R0, sX, 0, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R0, r_2, 8 * c, 16, 2 * wave, lane);               // fc2's k range of this slice
+        __builtin_amdgcn_sched_barrier(0);
+        v_mma_half<T>(acc1, R1, sX, 2, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R1, r_2, 8 * c + 4, 16, 2 * wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the last slice requests its own fc1 rows / bias again instead of branching: a conditional request makes hipcc's vmcnt counts at the
+        //  merge conservative, which turns the wait for the OLDER register set into a wait for the one just requested)
+        const int cn = c + 1 < nslice ? c + 1 : c;
+        float4 b1c[2] = {p_b1[0], p_b1[1]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p_b1[i] = *reinterpret_cast<const float4*>(p.b1 + cn * 256 + nb + i * 16 + fg * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 bb = b1c[i];
+#pragma unroll
+            for (int j = 0; j < V_MF; ++j) {
+                const float h[4] = {relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y), relu_f(acc1[i][j][2] + bb.z),
+                                    relu_f(acc1[i][j][3] + bb.w)};
+                v_st4<T>(sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2, h, cmax);
+            }
+        }
+        v_lds_barrier();                               // H_c complete
+        v_mma_half<T>(acc2, R0, sA, 0, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R0, r_1, 0, nct1, 16 * cn + 2 * wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        v_mma_half<T>(acc2, R1, sA, 2, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        v_load_half(R1, r_1, 4, nct1, 16 * cn + 2 * wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        v_lds_barrier();                               // sA free: the next slice's H, or the output image
+    }
+    // ---- out = LayerNorm(x1 + ffn + b2)
+    float4 p_b2[2], p_g2[2], p_be2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = nb + i * 16 + fg * 4;
+        p_b2[i] = *reinterpret_cast<const float4*>(sPV + n);
+        p_g2[i] = *reinterpret_cast<const float4*>(sPV + V_D + n);
+        p_be2[i] = *reinterpret_cast<const float4*>(sPV + 2 * V_D + n);
+        const float4 bb = p_b2[i];
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) {
+            float r4[4];
+            v_ld4<T>(sX + (j * 16 + fr) * V_LDA + n * 2, r4);
+            v[i][j][0] = acc2[i][j][0] + bb.x + r4[0]; v[i][j][1] = acc2[i][j][1] + bb.y + r4[1];
+            v[i][j][2] = acc2[i][j][2] + bb.z + r4[2]; v[i][j][3] = acc2[i][j][3] + bb.w + r4[3];
+        }
+    }
+    v_layernorm<T, true>(v, p_g2, p_be2, sRed, wave, fr, fg);
+    int len = p.L;
+    if (p.lens) { len = p.lens[b]; len = len < 1 ? 1 : len > p.L ? p.L : len; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < V_MF; ++j) {
+            char* dst = sA + (j * 16 + fr) * V_LDA + (nb + i * 16 + fg * 4) * 2;
+            v_st4<T>(dst, v[i][j], cmax);
+            if (p.pooled[st] && r0 + j * 16 + fr < len) {
+                float r4[4];
+                v_ld4<T>(dst, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs[e] += r4[e];
+            }
+        }
+        if (p.pooled[st]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = cs[e];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                cs[e] = t;
+            }
+            if (fr == 0) {
+                float* dst = p.pooled[st] + (size_t)b * p.ld_pool + nb + i * 16 + fg * 4;
+                const float invl = 1.0f / (float)len;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e] = cs[e] * invl;
+            }
+        }
+    }
+    v_lds_barrier();
+    for (int e = tid; e < nrow * 32; e += 512) {
+        const int row = e >> 5, c = e & 31;
+        *reinterpret_cast<uint4*>(out + (size_t)row * V_D + c * 8) = *reinterpret_cast<const uint4*>(sA + row * V_LDA + c * 16);
+    }
+    if (p.calib) {
+        const float m = wave_max(cmax);
+        if (lane == 0) {
+            if (m <= 3.0e38f) atomicMax(p.calib, __float_as_uint(m));
+            else atomicAdd(p.calib + 1, 1u);
+        }
+    }
+}
+
 bool vla_post_ok(int dt, int d_model, int heads, int d_ff) {
     return (dt == DT_BF16 || dt == DT_F16) && d_model == V_D && heads == 4 && d_ff >= 256 && d_ff % 256 == 0;
 }
@@ -462,10 +719,13 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
     // the pooled mean is complete inside one workgroup only when the block covers the whole instruction
     if ((p.pooled[0] || p.pooled[1]) && p.L > V_RB) return hipErrorInvalidValue;
     const void* fn = dt == DT_BF16 ? reinterpret_cast<const void*>(vla_post_kernel<bf16>) : reinterpret_cast<const void*>(vla_post_kernel<f16>);
+    if (p.wfrag) fn = dt == DT_BF16 ? reinterpret_cast<const void*>(vla_post_wf_kernel<bf16>) : reinterpret_cast<const void*>(vla_post_wf_kernel<f16>);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_wf_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vla_post_wf_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_once.done();
     }
     VlaPost q = p;
@@ -477,7 +737,7 @@ hipError_t launch_vla_post(const VlaPost& p, int dt, hipStream_t s) {
 #endif
     void* args[] = {&q};
     const int nblk = (p.L + V_RB - 1) / V_RB;
-    return hipLaunchKernel(fn, dim3(p.B * nblk, p.streams), dim3(512), args, V_LDS, s);
+    return hipLaunchKernel(fn, dim3(p.B * nblk, p.streams), dim3(512), args, p.wfrag ? V_LDS_WF : V_LDS, s);
 }
 
 }  // namespace hcm

@@ -281,6 +281,20 @@ static void* make_conv_frag(int dt, Uploader& up, const HostTensor& w) {
     return up.typed(fo, dt);
 }
 
+// a linear layer's [N][K] weight in MFMA-FRAGMENT order (device twin: pack_frag_kernel, bert_block.hip): the 16-byte chunk W[ct*16 + fr][ks*32 + fg*8 ..]
+// at chunk index (ks*(N/16) + ct)*64 + fg*16 + fr -- the 1 KB a wave loads for one operand fragment is contiguous.  N % 16 == 0, K % 32 == 0.
+static void* make_linear_frag(int dt, Uploader& up, const HostTensor& w) {
+    const int N = (int)w.shape[0], K = (int)w.shape[1];
+    if (N % 16 || K % 32) return nullptr;
+    std::vector<float> fo((size_t)N * K);
+    for (int ks = 0; ks < K / 32; ++ks)
+        for (int ct = 0; ct < N / 16; ++ct)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e)
+                    fo[(((size_t)ks * (N / 16) + ct) * 64 + l) * 8 + e] = w.f[(size_t)(ct * 16 + (l & 15)) * K + ks * 32 + (l >> 4) * 8 + e];
+    return up.typed(fo, dt);
+}
+
 // eval-mode BatchNorm2d folded into the preceding bias-free conv: y = conv(x)*g/sqrt(v+eps) + (b - m*g/sqrt(v+eps))
 static void bn_fold(hcm_ctx* ctx, int model, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& bias, bool stem = false);
 static ConvW make_conv_bn(hcm_ctx* ctx, int dt, Uploader& up, int model, const std::string& wkey, const std::string& bn, bool stem = false) {
@@ -854,6 +868,11 @@ void prepare_high(hcm_ctx* ctx) {
         L.ff1 = make_linear(up, {&T_(ctx, M, p + "pwff.fc1.weight")}, {&T_(ctx, M, p + "pwff.fc1.bias")}, ctx->dt_vla);
         L.ff2 = make_linear(up, {&T_(ctx, M, p + "pwff.fc2.weight")}, {&T_(ctx, M, p + "pwff.fc2.bias")}, ctx->dt_vla);
         L.ln_ff = make_norm(ctx, up, M, p + "pwff.layer_norm");
+        if ((ctx->dt_vla == DT_F16 || ctx->dt_vla == DT_BF16) && c.d_model == 256 && c.d_ff % 256 == 0) {
+            L.o_f = make_linear_frag(ctx->dt_vla, up, T_(ctx, M, a + "fc_o.weight"));
+            L.ff1_f = make_linear_frag(ctx->dt_vla, up, T_(ctx, M, p + "pwff.fc1.weight"));
+            L.ff2_f = make_linear_frag(ctx->dt_vla, up, T_(ctx, M, p + "pwff.fc2.weight"));
+        }
         v.layers.push_back(L);
     }
     {

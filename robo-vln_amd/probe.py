@@ -35,12 +35,13 @@ class DepthCnnVlaProbe:
     """cnn_sd: SimpleDepthCNN state_dict (keys cnn.{0,2,4,7}.{weight,bias}); vla_sd: Visual_Ling_Attn state_dict (N = 1)."""
 
     def __init__(self, cnn_sd, vla_sd, depth_hw=256, instr_len=80, heads=4, precision="fp16", device="cuda", graph=False, fused_layer=True, overlap=True,
-                 fused_cnn=True):
+                 fused_cnn=True, frag_weights=True):
         """graph=True: forward() is captured once per batch size into a hipGraph (torch.cuda.CUDAGraph over the library's launches on
         the capture stream) with engine-owned static input / output buffers, and replayed: the ~16 dependent launches then cost one."""
         self._graph = bool(graph)
         self._unfused = not fused_layer                 # launch-per-op cross-modal layer (A/B and test aid)
         self._fused_cnn = bool(fused_cnn)               # the three convolutions in one launch (hcm_op_simplecnn3); False: launch per conv (A/B and test aid)
+        self._frag_weights = bool(frag_weights)         # fused layer: weights in fragment order, read straight into registers (hcm_op_vla_layer_frag); False: LDS ring
         self._overlap = bool(overlap)                   # instruction branch on a second stream
         self._side = torch.cuda.Stream() if overlap else None
         self._graphs = {}
@@ -90,6 +91,13 @@ class DepthCnnVlaProbe:
         self.f1, self.f2 = lin("layers.0.pwff.fc1"), lin("layers.0.pwff.fc2")
         self.ln_ff = (F32(g(vla_sd, "layers.0.pwff.layer_norm.weight")), F32(g(vla_sd, "layers.0.pwff.layer_norm.bias")))
         self.pe = F32(sinusoid_table(instr_len, d))
+        self.wf = None
+        d_ff = self.f1[0].shape[0]
+        if self._frag_weights and self.tdt != torch.float32 and d == 256 and d_ff % 256 == 0:
+            self.wf = tuple(torch.empty_like(w) for w in (self.fo[0], self.f1[0], self.f2[0]))
+            for src, dst, (N, K) in zip((self.fo[0], self.f1[0], self.f2[0]), self.wf, ((d, d), (d_ff, d), (d, d_ff))):
+                self._ck(self.lib.hcm_op_pack_frag(_p(src), _p(dst), self.code, N, K, None))
+            torch.cuda.synchronize()
 
     def _ck(self, rc):
         if rc != 0:
@@ -195,8 +203,10 @@ class DepthCnnVlaProbe:
             # attention + fc_o + LayerNorm + feed-forward + LayerNorm: one launch (csrc/vla_fused.hip, the model path's kernel)
             out = e(rows, self.d)
             arr = lambda *v: (C.c_void_p * len(v))(*v)
-            self._ck(lib.hcm_op_vla_layer(_p(I), _p(I), arr(kv.data_ptr()), (C.c_int * 1)(1), None, arr(out.data_ptr()), None, 0,
-                                          _p(self.fo[0]), _p(self.fo[1]), _p(self.f1[0]), _p(self.f1[1]), _p(self.f2[0]), _p(self.f2[1]),
+            fn = lib.hcm_op_vla_layer_frag if self.wf is not None else lib.hcm_op_vla_layer
+            wo, w1, w2 = self.wf if self.wf is not None else (self.fo[0], self.f1[0], self.f2[0])
+            self._ck(fn(_p(I), _p(I), arr(kv.data_ptr()), (C.c_int * 1)(1), None, arr(out.data_ptr()), None, 0,
+                                          _p(wo), _p(self.fo[1]), _p(w1), _p(self.f1[1]), _p(w2), _p(self.f2[1]),
                                           _p(self.ln_att[0]), _p(self.ln_att[1]), _p(self.ln_ff[0]), _p(self.ln_ff[1]), None,
                                           code, B, self.L, d_ff, 1, self._st()))
             return out.reshape(B, self.L, self.d)

@@ -109,6 +109,26 @@ def test_fused_cross_modal_layer_equals_the_launch_per_op_form(env):
         assert err <= 8e-3, (k, err)      # measured: 1e-4 .. 4e-3 (three layers of bf16 LayerNorm outputs, one ulp = 4e-3 at 1.0)
 
 
+@pytest.mark.parametrize("env", [
+    {},
+    {"HCMT_VLA_LAYERS": "3", "HCMT_L": "37"},
+    {"HCMT_VLA_LAYERS": "2", "HCMT_L": "100"},
+    {"HCMT_VLA_LAYERS": "2", "HCMT_L": "48", "HCMT_RAGGED": "1"},
+    {"HCMT_DEPTH_HW": "256", "HCMT_L": "80", "HCMT_PREC": "bf16"},
+])
+def test_cross_modal_layer_weights_into_registers_equals_the_lds_ring(env):
+    """Round 6: vla_post_wf_kernel (the layer's weights in fragment order, every wave reading its operand fragments straight from L2 into two
+    register sets; barriers only where the activation buffers change hands) against vla_post_kernel (weights through a 2 x 32 KB LDS ring behind a
+    barrier per K tile, HCM_NO_VLA_WFRAG=1): the same MFMA instruction over the same k order on the same operands, the same LayerNorm reduction
+    order -- the whole step agrees to the bit."""
+    with tempfile.TemporaryDirectory() as d:
+        a = _run(dict(env), os.path.join(d, "a.npz"))
+        b = _run(dict(env, HCM_NO_VLA_WFRAG="1"), os.path.join(d, "b.npz"))
+    assert np.isfinite(a["rec"]).all()
+    for k in ("rec", "hh", "lh"):
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_depth_layer3_run_equals_the_launch_per_conv_form():
     """depth_l3_kernel (igemm.hip): the five identity bottlenecks of the depth trunk's layer3 on its 8 x 8 map as one launch, against the fifteen
     conv + fused-GroupNorm launches it replaces: the same MFMA products in the same k order, the GroupNorm statistics summed in a different

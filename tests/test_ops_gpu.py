@@ -895,6 +895,22 @@ def test_fused_cross_modal_layer_op(prec, B, L, Lk, fuse, ragged):
                               _p(Wd["b2"]), _p(Wd["g1"]), _p(Wd["be1"]), _p(Wd["g2"]), _p(Wd["be2"]), _p(lens.cuda()) if ragged else None, code, B, L, dff, 2, None)
     assert rc == 0
     torch.cuda.synchronize()
+    # the same layer with its weights in fragment order, read straight into registers (hcm_op_vla_layer_frag, round 6): bit-identical
+    Wf = {}
+    for k, (N, K) in (("wo", (d, d)), ("w1", (dff, d)), ("w2", (d, dff))):
+        Wf[k] = torch.empty_like(Wd[k])
+        assert lib.hcm_op_pack_frag(_p(Wd[k]), _p(Wf[k]), code, N, K, None) == 0
+    outs_f = [torch.full((B, L, d), float("nan"), device="cuda", dtype=tdt) for _ in range(2)]
+    pooled_f = [torch.full((B, 300), float("nan"), device="cuda") for _ in range(2)] if L <= 80 else None
+    rc = lib.hcm_op_vla_layer_frag(_p(qd), _p(Id), arr(ins) if fuse else None, (C.c_int * 2)(*Lk) if fuse else None, None if fuse else arr(ins), arr(outs_f),
+                                   arr([p[:, 17:] for p in pooled_f]) if pooled_f else None, 300, _p(Wf["wo"]), _p(Wd["bo"]), _p(Wf["w1"]), _p(Wd["b1"]), _p(Wf["w2"]),
+                                   _p(Wd["b2"]), _p(Wd["g1"]), _p(Wd["be1"]), _p(Wd["g2"]), _p(Wd["be2"]), _p(lens.cuda()) if ragged else None, code, B, L, dff, 2, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for s_ in range(2):
+        assert torch.equal(outs_f[s_].view(torch.int16), outs[s_].view(torch.int16)), s_
+        if pooled:
+            assert torch.equal(pooled_f[s_][:, 17:17 + d], pooled[s_][:, 17:17 + d]) and torch.isnan(pooled_f[s_][:, :17]).all() and torch.isnan(pooled_f[s_][:, 17 + d:]).all()
     for s_ in range(2):
         y, pm = refs[s_]
         err = (outs[s_].float().cpu() - y).abs().max().item()
