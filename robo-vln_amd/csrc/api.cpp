@@ -1201,12 +1201,10 @@ int hcm_op_linear(const void* x, const void* w, const float* bias, const void* r
                   int act, int out_f32, void* stream) {
     // skinny long-K layers (M = batch rows behind a Flatten: SimpleCNN's 25088-wide FC) are split along K exactly as the model path does
     // (forward.cpp: Fwd::linear): grouped launch over K slices into f32 partials, fixed-order reduction with bias + activation
-    if (!residual && M <= 256 && K >= 2048) {
-        const int CHw = dtype == HCM_F32 ? 4 : 8;
-        int S = 1;
-        const long blocks = (long)((M + 63) / 64) * ((N + 31) / 32);
-        while (S < 16 && blocks * S < 256 && K % (2 * S * 64) == 0 && K / (2 * S) >= 256) S *= 2;
-        if (K % (S * CHw)) S = 1;
+    {
+        int S = splitk_slices(M, N, K, dtype == HCM_F32 ? 4 : 8, residual != nullptr);
+        static const int force_s = dev_env("HCM_SPLITK_FORCE") ? atoi(dev_env("HCM_SPLITK_FORCE")) : 0;      // (development build: timing experiments)
+        if (force_s > 0 && !residual && K % (force_s * 64) == 0) S = force_s;
         if (S > 1) {
             float* part = (float*)op_scratch((size_t)S * M * N * 4);
             if (!part) return HCM_ERR_NOMEM;

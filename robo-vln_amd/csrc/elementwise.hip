@@ -1189,7 +1189,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
         const int n = (int)(e % N);
         const size_t m = e / N;
         float a = bias ? bias[n] : 0.f;
-        for (int s_ = 0; s_ < S; ++s_) a += part[(size_t)s_ * total + e];
+        // the same left-to-right sum, eight independent requests at a time (as a plain loop the S loads were one latency chain: 25 us at 56 slices)
+        int s_ = 0;
+        for (; s_ + 8 <= S; s_ += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s_ + j) * total + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += v[j];
+        }
+        for (; s_ < S; ++s_) a += part[(size_t)s_ * total + e];
         if (act == ACT_RELU) a = relu_f(a);
         else if (act == ACT_GELU) a = gelu_erf(a);
         if (out_f32) reinterpret_cast<float*>(y)[m * ldy + n] = a;

@@ -213,13 +213,8 @@ struct Fwd {
                 const void* res = nullptr, int ldr = 0, int wdt = -1, const LnFold* lf = nullptr) {
         const int wd = wdt < 0 ? w.dt : wdt;
         const int CHw = wd == DT_F32 ? 4 : 8;
-        int S = 1;
         static const bool no_split = dev_env("HCM_NO_SPLITK") != nullptr;
-        if (!no_split && !res && M <= 256 && w.K >= 2048) {
-            const long blocks = (long)((M + 63) / 64) * ((w.N + 31) / 32);
-            while (S < 16 && blocks * S < 256 && w.K % (2 * S * 64) == 0 && w.K / (2 * S) >= 256) S *= 2;
-            if (w.K % (S * CHw)) S = 1;
-        }
+        const int S = no_split ? 1 : splitk_slices(M, w.N, w.K, CHw, res != nullptr);
         float* part = S > 1 ? alloc_f((size_t)S * M * w.N) : nullptr;       // allocated in the dry run too
         if (dry) return;
         IGemm g;

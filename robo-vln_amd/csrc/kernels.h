@@ -271,6 +271,18 @@ hipError_t launch_lstm_cell(const float* gates, const float* h_in, const float* 
 hipError_t launch_gru_cell(const float* gi, const float* gh, const float* h_in, const float* mask, float* h_out,
                            int B, int Hd, const Heads& heads, hipStream_t s);
 // split-K: fixed-order sum of S f32 partial results [S][M][N] + bias + activation (see Fwd::linear)
+// How many K slices a skinny long-K linear layer is cut into (forward.cpp Fwd::linear and hcm_op_linear use the same rule, so an operator call
+// reproduces the model path bit for bit): powers of two while the (64 x 32-tile) grid stays under 256 workgroups and a slice keeps >= 256 columns
+// in whole 64-column K tiles.  (Round 6 tried one odd factor on top where the doubling stops on divisibility -- SimpleCNN's 25088 = 2^9 x 49
+// columns stop at 8 slices -- and measured the GEMM at 15-19 us for 8, 14, 28 and 56 slices alike: it is not a per-workgroup chain, DESIGN_LOG R6.14.)
+static inline int splitk_slices(int M, int N, int K, int CHw, bool has_res) {
+    int S = 1;
+    if (has_res || M > 256 || K < 2048) return 1;
+    const long blocks = (long)((M + 63) / 64) * ((N + 31) / 32);
+    while (S < 16 && blocks * S < 256 && K % (2 * S * 64) == 0 && K / (2 * S) >= 256) S *= 2;
+    if (K % (S * CHw)) S = 1;
+    return S;
+}
 hipError_t launch_splitk_reduce(const float* part, const float* bias, void* y, int dt, int S, int M, int N, int ldy, int act, int out_f32,
                                 hipStream_t s);
 // CMANet (models/cma.py) pieces: instruction embedding + lengths, one packed-LSTM time step, single-query attention

@@ -91,6 +91,32 @@ def test_linear(prec, mnk, act):
         assert err <= (tol if not out_f32 or prec == "fp32" else 2e-3) * max(1.0, ref.abs().max().item()), (err, out_f32)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("mnk", [(256, 128, 25088), (3, 128, 25088), (64, 256, 25088), (256, 128, 4608), (200, 512, 15360), (5, 128, 6400), (256, 128, 2048)])
+def test_linear_long_k_split_along_k(prec, mnk):
+    """Skinny long-K linear layers (the projections behind a Flatten: SimpleCNN's 25088-wide FC, simple_cnns.py:51-101; the encoders' own
+    linear layers at M = batch rows) are cut into K slices summed in a fixed order (kernels.h splitk_slices; forward.cpp Fwd::linear uses the same
+    rule; the reduction requests eight partials at a time since round 6, same left-to-right sum): K = 2^9 x 49, 2^10 x 15, 2^8 x 25, 2^9 x 9, 2^11.
+    Against x @ W^T in float64 on the rounded operands; run to run bit equality (fixed order)."""
+    lib, L = _lib()
+    code, tdt, tol = DT[prec]
+    M, N, K = mnk
+    x = _rnd(M, K).to(tdt).float()
+    w = (_rnd(N, K, seed=1) * (3.0 / K) ** 0.5).to(tdt).float()
+    b = _rnd(N, seed=2)
+    ref = F.relu(x.double() @ w.double().t() + b.double()).float()
+    xd, wd, bd = x.to("cuda", tdt), w.to("cuda", tdt), b.to("cuda")
+    ys = []
+    for rep in range(2):
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+        assert lib.hcm_op_linear(_p(xd), _p(wd), _p(bd), None, _p(y), code, M, N, K, 1, 1, None) == 0
+        torch.cuda.synchronize()
+        ys.append(y.cpu())
+    assert torch.equal(ys[0], ys[1])
+    err = (ys[0] - ref).abs().max().item()
+    assert err <= (2e-4 if prec != "fp32" else 5e-4) * max(1.0, ref.abs().max().item()), err        # f32 accumulation of exactly representable products
+
+
 @pytest.mark.parametrize("impl", [1, 2])
 def test_gelu_epilogue_accuracy(impl):
     """The 16-bit paths' erf-GELU (csrc/dev.h gelu_fast / gelu_vec: Abramowitz-Stegun 7.1.28, one v_rcp + packed FMAs) seen by itself:
